@@ -1,0 +1,72 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def rel_err(a, b):
+    """max |a-b| / (|b| + mean|b|) over the tensor; NaN==NaN and inf==inf count as equal.
+    The mean-|b| floor is the tolerance convention of this repo ('Parity tolerances')."""
+    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    fin = torch.isfinite(b)
+    scale = b[fin].abs().mean() if fin.any() else torch.tensor(1.0, dtype=torch.float64)
+    e = (a - b).abs() / (b.abs() + scale + 1e-30)
+    e = torch.where(same, torch.zeros_like(e), e)
+    return float(torch.nan_to_num(e, nan=float("inf")).max())
+
+
+def bad_frac(a, b, tol):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    if a.numel() == 0:
+        return 0.0
+    same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    fin = torch.isfinite(b)
+    scale = b[fin].abs().mean() if fin.any() else torch.tensor(1.0, dtype=torch.float64)
+    e = (a - b).abs() / (b.abs() + scale + 1e-30)
+    e = torch.where(same, torch.zeros_like(e), e)
+    return float((torch.nan_to_num(e, nan=float("inf")) > tol).double().mean())
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def synth_weights():
+    from robir_amd import synth
+    sd = synth.synth_state_dict(0, variance=0.3)
+    return sd
+
+
+@pytest.fixture(scope="session")
+def oracle_sd(synth_weights):
+    from robir_oracle import nets
+    return nets.as_torch(synth_weights)
+
+
+@pytest.fixture(scope="session")
+def oracle_octree(oracle_sd):
+    """Octree built by the oracle from the synthetic SDF (about 5-10 s on 8 cores)."""
+    from robir_oracle import nets, octree
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    return octree.build(lambda x: nets.implicit_forward(oracle_sd, x)[:, 0],
+                        lambda x: nets.implicit_gradient(oracle_sd, x), [-1.0] * 3, [1.0] * 3)
