@@ -1,0 +1,93 @@
+/* robir_hip.h -- C ABI of librobir_hip.so: hand-written gfx950 (MI355X) kernels for RobIR's per-ray forward
+ * renderer hot path.
+ *
+ * Conventions ("C-ABI layer"):
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / a torch tensor's data_ptr()) unless marked HOST;
+ *   - tensors are dense row-major fp32 unless stated; masks are uint8 (0/1); indices are int32 / int64 as declared;
+ *   - the library never allocates, never synchronises and keeps no state: workspaces are caller-provided,
+ *     kernels are enqueued on the given stream (rb_stream_t == hipStream_t, 0 = default stream);
+ *   - every entry point returns 0 on success, non-zero on error (text via rb_last_error(), thread local)
+ *     and never throws.
+ *
+ * Each group cites the reference interface (ingra14m/RobIR, file:line) it replaces.  The reference has no FFI
+ * of its own for this path (it is pure PyTorch); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ */
+#ifndef ROBIR_HIP_H
+#define ROBIR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_ABI_VERSION 1
+
+typedef void* rb_stream_t; /* hipStream_t */
+
+int rb_abi_version(void);
+const char* rb_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight packing.  A network is handed to the MLP kernels as the concatenation of its packed layers.
+ * Packed layer (n_pad, k_pad multiples of 16) = n_pad/16 chunks of (16 + 16*k_pad) floats:
+ *   [bias of the 16 neurons] [kb][lane 0..63][r 0..3] = W[16*jb + (lane&15)][16*kb + 4*(lane>>4) + r]
+ * i.e. exactly the A-operand order of v_mfma_f32_16x16x4_f32 (robir_amd/csrc/mlp_engine.h).
+ * Replaces: nn.Linear / weight_norm parameter storage, model/neus_model.py:350-381,
+ *           model/implicit_differentiable_renderer.py:186-193,241-248, model/sg_envmap_material.py:52-68.
+ * k_perm (device int32[k_pad], may be NULL): packed input column k reads source column k_perm[k] (-1: zero).
+ * ------------------------------------------------------------------------------------------------------------ */
+long rb_packed_layer_floats(int n_pad, int k_pad);
+int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
+                  float w_scale, float* out, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Feature construction (positional encodings), accurate sinf/cosf.
+ * Replaces: model/embedder.py:7-55 (get_embedder), model/neus_model.py:14-57,71-91 (IPE).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* X[M,128] = [PE10(p) | PE10(d) | 0 0]                                   VisNetwork input */
+int rb_feat_vis(const float* p, const float* d, long M, float* X, rb_stream_t stream);
+/* X[M,64] = [PE10(x*scale) | extra[M] or 0];  jvp!=0: X[4M,64] with rows (PE, dPE/dx, dPE/dy, dPE/dz) per point */
+int rb_feat_pe10(const float* x, long M, float scale, const float* extra, int jvp, float* X, rb_stream_t stream);
+/* X[M,64] = full-covariance IPE(x, var*I) (60) [+ noise[M,60]*noise_scale] | 0 x4 */
+int rb_feat_ipe(const float* x, long M, float var, const float* noise, float noise_scale, float* X,
+                rb_stream_t stream);
+/* X[M,304] = [feat[M,256 @feat_stride]*feat_scale | x*x_scale | PE4(view) | normal | 0 x15]   colour-net input */
+int rb_feat_color(const float* x, float x_scale, const float* view, const float* normal, const float* feat,
+                  long feat_stride, float feat_scale, long M, float* X, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused MLPs (fp32 MFMA, activations resident in registers across all layers).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* VisNetwork.forward (implicit_differentiable_renderer.py:250-258): X[M,128] -> logits[M,2].
+ * Wp: packed [128->256, 256->256 x3, 256->16]. */
+int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream);
+/* One linear layer X[M,64] -> Y[M,256] (packed 64->256); used to factor the visibility net's first layer. */
+int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream);
+/* SDFNetwork.forward / .gradient (model/neus_model.py:385-438), ImplicitNetworkMy.forward/.gradient (:788-818).
+ * X from rb_feat_pe10 (jvp rows for modes 2,3).  Wp packed [64->256, 256->256 x2, 256->208, 272->256, 256->256 x3,
+ * 256->272] (modes 1,3) or [... , 256->16] (modes 0,2).
+ * mode 0: out0[M] = sdf*out_scale          mode 1: out0[M,257] = (sdf,feat)*out_scale
+ * mode 2: + grad[M,3] = d sdf/d(x*scale) * grad_scale (forward-mode), out0[M]      mode 3: same with out0[M,257] */
+int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
+               float* grad, rb_stream_t stream);
+/* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
+ * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
+int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);
+/* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
+ * Wp packed [64->512, 512->512 x3, 512->144]. */
+int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream);
+/* raw[M,24,6] -> lgt_sgs[M,24,7] (implicit_differentiable_renderer.py:208-218). */
+int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
+/* SparseAE (model/sg_envmap_material.py:40-99): encoder X[M,64] -> raw latent[M,32]
+ * (packed [64->512, 512->512 x3, 512->32]); latent = act(raw*(1-var)) [+ lat2 = latent + noise*noise_scale];
+ * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus. */
+int rb_ae_encode(const float* X, long M, const float* Wp, float* raw_latent, rb_stream_t stream);
+int rb_ae_latent(const float* raw, long M, const float* var, int act, const float* noise, float noise_scale, float* lat,
+                 float* lat2, rb_stream_t stream);
+int rb_ae_decode(const float* lat, long M, const float* Wp, int n_out, int sigmoid_out, float* Y, rb_stream_t stream);
+/* y = a + s*b (n floats) */
+int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBIR_HIP_H */

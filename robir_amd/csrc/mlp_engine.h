@@ -1,0 +1,209 @@
+// Wave-resident fp32 MLP engine for gfx950 (MI355X, CDNA4).
+//
+// Every small MLP on RobIR's per-ray hot path (visibility, SDF, colour, indirect illumination, the sparse
+// auto-encoders) is evaluated "transposed":  H_out^T = W . H_in^T  with  v_mfma_f32_16x16x4_f32
+//   A operand  = weights      lane l holds W[16*jb + (l&15)][16*kb + 4*(l>>4) + r]        (r = MFMA step 0..3)
+//   B operand  = activations  lane l holds h_in[sample (l&15)][16*kb + 4*(l>>4) + r]
+//   C/D        = lane l, reg r holds h_out[sample (l&15)][16*jb + 4*(l>>4) + r]
+// so the accumulator registers of one layer ARE the B operands of the next: activations of a tile of
+// 16 samples never leave the register file between the first and the last layer (no LDS / HBM round trip),
+// and the K reduction is an exact fp32 fma chain (f32-input MFMA, bitwise an fmaf loop).
+//
+// A wave owns NT tiles of 16 samples (NT=2 for 256-wide nets: 2 independent accumulator chains hide the
+// 40-cycle dependent MFMA latency and each weight register feeds 2 MFMAs; NT=1 for 512-wide nets, where the
+// two chains come from splitting K by block parity).  A workgroup is 4 waves (one per SIMD, up to 512 VGPRs
+// each) that consume the same weight stream in lock step: weights are pre-packed on the host side of the C-ABI
+// into "chunks" (one per block of 16 output neurons: 16 bias floats + K*16 weights, already in lane order),
+// double-buffered through LDS with register staging (global -> VGPR while the previous chunk is being
+// multiplied, VGPR -> LDS, one barrier per chunk).
+//
+// Reference arithmetic restated by the kernels built on this engine: model/neus_model.py:385-417 (SDF),
+// :535-560 (colour); model/implicit_differentiable_renderer.py:199-222, 250-258; model/sg_envmap_material.py:74-99.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rb {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_THREADS = 256;  // 4 waves of 64
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2, ACT_SOFTPLUS100 = 3 };
+
+__host__ __device__ constexpr int chunk_f4(int K) { return K > 0 ? 4 + K * 4 : 0; }  // float4s per chunk
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float z) {
+  if constexpr (ACT == ACT_RELU) {
+    return fmaxf(z, 0.0f);
+  } else if constexpr (ACT == ACT_LEAKY02) {
+    return z > 0.0f ? z : 0.2f * z;
+  } else if constexpr (ACT == ACT_SOFTPLUS100) {
+    // torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
+    float bz = 100.0f * z;
+    return bz > 20.0f ? z : log1pf(expf(bz)) / 100.0f;
+  } else {
+    return z;
+  }
+}
+
+// d softplus100 / dz = sigmoid(100 z)   (1 above the threshold, like torch's softplus_backward)
+__device__ __forceinline__ float softplus100_grad(float z) {
+  float bz = 100.0f * z;
+  if (bz > 20.0f) return 1.0f;
+  float e = expf(bz);
+  return e / (e + 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight stream: double-buffered LDS chunks with register staging.  MAXK = largest K of any layer streamed.
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXK>
+struct WStream {
+  static constexpr int BUF_F4 = chunk_f4(MAXK);
+  static constexpr int NST = (BUF_F4 + WG_THREADS - 1) / WG_THREADS;
+  f4* lds;  // 2 * BUF_F4 float4s
+  int cur;
+  int tid;
+  f4 stage[NST];
+
+  __device__ __forceinline__ void init(f4* lds_base, int tid_) {
+    lds = lds_base;
+    cur = 0;
+    tid = tid_;
+  }
+  // Synchronously place the very first chunk of a pass into buffer `cur`.
+  template <int CF4>
+  __device__ __forceinline__ void prime(const f4* __restrict__ src) {
+#pragma unroll
+    for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
+      int idx = i * WG_THREADS + tid;
+      if (idx < CF4) lds[cur * BUF_F4 + idx] = src[idx];
+    }
+    __syncthreads();
+  }
+  template <int CF4>
+  __device__ __forceinline__ void prefetch(const f4* __restrict__ src) {
+#pragma unroll
+    for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
+      int idx = i * WG_THREADS + tid;
+      if (idx < CF4) stage[i] = src[idx];
+    }
+  }
+  // Store the staged chunk into the other buffer, then make it the current one (one barrier per chunk).
+  template <int CF4>
+  __device__ __forceinline__ void commit() {
+    if constexpr (CF4 > 0) {
+#pragma unroll
+      for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
+        int idx = i * WG_THREADS + tid;
+        if (idx < CF4) lds[(cur ^ 1) * BUF_F4 + idx] = stage[i];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  __device__ __forceinline__ const f4* chunk() const { return lds + cur * BUF_F4; }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// One dense layer  out = W . in + b  for the NT tiles of this wave.
+//   K, N       padded layer sizes (multiples of 16);  in: [NT][K/4] regs, out: [NT][N/4] regs (pre-activation)
+//   wl         packed chunks of this layer (N/16 chunks of chunk_f4(K) float4s); chunk 0 must already be current
+//   wnext      first chunk of whatever is streamed after this layer (NEXTK = its K; 0 = nothing follows)
+//   bias_on    per-lane: add the bias (false for tangent columns in forward-mode differentiation)
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int N, int NT, int NEXTK, class WS>
+__device__ __forceinline__ void dense_layer(WS& ws, const f4* __restrict__ wl, const f4* __restrict__ wnext,
+                                            const float (&in)[NT][K / 4], float (&out)[NT][N / 4], int lane,
+                                            bool bias_on) {
+  constexpr int NJB = N / 16, KB = K / 16, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
+  constexpr int NCH = (NT == 1) ? 2 : 1;  // accumulator chains per tile
+  const int g = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb) {
+    if (jb + 1 < NJB) {
+      ws.template prefetch<CF4>(wl + (jb + 1) * CF4);
+    } else {
+      if constexpr (NCF4 > 0) ws.template prefetch<NCF4>(wnext);
+    }
+    const f4* cw = ws.chunk();
+    f4 bias = cw[g];
+    if (!bias_on) bias = f4{0.f, 0.f, 0.f, 0.f};
+    f4 acc[NT][NCH];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = bias;
+      if constexpr (NCH == 2) acc[t][1] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f4 w = cw[4 + kb * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int c = (NCH == 2) ? (kb & 1) : 0;
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], in[t][kb * 4 + r], acc[t][c], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f4 a = acc[t][0];
+      if constexpr (NCH == 2) a = a + acc[t][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][jb * 4 + r] = a[r];
+    }
+    if (jb + 1 < NJB) {
+      ws.template commit<CF4>();
+    } else {
+      ws.template commit<NCF4>();
+    }
+  }
+}
+
+template <int N, int NT, int ACT>
+__device__ __forceinline__ void activate(const float (&z)[NT][N / 4], float (&h)[NT][N / 4]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) h[t][i] = act_fn<ACT>(z[t][i]);
+}
+
+// Forward-mode tangent propagation through Softplus(beta=100): lanes are (value, d/dx, d/dy, d/dz) quads.
+// value lane: h = softplus(z); tangent lanes: h = z_t * softplus'(z_value), z_value broadcast inside the quad.
+template <int N, int NT>
+__device__ __forceinline__ void activate_softplus_jvp(const float (&z)[NT][N / 4], float (&h)[NT][N / 4], int lane,
+                                                      float scale) {
+  const bool is_val = (lane & 3) == 0;
+  const int src = lane & ~3;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      float zv = __shfl(z[t][i], src);
+      float v = is_val ? act_fn<ACT_SOFTPLUS100>(zv) : z[t][i] * softplus100_grad(zv);
+      h[t][i] = v * scale;
+    }
+}
+
+// Load the B-layout input registers of one 16-sample tile from a row-major feature matrix X[M][KP]
+// (KP = padded feature count, multiple of 16).  Rows >= M read as zeros.
+template <int KP>
+__device__ __forceinline__ void load_features(const float* __restrict__ X, long row, long M, int lane,
+                                              float (&in)[KP / 4]) {
+  const int g = lane >> 4;
+  const bool ok = row < M;
+  const f4* p = reinterpret_cast<const f4*>(X + (ok ? row : 0) * KP) + g;
+#pragma unroll
+  for (int kb = 0; kb < KP / 16; ++kb) {
+    f4 v = ok ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = v[r];
+  }
+}
+
+}  // namespace rb

@@ -1,0 +1,686 @@
+// Fused MLP kernels of the per-ray hot path + weight packing + feature construction (C-ABI entry points).
+// See mlp_engine.h for the execution scheme.  All pointers are device pointers; nothing allocates.
+#include "../../include/robir_hip.h"
+#include "common.h"
+#include "mlp_engine.h"
+
+namespace rb {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(const char* what, const char* detail) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, detail);
+  return 1;
+}
+int check_launch(const char* kernel) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", kernel, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+// =====================================================================================================
+// Weight packing.  A packed layer = N/16 chunks; chunk jb = [bias(16jb .. 16jb+15)] ++
+// [kb = 0..K/16-1][lane = 0..63][r = 0..3] -> W[16jb + (lane&15)][16kb + 4(lane>>4) + r].
+// k_perm (optional, length k_pad): packed input column k reads source column k_perm[k]; -1 = structural zero.
+// =====================================================================================================
+__global__ void k_pack_layer(const float* __restrict__ W, const float* __restrict__ b, int n_out, int k_in, int n_pad,
+                             int k_pad, const int* __restrict__ k_perm, float w_scale, float* __restrict__ out) {
+  const long chunk = 16 + (long)k_pad * 16;
+  const long total = (long)(n_pad / 16) * chunk;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int jb = (int)(i / chunk);
+    const long o = i - (long)jb * chunk;
+    float v = 0.f;
+    if (o < 16) {
+      const int j = jb * 16 + (int)o;
+      if (b != nullptr && j < n_out) v = b[j];
+    } else {
+      const long q = o - 16;
+      const int r = (int)(q & 3), lane = (int)((q >> 2) & 63), kb = (int)(q >> 8);
+      const int j = jb * 16 + (lane & 15);
+      int k = kb * 16 + 4 * (lane >> 4) + r;
+      if (k_perm != nullptr) k = k_perm[k];
+      if (j < n_out && k >= 0 && k < k_in) v = W[(long)j * k_in + k] * w_scale;
+    }
+    out[i] = v;
+  }
+}
+
+// =====================================================================================================
+// Feature construction (positional encodings).  Accurate sinf/cosf: arguments reach 2^9*|x|.
+// PE layout (model/embedder.py:17-38): [x(3) | sin(2^0 x)(3) | cos(2^0 x)(3) | sin(2^1 x)(3) | ...].
+// =====================================================================================================
+template <int L>
+__device__ __forceinline__ void write_pe(const float x[3], float* __restrict__ dst) {
+  dst[0] = x[0];
+  dst[1] = x[1];
+  dst[2] = x[2];
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    const float f = (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a = x[c] * f;
+      dst[3 + 6 * k + c] = sinf(a);
+      dst[3 + 6 * k + 3 + c] = cosf(a);
+    }
+  }
+}
+// d(PE)/dx_c : only the components of coordinate c are non-zero.
+template <int L>
+__device__ __forceinline__ void write_pe_tangent(const float x[3], int c, float* __restrict__ dst) {
+#pragma unroll
+  for (int i = 0; i < 3 + 6 * L; ++i) dst[i] = 0.f;
+  dst[c] = 1.f;
+#pragma unroll
+  for (int k = 0; k < L; ++k) {
+    const float f = (float)(1 << k);
+    const float a = x[c] * f;
+    dst[3 + 6 * k + c] = f * cosf(a);
+    dst[3 + 6 * k + 3 + c] = -f * sinf(a);
+  }
+}
+
+// X[M,128] = [PE10(p) | PE10(d) | 0 0]   (VisNetwork input, implicit_differentiable_renderer.py:250-256)
+__global__ void k_feat_vis(const float* __restrict__ p, const float* __restrict__ d, long M, float* __restrict__ X) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float a[3] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+  float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+  float* row = X + i * 128;
+  write_pe<10>(a, row);
+  write_pe<10>(b, row + 63);
+  row[126] = 0.f;
+  row[127] = 0.f;
+}
+
+// X[M,64] = [PE10(x*scale) | extra]  (extra = 0, or hdr_shift for the indirect-illumination net)
+// jvp != 0: X[4M,64], row 4m = PE, rows 4m+1..3 = dPE/dx, dPE/dy, dPE/dz  (forward-mode SDF gradient)
+__global__ void k_feat_pe10(const float* __restrict__ x, long M, float scale, const float* __restrict__ extra, int jvp,
+                            float* __restrict__ X) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float a[3] = {x[3 * i] * scale, x[3 * i + 1] * scale, x[3 * i + 2] * scale};
+  if (!jvp) {
+    float* row = X + i * 64;
+    write_pe<10>(a, row);
+    row[63] = extra ? extra[i] : 0.f;
+  } else {
+    float* row = X + i * 256;
+    write_pe<10>(a, row);
+    row[63] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      write_pe_tangent<10>(a, c, row + 64 * (c + 1));
+      row[64 * (c + 1) + 63] = 0.f;
+    }
+  }
+}
+
+// Integrated PE, isotropic covariance var*I, full-covariance code path of the reference
+// (model/neus_model.py:14-57): [exp(-v_k/2) sin(2^k x_c) (k-major, 30) | exp(-v_k/2) sin(2^k x_c + pi/2) (30)],
+// arguments wrapped mod 100*pi when |arg| >= 100*pi.  X[M,64], columns 60..63 zero.
+__device__ __forceinline__ float py_mod(float a, float m) {  // torch.remainder: sign of the divisor
+  float r = fmodf(a, m);
+  if (r != 0.f && ((r < 0.f) != (m < 0.f))) r += m;
+  return r;
+}
+__global__ void k_feat_ipe(const float* __restrict__ x, long M, float var, const float* __restrict__ noise,
+                           float noise_scale, float* __restrict__ X) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float big = (float)(100.0 * 3.14159265358979323846);
+  const float half_pi = (float)(0.5 * 3.14159265358979323846);
+  float* row = X + i * 64;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const float f = (float)(1 << k);
+    const float damp = expf(-0.5f * (var * (f * f)));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float y = x[3 * i + c] * f;
+      float y2 = y + half_pi;
+      float a1 = fabsf(y) < big ? y : py_mod(y, big);
+      float a2 = fabsf(y2) < big ? y2 : py_mod(y2, big);
+      float e1 = damp * sinf(a1), e2 = damp * sinf(a2);
+      if (noise) {
+        e1 += noise[i * 60 + 3 * k + c] * noise_scale;
+        e2 += noise[i * 60 + 30 + 3 * k + c] * noise_scale;
+      }
+      row[3 * k + c] = e1;
+      row[30 + 3 * k + c] = e2;
+    }
+  }
+  row[60] = row[61] = row[62] = row[63] = 0.f;
+}
+
+// X[M,304] = [feat*feat_scale (256) | x*x_scale (3) | PE4(view) (27) | normal (3) | 0 x15]
+// (RenderingNetwork input, model/neus_model.py:535-545; the packed first layer is column-permuted to match)
+__global__ void k_feat_color(const float* __restrict__ x, float x_scale, const float* __restrict__ view,
+                             const float* __restrict__ normal, const float* __restrict__ feat, long feat_stride,
+                             float feat_scale, long M, float* __restrict__ X) {
+  long i = blockIdx.x;
+  if (i >= M) return;
+  float* row = X + i * 304;
+  const int t = threadIdx.x;  // 256 threads: one feature each
+  row[t] = feat[i * feat_stride + t] * feat_scale;
+  if (t == 0) {
+    float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
+    row[256] = x[3 * i] * x_scale;
+    row[257] = x[3 * i + 1] * x_scale;
+    row[258] = x[3 * i + 2] * x_scale;
+    write_pe<4>(v, row + 259);
+    row[286] = normal[3 * i];
+    row[287] = normal[3 * i + 1];
+    row[288] = normal[3 * i + 2];
+#pragma unroll
+    for (int k = 289; k < 304; ++k) row[k] = 0.f;
+  }
+}
+
+// =====================================================================================================
+// Kernels.  All: 256 threads (4 waves), 1 wave per SIMD, rows_per_block = 64*NT.
+// =====================================================================================================
+template <int K, int N>
+__host__ __device__ constexpr long layer_f4() { return (long)(N / 16) * chunk_f4(K); }
+
+// ---- visibility MLP: X[M,128] -> logits[M,2]   126(128) -> 256 x4 ReLU -> 2(16)
+__global__ __launch_bounds__(256, 1) void k_vis_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
+                                                     float* __restrict__ Y) {
+  __shared__ f4 lds[2 * chunk_f4(256)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<256> ws;
+  ws.init(lds, tid);
+  const f4* wl0 = Wp;
+  const f4* wl1 = wl0 + layer_f4<128, 256>();
+  const f4* wl4 = wl1 + 3 * layer_f4<256, 256>();
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
+  float h[2][64], z[2][64];
+  {
+    float in0[2][32];
+    load_features<128>(X, row0, M, lane, in0[0]);
+    load_features<128>(X, row0 + 16, M, lane, in0[1]);
+    ws.prime<chunk_f4(128)>(wl0);
+    dense_layer<128, 256, 2, 256>(ws, wl0, wl1, in0, z, lane, true);
+  }
+  activate<256, 2, ACT_RELU>(z, h);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    const f4* wl = wl1 + l * layer_f4<256, 256>();
+    dense_layer<256, 256, 2, 256>(ws, wl, wl + layer_f4<256, 256>(), h, z, lane, true);
+    activate<256, 2, ACT_RELU>(z, h);
+  }
+  float o[2][4];
+  dense_layer<256, 16, 2, 0>(ws, wl4, nullptr, h, o, lane, true);
+  if ((lane >> 4) == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      long row = row0 + 16 * t;
+      if (row < M) {
+        Y[row * 2] = o[t][0];
+        Y[row * 2 + 1] = o[t][1];
+      }
+    }
+  }
+}
+
+// ---- single linear layer X[M,64] -> Y[M,256] (no activation); used to split the visibility net's first layer
+//      into a per-point and a per-direction half for the fused diffuse-visibility kernel.
+__global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restrict__ X, long M,
+                                                           const f4* __restrict__ Wp, float* __restrict__ Y) {
+  __shared__ f4 lds[2 * chunk_f4(64)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<64> ws;
+  ws.init(lds, tid);
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
+  float in0[2][16], z[2][64];
+  load_features<64>(X, row0, M, lane, in0[0]);
+  load_features<64>(X, row0 + 16, M, lane, in0[1]);
+  ws.prime<chunk_f4(64)>(Wp);
+  dense_layer<64, 256, 2, 0>(ws, Wp, nullptr, in0, z, lane, true);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long row = row0 + 16 * t;
+    if (row < M) {
+      f4* dst = reinterpret_cast<f4*>(Y + row * 256) + g;
+#pragma unroll
+      for (int jb = 0; jb < 16; ++jb) dst[jb * 4] = f4{z[t][jb * 4], z[t][jb * 4 + 1], z[t][jb * 4 + 2], z[t][jb * 4 + 3]};
+    }
+  }
+}
+
+// ---- NeuS SDF network (model/neus_model.py:385-417): PE10 (64) -> 256,256,256,193(208) -> skip cat /sqrt2 (272)
+//      -> 256 x4 -> 257(272) | 1(16);  Softplus(beta=100, threshold 20).
+// MODE 0: sdf only -> out0[M]          MODE 1: sdf+feat -> out0[M,257]
+// MODE 2: forward-mode jvp, sdf only: X[4M,64] (value row + 3 tangent rows per point); out0[M], grad[M,3]
+// MODE 3: forward-mode jvp, full:     X[4M,64]; out0[M,257], grad[M,3]
+template <int NREG, int HREG, bool JVP>
+__device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (&h)[2][HREG], int lane, float scale) {
+  if constexpr (JVP) {
+    const bool is_val = (lane & 3) == 0;
+    const int src = lane & ~3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) {
+        float zv = __shfl(z[t][i], src);
+        float v = is_val ? act_fn<ACT_SOFTPLUS100>(zv) : z[t][i] * softplus100_grad(zv);
+        h[t][i] = v * scale;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) h[t][i] = act_fn<ACT_SOFTPLUS100>(z[t][i]) * scale;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
+                                                     float out_scale, float grad_scale, float* __restrict__ out0,
+                                                     float* __restrict__ grad) {
+  constexpr bool JVP = MODE >= 2;
+  constexpr bool FULL = (MODE == 1 || MODE == 3);
+  constexpr int NL = FULL ? 272 : 16;
+  __shared__ f4 lds[2 * chunk_f4(272)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<272> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<256, 256>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<64, 256>();
+  const f4* w3 = w1 + 2 * LF;
+  const f4* w4 = w3 + layer_f4<256, 208>();
+  const f4* w5 = w4 + layer_f4<272, 256>();
+  const f4* w8 = w5 + 3 * LF;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);  // row of X (a jvp column when JVP)
+  const bool bias_on = JVP ? ((lane & 3) == 0) : true;
+  const float inv_sqrt2 = 0.70710678118654752440f;
+  float x0[2][16], ha[2][64], z[2][64];
+  load_features<64>(X, row0, MR, lane, x0[0]);
+  load_features<64>(X, row0 + 16, MR, lane, x0[1]);
+  ws.prime<chunk_f4(64)>(w0);
+  dense_layer<64, 256, 2, 256>(ws, w0, w1, x0, z, lane, bias_on);
+  softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+#pragma unroll 1
+  for (int l = 0; l < 2; ++l) {
+    dense_layer<256, 256, 2, 256>(ws, w1 + l * LF, w1 + (l + 1) * LF, ha, z, lane, bias_on);
+    softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+  }
+  {
+    float hs[2][68];
+    {
+      float z3[2][52];
+      dense_layer<256, 208, 2, 272>(ws, w3, w4, ha, z3, lane, bias_on);
+      softplus_into<52, 68, JVP>(z3, hs, lane, inv_sqrt2);   // neurons 193..207 are padding: zero weights downstream
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hs[t][52 + i] = x0[t][i] * inv_sqrt2;
+    dense_layer<272, 256, 2, 256>(ws, w4, w5, hs, z, lane, bias_on);
+  }
+  softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    dense_layer<256, 256, 2, 256>(ws, w5 + l * LF, w5 + (l + 1) * LF, ha, z, lane, bias_on);
+    softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+  }
+  float zo[2][NL / 4];
+  dense_layer<256, NL, 2, 0>(ws, w8, nullptr, ha, zo, lane, bias_on);
+
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long row = row0 + 16 * t;
+    if (row >= MR) continue;
+    if constexpr (!JVP) {
+      if constexpr (FULL) {
+#pragma unroll
+        for (int jb = 0; jb < NL / 16; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = jb * 16 + 4 * g + r;
+            if (j < 257) out0[row * 257 + j] = zo[t][jb * 4 + r] * out_scale;
+          }
+      } else {
+        if (g == 0) out0[row] = zo[t][0] * out_scale;
+      }
+    } else {
+      const long m = row >> 2;
+      const int c = (int)(row & 3);
+      if (c == 0) {
+        if constexpr (FULL) {
+#pragma unroll
+          for (int jb = 0; jb < NL / 16; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = jb * 16 + 4 * g + r;
+              if (j < 257) out0[m * 257 + j] = zo[t][jb * 4 + r] * out_scale;
+            }
+        } else {
+          if (g == 0) out0[m] = zo[t][0] * out_scale;
+        }
+      } else if (g == 0) {
+        grad[m * 3 + (c - 1)] = zo[t][0] * grad_scale;
+      }
+    }
+  }
+}
+
+// ---- NeuS colour network (model/neus_model.py:535-560): 289(304) -> 256 x4 ReLU -> 3(16) -> sigmoid
+__global__ __launch_bounds__(256, 1) void k_color_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
+                                                       float* __restrict__ rgb) {
+  __shared__ f4 lds[2 * chunk_f4(304)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<304> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<256, 256>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<304, 256>();
+  const f4* w4 = w1 + 3 * LF;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
+  float h[2][64], z[2][64];
+  {
+    float in0[2][76];
+    load_features<304>(X, row0, M, lane, in0[0]);
+    load_features<304>(X, row0 + 16, M, lane, in0[1]);
+    ws.prime<chunk_f4(304)>(w0);
+    dense_layer<304, 256, 2, 256>(ws, w0, w1, in0, z, lane, true);
+  }
+  activate<256, 2, ACT_RELU>(z, h);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    dense_layer<256, 256, 2, 256>(ws, w1 + l * LF, w1 + (l + 1) * LF, h, z, lane, true);
+    activate<256, 2, ACT_RELU>(z, h);
+  }
+  float o[2][4];
+  dense_layer<256, 16, 2, 0>(ws, w4, nullptr, h, o, lane, true);
+  if ((lane >> 4) == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long row = row0 + 16 * t;
+      if (row < M) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rgb[row * 3 + c] = 1.0f / (1.0f + expf(-o[t][c]));
+      }
+    }
+  }
+}
+
+// ---- 512-wide nets, one 16-sample tile per wave.
+// ENC = false: IndirctIllumNetwork.lobe_layer  64 -> 512 x4 ReLU -> 144            (raw outputs [M,144])
+// ENC = true : SparseAE encoder                64 -> 512 x4 LeakyReLU(0.2) -> 32   (raw latent  [M,32])
+template <bool ENC>
+__global__ __launch_bounds__(256, 1) void k_wide_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
+                                                      float* __restrict__ Y) {
+  constexpr int NO = ENC ? 32 : 144;
+  constexpr int ACT = ENC ? ACT_LEAKY02 : ACT_RELU;
+  __shared__ f4 lds[2 * chunk_f4(512)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<512> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<512, 512>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<64, 512>();
+  const f4* w4 = w1 + 3 * LF;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  float h[1][128], z[1][128];
+  {
+    float in0[1][16];
+    load_features<64>(X, row, M, lane, in0[0]);
+    ws.prime<chunk_f4(64)>(w0);
+    dense_layer<64, 512, 1, 512>(ws, w0, w1, in0, z, lane, true);
+  }
+  activate<512, 1, ACT>(z, h);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    dense_layer<512, 512, 1, 512>(ws, w1 + l * LF, w1 + (l + 1) * LF, h, z, lane, true);
+    activate<512, 1, ACT>(z, h);
+  }
+  float o[1][NO / 4];
+  dense_layer<512, NO, 1, 0>(ws, w4, nullptr, h, o, lane, true);
+  if (row < M) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < NO / 16; ++jb) {
+      f4* dst = reinterpret_cast<f4*>(Y + row * NO + jb * 16) + g;
+      *dst = f4{o[0][jb * 4], o[0][jb * 4 + 1], o[0][jb * 4 + 2], o[0][jb * 4 + 3]};
+    }
+  }
+}
+
+// ---- SparseAE decoder (sg_envmap_material.py:61-68): 32 -> 128 -> 128 LeakyReLU(0.2) -> n_out(16)
+__global__ __launch_bounds__(256, 1) void k_ae_decode(const float* __restrict__ L, long M, const f4* __restrict__ Wp,
+                                                       int n_out, int sigmoid_out, float* __restrict__ Y) {
+  __shared__ f4 lds[2 * chunk_f4(128)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<128> ws;
+  ws.init(lds, tid);
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<32, 128>();
+  const f4* w2 = w1 + layer_f4<128, 128>();
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
+  float in0[2][8], h[2][32], z[2][32];
+  load_features<32>(L, row0, M, lane, in0[0]);
+  load_features<32>(L, row0 + 16, M, lane, in0[1]);
+  ws.prime<chunk_f4(32)>(w0);
+  dense_layer<32, 128, 2, 128>(ws, w0, w1, in0, z, lane, true);
+  activate<128, 2, ACT_LEAKY02>(z, h);
+  dense_layer<128, 128, 2, 128>(ws, w1, w2, h, z, lane, true);
+  activate<128, 2, ACT_LEAKY02>(z, h);
+  float o[2][4];
+  dense_layer<128, 16, 2, 0>(ws, w2, nullptr, h, o, lane, true);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long row = row0 + 16 * t;
+    if (row < M) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * g + r;
+        if (j < n_out) {
+          float v = o[t][r];
+          Y[row * n_out + j] = sigmoid_out ? 1.0f / (1.0f + expf(-v)) : v;
+        }
+      }
+    }
+  }
+}
+
+// ---- small element-wise pieces of the auto-encoders / indirect-illumination head
+// latent = act(raw * (1 - var));  act: 0 sigmoid, 1 softplus(beta=1, threshold 20)   (sg_envmap_material.py:74-99)
+// writes lat[M,32]; if lat2 != null also lat2 = lat + noise*noise_scale (smooth_on_latent branch)
+__global__ void k_ae_latent(const float* __restrict__ raw, long M, const float* __restrict__ var, int act,
+                            const float* __restrict__ noise, float noise_scale, float* __restrict__ lat,
+                            float* __restrict__ lat2) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= M * 32) return;
+  float v = raw[i];
+  if (var) v = v * (1.0f - var[i & 31]);
+  float a;
+  if (act == 0) {
+    a = 1.0f / (1.0f + expf(-v));
+  } else {
+    a = v > 20.0f ? v : log1pf(expf(v));
+  }
+  lat[i] = a;
+  if (lat2) lat2[i] = a + noise[i] * noise_scale;
+}
+
+// y = a + s*b over n floats
+__global__ void k_axpy(const float* __restrict__ a, const float* __restrict__ b, float s, long n, float* __restrict__ y) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a[i] + s * b[i];
+}
+
+// IndirctIllumNetwork head (implicit_differentiable_renderer.py:206-218): raw[M,24,6] -> sgs[M,24,7]
+__global__ void k_illum_decode(const float* __restrict__ raw, long n_lobes, float* __restrict__ sgs) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n_lobes) return;
+  const float* r = raw + i * 6;
+  const float two_pi = (float)(2.0 * 3.14159265358979323846), pi = (float)3.14159265358979323846;
+  float a = 1.0f / (1.0f + expf(-r[0])), b = 1.0f / (1.0f + expf(-r[1]));
+  float theta = a * 2.0f * pi, phi = b * pi;
+  (void)two_pi;
+  float* o = sgs + i * 7;
+  o[0] = cosf(theta) * sinf(phi);
+  o[1] = sinf(theta) * sinf(phi);
+  o[2] = cosf(phi);
+  o[3] = (1.0f / (1.0f + expf(-r[2]))) * 30.0f + 0.1f;
+  o[4] = fmaxf(r[3], 0.f);
+  o[5] = fmaxf(r[4], 0.f);
+  o[6] = fmaxf(r[5], 0.f);
+}
+
+}  // namespace rb
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+using namespace rb;
+
+extern "C" {
+
+int rb_abi_version(void) { return RB_ABI_VERSION; }
+const char* rb_last_error(void) { return rb::err_buf(); }
+
+long rb_packed_layer_floats(int n_pad, int k_pad) { return (long)(n_pad / 16) * (16 + (long)k_pad * 16); }
+
+int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
+                  float w_scale, float* out, rb_stream_t stream) {
+  RB_REQUIRE(W && out, "null pointer");
+  RB_REQUIRE(n_pad % 16 == 0 && k_pad % 16 == 0 && n_pad >= n_out && (k_perm || k_pad >= k_in), "bad padding");
+  long total = rb_packed_layer_floats(n_pad, k_pad);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_layer, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, b, n_out, k_in, n_pad, k_pad,
+                     k_perm, w_scale, out);
+  return check_launch("k_pack_layer");
+}
+
+int rb_feat_vis(const float* p, const float* d, long M, float* X, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(p && d && X, "null pointer");
+  hipLaunchKernelGGL(k_feat_vis, grid1d(M, 256), dim3(256), 0, (hipStream_t)stream, p, d, M, X);
+  return check_launch("k_feat_vis");
+}
+
+int rb_feat_pe10(const float* x, long M, float scale, const float* extra, int jvp, float* X, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && X, "null pointer");
+  RB_REQUIRE(!(jvp && extra), "extra column not supported with jvp rows");
+  hipLaunchKernelGGL(k_feat_pe10, grid1d(M, 128), dim3(128), 0, (hipStream_t)stream, x, M, scale, extra, jvp, X);
+  return check_launch("k_feat_pe10");
+}
+
+int rb_feat_ipe(const float* x, long M, float var, const float* noise, float noise_scale, float* X,
+                rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && X, "null pointer");
+  hipLaunchKernelGGL(k_feat_ipe, grid1d(M, 128), dim3(128), 0, (hipStream_t)stream, x, M, var, noise, noise_scale, X);
+  return check_launch("k_feat_ipe");
+}
+
+int rb_feat_color(const float* x, float x_scale, const float* view, const float* normal, const float* feat,
+                  long feat_stride, float feat_scale, long M, float* X, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && view && normal && feat && X, "null pointer");
+  hipLaunchKernelGGL(k_feat_color, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, x_scale, view, normal, feat,
+                     feat_stride, feat_scale, M, X);
+  return check_launch("k_feat_color");
+}
+
+int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && logits, "null pointer");
+  hipLaunchKernelGGL(k_vis_mlp, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, logits);
+  return check_launch("k_vis_mlp");
+}
+
+int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && Y, "null pointer");
+  hipLaunchKernelGGL(k_linear_64_256, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, Y);
+  return check_launch("k_linear_64_256");
+}
+
+int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
+               float* grad, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && out0, "null pointer");
+  RB_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0..3");
+  RB_REQUIRE(mode < 2 || grad, "jvp modes need a gradient output");
+  const long MR = mode >= 2 ? 4 * M : M;
+  dim3 grid = grid1d(MR, 128), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const f4* W = (const f4*)Wp;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(k_sdf_mlp<0>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    case 1: hipLaunchKernelGGL(k_sdf_mlp<1>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    case 2: hipLaunchKernelGGL(k_sdf_mlp<2>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    default: hipLaunchKernelGGL(k_sdf_mlp<3>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+  }
+  return check_launch("k_sdf_mlp");
+}
+
+int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && rgb, "null pointer");
+  hipLaunchKernelGGL(k_color_mlp, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, rgb);
+  return check_launch("k_color_mlp");
+}
+
+int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && raw, "null pointer");
+  hipLaunchKernelGGL(k_wide_mlp<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, raw);
+  return check_launch("k_wide_mlp<illum>");
+}
+
+int rb_ae_encode(const float* X, long M, const float* Wp, float* raw_latent, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && raw_latent, "null pointer");
+  hipLaunchKernelGGL(k_wide_mlp<true>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
+                     raw_latent);
+  return check_launch("k_wide_mlp<enc>");
+}
+
+int rb_ae_latent(const float* raw, long M, const float* var, int act, const float* noise, float noise_scale, float* lat,
+                 float* lat2, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(raw && lat, "null pointer");
+  RB_REQUIRE(!lat2 || noise, "lat2 needs noise");
+  hipLaunchKernelGGL(k_ae_latent, grid1d(M * 32, 256), dim3(256), 0, (hipStream_t)stream, raw, M, var, act, noise,
+                     noise_scale, lat, lat2);
+  return check_launch("k_ae_latent");
+}
+
+int rb_ae_decode(const float* lat, long M, const float* Wp, int n_out, int sigmoid_out, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(lat && Wp && Y, "null pointer");
+  RB_REQUIRE(n_out >= 1 && n_out <= 16, "n_out must be 1..16");
+  hipLaunchKernelGGL(k_ae_decode, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, lat, M, (const f4*)Wp, n_out,
+                     sigmoid_out, Y);
+  return check_launch("k_ae_decode");
+}
+
+int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(a && b && y, "null pointer");
+  hipLaunchKernelGGL(k_axpy, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a, b, s, n, y);
+  return check_launch("k_axpy");
+}
+
+int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(raw && sgs, "null pointer");
+  hipLaunchKernelGGL(k_illum_decode, grid1d(M * 24, 256), dim3(256), 0, (hipStream_t)stream, raw, M * 24, sgs);
+  return check_launch("k_illum_decode");
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+"""State dict (reference key names) -> packed weight blobs for the HIP MLP kernels.
+
+Layouts are defined by include/robir_hip.h ("Weight packing") and robir_amd/csrc/mlp_engine.h.  Packing itself
+runs on the device (rb_pack_layer); this module only decides layer order, padding and input-column permutations.
+Weight-norm (model/neus_model.py:378-379) is folded once here: W = g * v / |v|_row.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+SDF = "implicit_network.neus_model.sdf_network."
+COL = "implicit_network.neus_model.color_network."
+VIS = "visibility_network.vis_layer."
+ILL = "indirect_illum_network."
+MAT = "envmap_material_network."
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def _fold_wn(sd, prefix):
+    v, g = sd[prefix + "weight_v"].float(), sd[prefix + "weight_g"].float()
+    return (v * (g / v.norm(dim=1, keepdim=True))).contiguous()
+
+
+def pack_layers(layers, device):
+    """layers: list of dict(W[N,K], b[N] or None, n_pad, k_pad, perm (list[int]|None)).  Returns one fp32 blob."""
+    L = _lib.lib()
+    sizes = [int(L.rb_packed_layer_floats(l["n_pad"], l["k_pad"])) for l in layers]
+    blob = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    off = 0
+    keep = []
+    for l, sz in zip(layers, sizes):
+        W = l["W"].to(device=device, dtype=torch.float32).contiguous()
+        b = l["b"].to(device=device, dtype=torch.float32).contiguous() if l.get("b") is not None else None
+        perm = None
+        if l.get("perm") is not None:
+            perm = torch.tensor(l["perm"], dtype=torch.int32, device=device)
+            assert perm.numel() == l["k_pad"]
+        keep += [W, b, perm]
+        out = blob[off:off + sz]
+        _lib.call("rb_pack_layer", _lib.ptr(W), _lib.ptr(b), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
+                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), _lib.ptr(perm), ctypes.c_float(1.0),
+                  ctypes.c_void_p(out.data_ptr()), _lib.stream_ptr())
+        off += sz
+    torch.cuda.current_stream().synchronize()   # W/b/perm temporaries must outlive the pack kernels
+    return blob
+
+
+def _t(sd, k):
+    v = sd[k]
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+
+
+def pack_vis(sd, device):
+    """[128->256, 256->256 x3, 256->16]  (VisNetwork, implicit_differentiable_renderer.py:241-248)."""
+    ls = []
+    for i in range(5):
+        W, b = _t(sd, VIS + "%d.weight" % (2 * i)), _t(sd, VIS + "%d.bias" % (2 * i))
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
+    return pack_layers(ls, device)
+
+
+def pack_vis_split(sd, device):
+    """First visibility layer split into its point half (with bias) and direction half (no bias), each 64->256,
+    plus the hidden stack [256->256 x3] and the 2x256 output layer kept in plain row-major form."""
+    W0, b0 = _t(sd, VIS + "0.weight").float(), _t(sd, VIS + "0.bias").float()
+    wp = pack_layers([dict(W=W0[:, :63].contiguous(), b=b0, n_pad=256, k_pad=64)], device)
+    wd = pack_layers([dict(W=W0[:, 63:].contiguous(), b=None, n_pad=256, k_pad=64)], device)
+    hid = pack_layers([dict(W=_t(sd, VIS + "%d.weight" % (2 * i)), b=_t(sd, VIS + "%d.bias" % (2 * i)), n_pad=256,
+                            k_pad=256) for i in (1, 2, 3)], device)
+    w_last = _t(sd, VIS + "8.weight").to(device=device, dtype=torch.float32).contiguous()      # [2,256]
+    b_last = _t(sd, VIS + "8.bias").to(device=device, dtype=torch.float32).contiguous()        # [2]
+    return dict(point=wp, dir=wd, hidden=hid, w_last=w_last, b_last=b_last)
+
+
+def pack_sdf(sd, device, full=True):
+    """[64->256, 256->256 x2, 256->208, 272->256, 256->256 x3, 256->272|16]  (SDFNetwork, neus_model.py:350-381)."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
+    ls = []
+    for l in range(9):
+        W = _fold_wn(sdt, SDF + "lin%d." % l)
+        b = sdt[SDF + "lin%d.bias" % l].float()
+        n_pad, k_pad, perm = _pad16(W.shape[0]), _pad16(W.shape[1]), None
+        if l == 4:   # input = cat[act(lin3) (193), PE (63)] -> packed order [208 slots | 64 slots]
+            k_pad = 272
+            perm = [k if k < 193 else -1 for k in range(208)] + [193 + j if j < 63 else -1 for j in range(64)]
+        if l == 8 and not full:
+            W, b, n_pad = W[:1].contiguous(), b[:1].contiguous(), 16
+        ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
+    return pack_layers(ls, device)
+
+
+def pack_color(sd, device):
+    """[304->256 (cols permuted to [feat|x|PE4(view)|normal]), 256->256 x3, 256->16]  (neus_model.py:511-531)."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}
+    ls = []
+    for l in range(5):
+        W = _fold_wn(sdt, COL + "lin%d." % l)
+        b = sdt[COL + "lin%d.bias" % l].float()
+        perm = None
+        if l == 0:
+            perm = [33 + k for k in range(256)] + list(range(33)) + [-1] * 15
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=304 if l == 0 else _pad16(W.shape[1]), perm=perm))
+    return pack_layers(ls, device)
+
+
+def pack_illum(sd, device):
+    ls = []
+    for i in range(5):
+        W, b = _t(sd, ILL + "lobe_layer.%d.weight" % (2 * i)), _t(sd, ILL + "lobe_layer.%d.bias" % (2 * i))
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
+    return pack_layers(ls, device)
+
+
+def pack_sparse_ae(sd, prefix, device):
+    """-> (encoder blob [64->512, 512->512 x3, 512->32], decoder blob [32->128, 128->128, 128->16])."""
+    enc, dec = [], []
+    for i in range(5):
+        W = _t(sd, prefix + ".brdf_encoder_layer.%d.weight" % (2 * i))
+        b = _t(sd, prefix + ".brdf_encoder_layer.%d.bias" % (2 * i))
+        enc.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
+    for i in range(3):
+        W = _t(sd, prefix + ".brdf_decoder_layer.%d.weight" % (2 * i))
+        b = _t(sd, prefix + ".brdf_decoder_layer.%d.bias" % (2 * i))
+        dec.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
+    return pack_layers(enc, device), pack_layers(dec, device)

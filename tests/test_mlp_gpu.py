@@ -1,0 +1,147 @@
+"""HIP MLP kernels (through the C-ABI) against the oracle on identical inputs and weights.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pts_dirs():
+    g = np.random.Generator(np.random.PCG64(99))
+    M = 1000   # not a multiple of the 128-row block: exercises the ragged tail
+    pts = torch.from_numpy((g.standard_normal((M, 3)) * 0.25).astype(np.float32))
+    dirs = torch.from_numpy(g.standard_normal((M, 3)).astype(np.float32))
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    return pts, dirs
+
+
+def test_features(dev, pts_dirs):
+    from robir_amd import ops
+    from robir_oracle.encoding import pe, ipe_isotropic
+    pts, dirs = pts_dirs
+    X = ops.feat_vis(pts.to(dev), dirs.to(dev)).cpu()
+    ref = torch.cat([pe(pts, 10), pe(dirs, 10)], -1)
+    assert rel_err(X[:, :126], ref) <= 1e-5
+    assert float(X[:, 126:].abs().max()) == 0.0
+    X = ops.feat_pe10(pts.to(dev), scale=2.0).cpu()
+    assert rel_err(X[:, :63], pe(pts * 2.0, 10)) <= 1e-5
+    I = ops.feat_ipe(pts.to(dev) * 300.0, 1e-5).cpu()
+    assert rel_err(I[:, :60], ipe_isotropic(pts * 300.0, 1e-5)) <= 1e-4
+
+
+def test_pe_tangent_rows(dev, pts_dirs):
+    from robir_amd import ops
+    from robir_oracle.encoding import pe
+    pts, _ = pts_dirs
+    p = pts[:64].double().requires_grad_(True)
+    J = torch.autograd.functional.jacobian(lambda q: pe(q, 10).sum(0), p)   # [63, 64, 3]
+    X = ops.feat_pe10(pts[:64].to(dev), scale=1.0, jvp=True).cpu().reshape(64, 4, 64)
+    for c in range(3):
+        assert rel_err(X[:, 1 + c, :63], J[:, :, c].T.float()) <= 1e-4
+
+
+def test_vis_mlp(dev, pts_dirs, synth_weights, oracle_sd):
+    from robir_amd import ops, packing
+    from robir_oracle import nets
+    pts, dirs = pts_dirs
+    blob = packing.pack_vis(synth_weights, dev)
+    out = ops.vis_mlp(ops.feat_vis(pts.to(dev), dirs.to(dev)), blob).cpu()
+    assert rel_err(out, nets.vis_logits(oracle_sd, pts, dirs)) <= TOL
+    g = load_golden("nets")
+    out = ops.vis_mlp(ops.feat_vis(torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)), blob).cpu()
+    assert rel_err(out, g["vis_logits"]) <= TOL          # against the reference's own output
+
+
+def test_linear_split_layer(dev, pts_dirs, synth_weights):
+    from robir_amd import ops, packing
+    from robir_oracle.encoding import pe
+    pts, dirs = pts_dirs
+    sp = packing.pack_vis_split(synth_weights, dev)
+    W0 = torch.from_numpy(synth_weights["visibility_network.vis_layer.0.weight"])
+    b0 = torch.from_numpy(synth_weights["visibility_network.vis_layer.0.bias"])
+    A = ops.linear_64_256(ops.feat_pe10(pts.to(dev)), sp["point"]).cpu()
+    B = ops.linear_64_256(ops.feat_pe10(dirs.to(dev)), sp["dir"]).cpu()
+    assert rel_err(A, pe(pts, 10) @ W0[:, :63].T + b0) <= TOL
+    assert rel_err(B, pe(dirs, 10) @ W0[:, 63:].T) <= TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_sdf_mlp(dev, pts_dirs, synth_weights, oracle_sd, mode):
+    from robir_amd import ops, packing
+    from robir_oracle import nets
+    pts, _ = pts_dirs
+    full = mode in (1, 3)
+    blob = packing.pack_sdf(synth_weights, dev, full=full)
+    X = ops.feat_pe10(pts.to(dev), scale=2.0, jvp=mode >= 2)
+    out0, grad = ops.sdf_mlp(X, pts.shape[0], blob, mode, out_scale=0.5, grad_scale=1.0)
+    ref = nets.implicit_forward(oracle_sd, pts)
+    if full:
+        assert rel_err(out0.cpu(), ref) <= TOL
+    else:
+        assert rel_err(out0.cpu(), ref[:, 0]) <= TOL
+    if mode >= 2:
+        assert rel_err(grad.cpu(), nets.implicit_gradient(oracle_sd, pts)) <= TOL
+
+
+def test_sdf_golden(dev, synth_weights):
+    from robir_amd import ops, packing
+    g = load_golden("nets")
+    pts = torch.from_numpy(g["pts"]).to(dev)
+    blob = packing.pack_sdf(synth_weights, dev, full=True)
+    out0, grad = ops.sdf_mlp(ops.feat_pe10(pts, scale=2.0, jvp=True), pts.shape[0], blob, 3, 0.5, 1.0)
+    assert rel_err(out0.cpu(), g["sdf_feat"]) <= TOL
+    assert rel_err(grad.cpu(), g["grad"]) <= TOL
+
+
+def test_color_mlp(dev, synth_weights):
+    from robir_amd import ops, packing
+    g = load_golden("nets")
+    pts, dirs = torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
+    feat = torch.from_numpy(g["sdf_feat"]).to(dev)      # wrapper output: features are halved (neus_model.py:790-791)
+    nrm = torch.from_numpy(g["color_normals"]).to(dev)
+    X = ops.feat_color(pts, dirs, nrm, feat[:, 1:], x_scale=2.0, feat_scale=2.0)
+    rgb = ops.color_mlp(X, packing.pack_color(synth_weights, dev)).cpu()
+    assert rel_err(rgb, g["color"]) <= TOL
+
+
+def test_illum_and_autoencoders(dev, synth_weights):
+    from robir_amd import ops, packing
+    g = load_golden("nets")
+    pts = torch.from_numpy(g["pts"]).to(dev)
+    hdr = torch.from_numpy(g["hdr"]).to(dev)
+    n64, n32, n60 = (torch.from_numpy(g[k]).to(dev) for k in ("illum_noise", "spec_noise", "normal_noise"))
+    X = ops.feat_pe10(pts, extra=hdr)
+    sgs = ops.illum_decode(ops.illum_mlp(X, packing.pack_illum(synth_weights, dev))).cpu()
+    assert rel_err(sgs, g["illum_sgs"]) <= TOL
+    # integral layer: SparseAE(64->3), latent softplus, re-encode of x + 0.02*noise, |.| of the SECOND output
+    enc, dec = packing.pack_sparse_ae(synth_weights, "indirect_illum_network.integral_layer", dev)
+    lat, _ = ops.ae_latent(ops.ae_encode(ops.axpy(X, n64, 0.02), enc), act=1)
+    integ = ops.ae_decode(lat, dec, 3, False).abs().cpu()
+    assert rel_err(integ, g["illum_int"]) <= TOL
+    # spec AE: latent sigmoid, second decode of latent + 0.01*noise, sigmoid out
+    enc, dec = packing.pack_sparse_ae(synth_weights, "envmap_material_network.spec_brdf_encoder_layer", dev)
+    lat, lat2 = ops.ae_latent(ops.ae_encode(ops.feat_pe10(pts), enc), act=0, noise=n32, noise_scale=0.01)
+    brdf, brdf2 = ops.ae_decode(lat, dec, 5, True).cpu(), ops.ae_decode(lat2, dec, 5, True).cpu()
+    assert rel_err(brdf[:, :3], g["mat_sg_diffuse_albedo"]) <= TOL
+    assert rel_err(brdf[:, 3:4] * 0.9 + 0.09, g["mat_sg_roughness"]) <= TOL
+    assert rel_err(brdf2[:, 4:5], g["mat_random_xi_metallic"]) <= TOL
+    # normal AE on IPE features, re-encode of ipe + 0.02*noise
+    enc, dec = packing.pack_sparse_ae(synth_weights, "envmap_material_network.normal_decoder_layer", dev)
+    lat, _ = ops.ae_latent(ops.ae_encode(ops.feat_ipe(pts, 1e-5), enc), act=0)
+    nm = ops.ae_decode(lat, dec, 3, False).cpu()
+    nm = nm / torch.clamp(nm.norm(dim=-1, keepdim=True), 1e-4)
+    assert rel_err(nm, g["mat_sg_normal_map"]) <= TOL
+    lat, _ = ops.ae_latent(ops.ae_encode(ops.feat_ipe(pts, 1e-5, noise=n60, noise_scale=0.02), enc), act=0)
+    nm2 = ops.ae_decode(lat, dec, 3, False).cpu()
+    nm2 = nm2 / torch.clamp(nm2.norm(dim=-1, keepdim=True), 1e-4)
+    assert rel_err(nm2, g["mat_random_xi_normal"]) <= TOL
