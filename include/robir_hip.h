@@ -43,8 +43,8 @@ int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad
  * Feature construction (positional encodings), accurate sinf/cosf.
  * Replaces: model/embedder.py:7-55 (get_embedder), model/neus_model.py:14-57,71-91 (IPE).
  * ------------------------------------------------------------------------------------------------------------ */
-/* X[M,128] = [PE10(p) | PE10(d) | 0 0]                                   VisNetwork input */
-int rb_feat_vis(const float* p, const float* d, long M, float* X, rb_stream_t stream);
+/* X[M,128] = [PE10(p[i/rep]) | PE10(d[i]) | 0 0]   VisNetwork input; p holds M/rep points, d holds M directions */
+int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_stream_t stream);
 /* X[M,64] = [PE10(x*scale) | extra[M] or 0];  jvp!=0: X[4M,64] with rows (PE, dPE/dx, dPE/dy, dPE/dz) per point */
 int rb_feat_pe10(const float* x, long M, float scale, const float* extra, int jvp, float* X, rb_stream_t stream);
 /* X[M,64] = full-covariance IPE(x, var*I) (60) [+ noise[M,60]*noise_scale] | 0 x4 */
@@ -86,6 +86,44 @@ int rb_ae_latent(const float* raw, long M, const float* var, int act, const floa
 int rb_ae_decode(const float* lat, long M, const float* Wp, int n_out, int sigmoid_out, float* Y, rb_stream_t stream);
 /* y = a + s*b (n floats) */
 int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Light-SG ("diffuse") visibility -- get_diffuse_visibility, model/sg_render.py:111-195.
+ * rb_dvis_dirs: per chunk c (C chunks share the light lgt[L,7] but have their own draws u_theta/u_phi[C,L,nsamp]):
+ *   dirs[C*L*nsamp,3], wdir[C*L*nsamp] = exp(lambda(d.axis-1)), wsum[C*L] = sum_s wdir + 1e-6.
+ * rb_dvis_fused: one workgroup per point.  A[n,256] = W0[:, :63].PE10(p)+b0 and Bd[C*L*nsamp,256] = W0[:,63:].PE10(d)
+ *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
+ *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta, const float* u_phi, float thr,
+                 float* dirs, float* wdir, float* wsum, rb_stream_t stream);
+int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                  const float* wdir, const float* wsum, const float* Whid, const float* wlast, const float* blast, int L,
+                  int nsamp, int argmax_vis, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BRDF-lobe ("specular") visibility -- get_specular_visibility, single-view branch, model/sg_render.py:198-301.
+ * rb_spec_vis_sample: sharp[n] = clip(warped lambda, 0.1, 50), chunk_min[C] (uint32 bit pattern of the per-chunk
+ *   minimum: the reference's batch-global sharpness.min()), dirs[n*nsamp,3], wts[n*nsamp], front[n*nsamp] (uint8).
+ * rb_spec_vis_reduce: logits[n*nsamp,2] of the visibility MLP -> bvis[n]; inv: use softmax[...,0] (indirect pass).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_spec_vis_sample(const float* normal, const float* view, const float* rough, const int* chunk_id, long n,
+                       int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
+                       unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);
+int rb_spec_vis_reduce(const float* logits, const unsigned char* front, const float* wts, long n, int nsamp, int inv,
+                       int argmax_vis, int testing, float* bvis, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * SG shading -- render_with_sg (model/sg_render.py:343-565) incl. lambda_trick (:84-104), hemisphere_int (:62-81).
+ * lgt: [M,7] (per_point_lgt=0) or [n,M,7]; light_vis[n,M] or NULL (comp_vis=False); metallic[n] or NULL;
+ * indir_integral[n,3] or NULL (replaces the diffuse term).  Outputs [n,3]; out_shadow may be NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_sg_shade(const float* normal, const float* view, const float* lgt, int per_point_lgt, int M, float f0,
+                const float* rough, const float* albedo, const float* metallic, const float* light_vis,
+                const float* bvis, const float* indir_integral, int lin_diff, long n, float* out_rgb, float* out_spec,
+                float* out_diff, float* out_shadow, rb_stream_t stream);
+/* y = x/(|x|+eps) (mode 0) or x/max(|x|,eps) (mode 1) on rows of 3 */
+int rb_normalize3(const float* x, long n, float eps, int mode, float* y, rb_stream_t stream);
 
 #ifdef __cplusplus
 }

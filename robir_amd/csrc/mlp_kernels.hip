@@ -85,10 +85,12 @@ __device__ __forceinline__ void write_pe_tangent(const float x[3], int c, float*
 }
 
 // X[M,128] = [PE10(p) | PE10(d) | 0 0]   (VisNetwork input, implicit_differentiable_renderer.py:250-256)
-__global__ void k_feat_vis(const float* __restrict__ p, const float* __restrict__ d, long M, float* __restrict__ X) {
+__global__ void k_feat_vis(const float* __restrict__ p, const float* __restrict__ d, long M, int rep,
+                           float* __restrict__ X) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= M) return;
-  float a[3] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+  const long ip = i / rep;  // each point is paired with `rep` consecutive directions
+  float a[3] = {p[3 * ip], p[3 * ip + 1], p[3 * ip + 2]};
   float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
   float* row = X + i * 128;
   write_pe<10>(a, row);
@@ -563,10 +565,11 @@ int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad
   return check_launch("k_pack_layer");
 }
 
-int rb_feat_vis(const float* p, const float* d, long M, float* X, rb_stream_t stream) {
+int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(p && d && X, "null pointer");
-  hipLaunchKernelGGL(k_feat_vis, grid1d(M, 256), dim3(256), 0, (hipStream_t)stream, p, d, M, X);
+  RB_REQUIRE(rep >= 1, "rep must be >= 1");
+  hipLaunchKernelGGL(k_feat_vis, grid1d(M, 256), dim3(256), 0, (hipStream_t)stream, p, d, M, rep, X);
   return check_launch("k_feat_vis");
 }
 

@@ -1,0 +1,408 @@
+"""nn.Module mirrors of the reference's networks: identical constructor arguments and state-dict keys
+(so Norm/Vis/PBR checkpoints load unchanged), forward passes run on the HIP kernels.
+
+Mirrors: model/implicit_differentiable_renderer.py:170-258 (IndirctIllumNetwork, VisNetwork),
+model/sg_envmap_material.py:40-275 (SparseAE, EnvmapMaterialNetwork),
+model/neus_model.py:312-438,489-560,644-650,682-884 (SDFNetwork, RenderingNetwork, SingleVarianceNetwork,
+NeuSModel, ImplicitNetworkMy).
+
+Forward-only: the kernels carry no autograd.  A parameter that requires grad while torch.is_grad_enabled() and the
+module is in training mode raises (the drop-in is for inference / --plot_only rendering).
+Every forward that the reference randomises takes the draws as an optional explicit tensor (`noise=`); when omitted
+they are drawn with torch.randn on the device, in the reference's order.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+
+
+def _param_sig(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+class _Packed:
+    """Lazy, parameter-version-keyed cache of packed weight blobs."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, key, module, builder):
+        sig = (_param_sig(module), str(next(module.parameters()).device))
+        ent = self._cache.get(key)
+        if ent is None or ent[0] != sig:
+            sd = {k: v.detach() for k, v in module.state_dict(prefix="").items()}
+            ent = (sig, builder(sd))
+            self._cache[key] = ent
+        return ent[1]
+
+
+def _require_dims(name, got, want):
+    if list(got) != list(want):
+        raise NotImplementedError(f"{name}: the HIP kernels are built for dims {want}, got {list(got)}")
+
+
+def _dev(module):
+    return next(module.parameters()).device
+
+
+# ----------------------------------------------------------------------------------------- visibility
+class VisNetwork(nn.Module):
+    """implicit_differentiable_renderer.py:225-258."""
+
+    def __init__(self, points_multires=10, dirs_multires=4, dims=[128, 128, 128, 128]):
+        super().__init__()
+        if points_multires != 10 or dirs_multires != 10:
+            raise NotImplementedError("HIP visibility kernels are built for points_multires = dirs_multires = 10")
+        _require_dims("visibility_network", dims, [256] * 4)
+        layers, dim = [], 126
+        for d in dims:
+            layers += [nn.Linear(dim, d), nn.ReLU()]
+            dim = d
+        layers.append(nn.Linear(dim, 2))
+        self.vis_layer = nn.Sequential(*layers)
+        self._packed = _Packed()
+
+    def _rename(self, sd):
+        return {"visibility_network." + k: v for k, v in sd.items()}
+
+    def packed_full(self):
+        return self._packed.get("full", self, lambda sd: packing.pack_vis(self._rename(sd), _dev(self)))
+
+    def packed_split(self):
+        return self._packed.get("split", self, lambda sd: packing.pack_vis_split(self._rename(sd), _dev(self)))
+
+    def forward(self, points, view_dirs):
+        if points.shape[0] == 0:
+            return torch.zeros(0, 2, device=points.device)
+        return ops.vis_mlp(ops.feat_vis(points.float().contiguous(), view_dirs.float().contiguous()), self.packed_full())
+
+
+# ----------------------------------------------------------------------------------------- sparse auto-encoder
+class SparseAE(nn.Module):
+    """sg_envmap_material.py:40-118 (forward/encode)."""
+
+    def __init__(self, in_dim, out_dim, smooth_on_latent=True, out_act=torch.sigmoid, latent_dim=32, high_lr=False):
+        super().__init__()
+        if latent_dim != 32 or in_dim > 64 or out_dim > 16:
+            raise NotImplementedError("HIP SparseAE kernels: in_dim <= 64, latent 32, out_dim <= 16")
+        enc, dim = [], in_dim
+        for d in [512, 512, 512, 512]:
+            enc += [nn.Linear(dim, d), nn.LeakyReLU(0.2)]
+            dim = d
+        enc.append(nn.Linear(dim, latent_dim))
+        self.brdf_encoder_layer = nn.Sequential(*enc)
+        dec, dim = [], latent_dim
+        for d in [128, 128]:
+            dec += [nn.Linear(dim, d), nn.LeakyReLU(0.2)]
+            dim = d
+        dec.append(nn.Linear(dim, out_dim))
+        self.brdf_decoder_layer = nn.Sequential(*dec)
+        self.in_dim, self.out_dim, self.latent_dim = in_dim, out_dim, latent_dim
+        self.smooth_on_latent = smooth_on_latent
+        self.out_act = out_act
+        self.high_lr = high_lr
+        self.lc_act = torch.sigmoid            # runners replace this with F.softplus for the integral layer
+        self.var = torch.zeros(latent_dim)     # plain attribute, like the reference (not in the state dict)
+        self._packed = _Packed()
+
+    def _blobs(self):
+        return self._packed.get("ae", self, lambda sd: packing.pack_sparse_ae(
+            {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
+
+    def _latent_act_code(self):
+        name = getattr(self.lc_act, "__name__", "")
+        if name == "softplus":
+            return 1
+        if name == "sigmoid":
+            return 0
+        raise NotImplementedError(f"latent activation {self.lc_act}")
+
+    def _var(self, dev):
+        v = self.var
+        if isinstance(v, torch.Tensor) and bool((v != 0).any()):
+            return v.to(device=dev, dtype=torch.float32).contiguous()
+        return None
+
+    def run(self, X, noise=None, X_noisy=None):
+        """X [n,64] padded features.  smooth_on_latent: noise [n,32]; else X_noisy [n,64] = features of the perturbed input."""
+        enc, dec = self._blobs()
+        dev = X.device
+        sig_out = self.out_act is not None
+        if sig_out and getattr(self.out_act, "__name__", "") != "sigmoid":
+            raise NotImplementedError("out_act must be torch.sigmoid or None")
+        if self.smooth_on_latent:
+            lat, lat2 = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code(), noise, 0.01)
+        else:
+            lat, _ = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code())
+            lat2, _ = ops.ae_latent(ops.ae_encode(X_noisy, enc), self._var(dev), self._latent_act_code())
+        return ops.ae_decode(lat, dec, self.out_dim, sig_out), ops.ae_decode(lat2, dec, self.out_dim, sig_out)
+
+    def forward(self, values, noise=None):
+        """values [n,in_dim] already-embedded inputs (as the reference passes them)."""
+        n = values.shape[0]
+        X = torch.zeros(n, 64, device=values.device)
+        X[:, :self.in_dim] = values
+        if self.smooth_on_latent:
+            if noise is None:
+                noise = torch.randn(n, 32, device=values.device)
+            return self.run(X, noise=noise)
+        if noise is None:
+            noise = torch.randn(n, self.in_dim, device=values.device)
+        Xn = torch.zeros(n, 64, device=values.device)
+        Xn[:, :self.in_dim] = ops.axpy(values.contiguous(), noise.contiguous(), 0.02)
+        return self.run(X, X_noisy=Xn)
+
+
+# ----------------------------------------------------------------------------------------- indirect illumination
+class IndirctIllumNetwork(nn.Module):
+    """implicit_differentiable_renderer.py:170-222."""
+
+    def __init__(self, multires=0, dims=[128, 128, 128, 128], num_lgt_sgs=24, no_hdr=False):
+        super().__init__()
+        if multires != 10 or num_lgt_sgs != 24 or no_hdr:
+            raise NotImplementedError("HIP indirect-illumination kernels: multires=10, 24 lobes, hdr input")
+        _require_dims("indirect_illum_network", dims, [512] * 4)
+        self.num_lgt_sgs = num_lgt_sgs
+        self.use_hdr = True
+        layers, dim = [], 64
+        for d in dims:
+            layers += [nn.Linear(dim, d), nn.ReLU()]
+            dim = d
+        layers.append(nn.Linear(dim, num_lgt_sgs * 6))
+        self.lobe_layer = nn.Sequential(*layers)
+        self.integral_layer = SparseAE(64, 3, out_act=None, smooth_on_latent=False)
+        self.integral_layer.lc_act = torch.nn.functional.softplus
+        self._packed = _Packed()
+
+    def forward(self, points, hdr_shift, noise=None):
+        n = points.shape[0]
+        dev = points.device
+        blob = self._packed.get("lobe", self.lobe_layer, lambda sd: packing.pack_illum(
+            {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
+        X = ops.feat_pe10(points.float().contiguous(), extra=hdr_shift.float().contiguous())
+        sgs = ops.illum_decode(ops.illum_mlp(X, blob))
+        if noise is None:
+            noise = torch.randn(n, 64, device=dev)
+        Xn = ops.axpy(X, noise.float().contiguous(), 0.02)
+        _, second = self.integral_layer.run(X, X_noisy=Xn)
+        return sgs, second.abs()
+
+
+# ----------------------------------------------------------------------------------------- materials + light
+def fibonacci_sphere(samples=1):
+    from .synth import fibonacci_lobes
+    return fibonacci_lobes(samples).astype(np.float64)
+
+
+def compute_energy(lgtSGs):
+    lam = torch.abs(lgtSGs[:, 3:4])
+    mu = torch.abs(lgtSGs[:, 4:])
+    return mu * 2.0 * np.pi / lam * (1.0 - torch.exp(-2.0 * lam))
+
+
+class EnvmapMaterialNetwork(nn.Module):
+    """sg_envmap_material.py:121-275."""
+
+    def __init__(self, multires=0, brdf_encoder_dims=[512, 512, 512, 512], brdf_decoder_dims=[128, 128],
+                 num_lgt_sgs=32, upper_hemi=False, specular_albedo=0.02, latent_dim=32):
+        super().__init__()
+        if multires != 10:
+            raise NotImplementedError("HIP material kernels: multires=10")
+        self.numLgtSGs = num_lgt_sgs
+        self.envmap = None
+        self.latent_dim = latent_dim
+        self.brdf_encoder_layer = SparseAE(63, 5, out_act=None)
+        self.spec_brdf_encoder_layer = SparseAE(63, 5, high_lr=True)
+        self.normal_decoder_layer = SparseAE(60, 3, out_act=None, smooth_on_latent=False)
+        self.specular_reflectance = nn.Parameter(torch.full((1, 1), float(specular_albedo)))
+        from .synth import synth_light_sgs
+        self.lgtSGs = nn.Parameter(torch.from_numpy(synth_light_sgs(0, num_lgt_sgs)))
+        self.upper_hemi = upper_hemi
+
+    def restrict_lobes_upper(self, lgtSGs):
+        return torch.cat((lgtSGs[..., :1], torch.abs(lgtSGs[..., 1:2]), lgtSGs[..., 2:]), dim=-1)
+
+    def forward(self, points, train_spec=False, train_norm=False, noise=None):
+        """noise: dict with optional 'spec' [n,32] and 'normal' [n,60]."""
+        noise = noise or {}
+        n, dev = points.shape[0], points.device
+        pts = points.float().contiguous()
+        nz_n = noise.get("normal")
+        if train_norm is False or train_spec:
+            nz_s = noise.get("spec")
+            if nz_s is None:
+                nz_s = torch.randn(n, 32, device=dev)
+            brdf, brdf_r = self.spec_brdf_encoder_layer.run(ops.feat_pe10(pts), noise=nz_s.float().contiguous())
+        if nz_n is None:
+            nz_n = torch.randn(n, 60, device=dev)
+        nm, nm_r = self.normal_decoder_layer.run(ops.feat_ipe(pts, 1e-5),
+                                                 X_noisy=ops.feat_ipe(pts, 1e-5, nz_n.float().contiguous(), 0.02))
+        normal_map = ops.normalize3(nm, 1e-4, 1)
+        random_xi_normal = ops.normalize3(nm_r, 1e-4, 1)
+        if train_norm:
+            return {"sg_normal_map": normal_map, "random_xi_normal": random_xi_normal}
+        lgtSGs = self.restrict_lobes_upper(self.lgtSGs) if self.upper_hemi else self.lgtSGs
+        return {
+            "sg_lgtSGs": lgtSGs,
+            "sg_specular_reflectance": self.specular_reflectance,
+            "sg_roughness": brdf[..., 3:4] * 0.9 + 0.09,
+            "sg_metallic": brdf[..., 4:5] * 0.99 + 0.01,
+            "sg_normal_map": normal_map,
+            "sg_diffuse_albedo": brdf[..., :3],
+            "random_xi_roughness": brdf_r[..., 3:4] * 0.9 + 0.09,
+            "random_xi_metallic": brdf_r[..., 4:5],
+            "random_xi_diffuse_albedo": brdf_r[..., :3],
+            "random_xi_normal": random_xi_normal,
+        }
+
+    def get_light(self):
+        lgtSGs = self.lgtSGs.clone().detach()
+        return self.restrict_lobes_upper(lgtSGs) if self.upper_hemi else lgtSGs
+
+    def load_light(self, path):
+        """sg_envmap_material.py:257-268 (the .npy light; an .exr background is loaded only if a reader exists)."""
+        sg = torch.from_numpy(np.load(os.path.join(path, "sg_128.npy"))).to(self.lgtSGs.data.device)
+        self.lgtSGs.data = sg
+        exr = path + ".exr"
+        if os.path.exists(exr):
+            try:
+                import imageio
+                self.envmap = torch.from_numpy(np.float32(imageio.imread(exr)[:, :, :3])).to(sg.device)
+            except Exception as e:  # pragma: no cover
+                raise RuntimeError(f"cannot read {exr}: {e}")
+
+    def parameter_groups(self, lr=0.0005):
+        return [{"lr": lr, "params": self.brdf_encoder_layer.parameters()},
+                {"lr": lr, "params": self.spec_brdf_encoder_layer.parameters()},
+                {"lr": lr, "params": self.normal_decoder_layer.parameters()},
+                {"lr": lr, "params": self.specular_reflectance},
+                {"lr": lr, "params": self.lgtSGs}]
+
+
+# ----------------------------------------------------------------------------------------- NeuS networks
+def _wn_linear(k_in, n_out):
+    return nn.utils.weight_norm(nn.Linear(k_in, n_out))
+
+
+class SDFNetwork(nn.Module):
+    """neus_model.py:312-438 for the configuration NeuSModel instantiates (d_in 3, 257 out, 256x8, skip 4, PE10)."""
+
+    def __init__(self):
+        super().__init__()
+        dims = [63] + [256] * 8 + [257]
+        for l in range(9):
+            out = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
+            setattr(self, "lin%d" % l, _wn_linear(dims[l], out))
+        self.scale = 1
+        self._packed = _Packed()
+
+    def _sd(self, sd):
+        return {"implicit_network.neus_model.sdf_network." + k: v for k, v in sd.items()}
+
+    def packed(self, full):
+        return self._packed.get("full" if full else "sdf", self,
+                                lambda sd: packing.pack_sdf(self._sd(sd), _dev(self), full=full))
+
+    def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False):
+        """x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx."""
+        x = x.float().contiguous()
+        M = x.shape[0]
+        mode = (1 if full else 0) + (2 if grad else 0)
+        X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
+        return ops.sdf_mlp(X, M, self.packed(full), mode, out_scale, out_scale * in_scale)
+
+    def forward(self, inputs):
+        if inputs.numel() == 0:
+            return torch.ones_like(inputs)
+        shape = list(inputs.shape[:-1]) + [-1]
+        out, _ = self.eval_points(inputs.reshape(-1, 3))
+        return out.reshape(shape)
+
+    def sdf(self, x):
+        out, _ = self.eval_points(x.reshape(-1, 3), full=False)
+        return out[:, None]
+
+    def sdf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        _, g = self.eval_points(x.reshape(-1, 3), full=False, grad=True)
+        return g.unsqueeze(1)
+
+
+class RenderingNetwork(nn.Module):
+    """neus_model.py:489-560, mode 'idr' (d_feature 256, d_hidden 256, 4 layers, multires_view 4)."""
+
+    def __init__(self):
+        super().__init__()
+        dims = [289, 256, 256, 256, 256, 3]
+        for l in range(5):
+            setattr(self, "lin%d" % l, _wn_linear(dims[l], dims[l + 1]))
+        self._packed = _Packed()
+
+    def packed(self):
+        return self._packed.get("c", self, lambda sd: packing.pack_color(
+            {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
+
+    def forward(self, points, normals, view_dirs, feature_vectors, x_scale=1.0, feat_scale=1.0):
+        X = ops.feat_color(points.float().contiguous(), view_dirs.float().contiguous(), normals.float().contiguous(),
+                           feature_vectors, x_scale=x_scale, feat_scale=feat_scale)
+        return ops.color_mlp(X, self.packed())
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(init_val)))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
+
+
+class NeuSModel(nn.Module):
+    """neus_model.py:682-752 (mode 'idr', hashing False, no outside NeRF)."""
+
+    def __init__(self, mode="idr", hashing=False, outside=False, embed="PE"):
+        super().__init__()
+        if mode != "idr" or hashing or outside or embed != "PE":
+            raise NotImplementedError("only the shipped NeuS configuration (idr / PE / no hash / no outside) is built")
+        self.color_network = RenderingNetwork()
+        self.sdf_network = SDFNetwork()
+        self.deviation_network = SingleVarianceNetwork(0.3)
+
+    def sdf(self, x):
+        return self.sdf_network.sdf(x)
+
+    def sdf_and_feat(self, x):
+        out = self.sdf_network(x)
+        return out[..., :1], out[..., 1:]
+
+    def color(self, x, gradients, dirs, feature_vector):
+        return self.color_network(x, gradients, dirs, feature_vector)
+
+    def grad(self, x):
+        shape = list(x.shape[:-1]) + [-1]
+        return self.sdf_network.gradient(x.reshape(-1, 3)).reshape(shape)
+
+    def dev(self, x):
+        return self.deviation_network(x)
+
+    def radius(self):
+        return 2.0
+
+    def inv_s(self):
+        return float(torch.exp(self.deviation_network.variance.detach() * 10.0).clip(1e-6, 1e6))
+
+    def forward(self, pnts, dirs, **kwargs):
+        shape = list(pnts.shape[:-1]) + [-1]
+        if len(shape) > dirs.dim():
+            dirs = dirs[:, None, :].expand(pnts.shape)
+        x, d = pnts.reshape(-1, 3), dirs.reshape(-1, 3)
+        out, g = self.sdf_network.eval_points(x, full=True, grad=True)
+        rgb = self.color_network(x, g, d, out[:, 1:])
+        return rgb.view(shape), out[:, :1].reshape(shape)

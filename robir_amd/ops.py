@@ -15,11 +15,13 @@ def _f32(t):
     return t.contiguous()
 
 
-def feat_vis(p, d):
+def feat_vis(p, d, rep=1):
+    """p [M/rep,3] points, d [M,3] directions (rep consecutive directions per point)."""
     p, d = _f32(p), _f32(d)
-    M = p.shape[0]
+    M = d.shape[0]
+    assert p.shape[0] * rep == M
     X = torch.empty(M, 128, dtype=torch.float32, device=p.device)
-    call("rb_feat_vis", ptr(p), ptr(d), c_long(M), ptr(X), stream_ptr())
+    call("rb_feat_vis", ptr(p), ptr(d), c_long(M), c_int(rep), ptr(X), stream_ptr())
     return X
 
 
@@ -124,3 +126,77 @@ def axpy(a, b, s):
     y = torch.empty_like(a)
     call("rb_axpy", ptr(a), ptr(b), c_float(s), c_long(a.numel()), ptr(y), stream_ptr())
     return y
+
+
+def normalize3(x, eps, mode):
+    x = _f32(x)
+    y = torch.empty_like(x)
+    call("rb_normalize3", ptr(x), c_long(x.shape[0]), c_float(eps), c_int(mode), ptr(y), stream_ptr())
+    return y
+
+
+def dvis_dirs(lgt, u_theta, u_phi, thr=1.0):
+    """lgt [L,7]; u_theta/u_phi [C,L,nsamp] (or [L,nsamp]).  -> dirs [C*L*nsamp,3], wdir [C*L*nsamp], wsum [C*L]."""
+    lgt, u_theta, u_phi = _f32(lgt), _f32(u_theta), _f32(u_phi)
+    if u_theta.dim() == 2:
+        u_theta, u_phi = u_theta[None], u_phi[None]
+    C, L, ns = u_theta.shape
+    dev = lgt.device
+    dirs = torch.empty(C * L * ns, 3, dtype=torch.float32, device=dev)
+    wdir = torch.empty(C * L * ns, dtype=torch.float32, device=dev)
+    wsum = torch.empty(C * L, dtype=torch.float32, device=dev)
+    call("rb_dvis_dirs", ptr(lgt), c_int(L), c_int(ns), c_int(C), ptr(u_theta.contiguous()), ptr(u_phi.contiguous()),
+         c_float(thr), ptr(dirs), ptr(wdir), ptr(wsum), stream_ptr())
+    return dirs, wdir, wsum
+
+
+def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None):
+    normals = _f32(normals)
+    n = normals.shape[0]
+    out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
+    if chunk_id is not None:
+        assert chunk_id.dtype == torch.int32
+    call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+         ptr(split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L), c_int(nsamp),
+         c_int(1 if argmax_vis else 0), ptr(out), ptr(eval_count), stream_ptr())
+    return out
+
+
+def spec_vis_sample(normal, view, rough, chunk_id, n_chunks, u_theta, u_phi):
+    normal, view, rough = _f32(normal), _f32(view), _f32(rough).reshape(-1)
+    u_theta, u_phi = _f32(u_theta), _f32(u_phi)
+    n, ns = u_theta.shape
+    dev = normal.device
+    sharp = torch.empty(n, dtype=torch.float32, device=dev)
+    cmin = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+    dirs = torch.empty(n * ns, 3, dtype=torch.float32, device=dev)
+    wts = torch.empty(n * ns, dtype=torch.float32, device=dev)
+    front = torch.empty(n * ns, dtype=torch.uint8, device=dev)
+    call("rb_spec_vis_sample", ptr(normal), ptr(view), ptr(rough), ptr(chunk_id), c_long(n), c_int(n_chunks), c_int(ns),
+         ptr(u_theta), ptr(u_phi), ptr(sharp), ptr(cmin), ptr(dirs), ptr(wts), ptr(front), stream_ptr())
+    return dirs, wts, front
+
+
+def spec_vis_reduce(logits, front, wts, n, nsamp, inv, argmax_vis, testing):
+    bvis = torch.empty(n, dtype=torch.float32, device=logits.device)
+    call("rb_spec_vis_reduce", ptr(logits), ptr(front), ptr(wts), c_long(n), c_int(nsamp), c_int(int(inv)),
+         c_int(int(argmax_vis)), c_int(int(testing)), ptr(bvis), stream_ptr())
+    return bvis
+
+
+def sg_shade(normal, view, lgt, f0, rough, albedo, bvis, light_vis=None, metallic=None, indir_integral=None,
+             lin_diff=False, want_shadow=False):
+    normal, view, lgt, albedo = _f32(normal), _f32(view), _f32(lgt), _f32(albedo)
+    rough = _f32(rough).reshape(-1)
+    n = normal.shape[0]
+    per_point = lgt.dim() == 3
+    M = lgt.shape[-2]
+    dev = normal.device
+    rgb, spec, diff = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
+    shadow = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_shadow else None
+    call("rb_sg_shade", ptr(normal), ptr(view), ptr(lgt), c_int(1 if per_point else 0), c_int(M), c_float(f0), ptr(rough),
+         ptr(albedo), ptr(_f32(metallic).reshape(-1) if metallic is not None else None),
+         ptr(_f32(light_vis) if light_vis is not None else None), ptr(bvis),
+         ptr(_f32(indir_integral) if indir_integral is not None else None), c_int(1 if lin_diff else 0), c_long(n),
+         ptr(rgb), ptr(spec), ptr(diff), ptr(shadow), stream_ptr())
+    return rgb, spec, diff, shadow

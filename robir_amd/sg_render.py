@@ -1,0 +1,227 @@
+"""Drop-in for the reference's model/sg_render.py: same public names and signatures, HIP kernels underneath.
+
+render_with_all_sg / render_with_sg (sg_render.py:304-565), get_diffuse_visibility (:111-195),
+get_specular_visibility (:198-301), hemisphere_int / lambda_trick / norm_axis (:62-108), envmap helpers (:9-59).
+
+Extensions (keyword-only, ignored by reference callers):
+  draws     dict of explicit uniform draws replacing the torch.rand calls ('dvis_theta','dvis_phi' [C,L,nsamp] or
+            [L,nsamp]; 'svis_theta_dir','svis_phi_dir','svis_theta_ind','svis_phi_ind' [n,8]);
+  chunk_id  int32 [n] + n_chunks: several 1024-pixel chunks in one call, each keeping its own draws and its own
+            batch-global minimum in the specular cone (sg_render.py:222), i.e. exactly what the reference computes
+            when it renders the chunks one after another;
+  stats     dict receiving 'diffuse_vis_evals' (device counter tensor).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .nets import VisNetwork
+
+TINY_NUMBER = 1e-6
+
+
+# ----------------------------------------------------------------------------------------- small public helpers
+def norm_axis(x):
+    return ops.normalize3(x.reshape(-1, 3).float().contiguous(), TINY_NUMBER, 0).reshape(x.shape)
+
+
+def render_envmap_sg(lgtSGs, viewdirs):
+    """sum_k mu_k exp(lambda_k (d.lobe_k - 1)) (sg_render.py:26-42) -- logging helper, evaluated with torch ops."""
+    viewdirs = viewdirs.to(lgtSGs.device).unsqueeze(-2)
+    lobes = lgtSGs[..., :3] / torch.norm(lgtSGs[..., :3], dim=-1, keepdim=True)
+    lam, mu = torch.abs(lgtSGs[..., 3:4]), torch.abs(lgtSGs[..., -3:])
+    return torch.sum(mu * torch.exp(lam * (torch.sum(viewdirs * lobes, dim=-1, keepdim=True) - 1.0)), dim=-2)
+
+
+def compute_envmap(lgtSGs, H, W, upper_hemi=False):
+    phi, theta = torch.meshgrid([torch.linspace(0.0, np.pi / 2.0 if upper_hemi else np.pi, H),
+                                 torch.linspace(1.0 * np.pi, -1.0 * np.pi, W)], indexing="ij")
+    viewdirs = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], -1)
+    return render_envmap_sg(lgtSGs, viewdirs).reshape(H, W, 3)
+
+
+def render_envmap(envmap, viewdirs):
+    """Bilinear lat-long lookup (sg_render.py:45-59)."""
+    import torch.nn.functional as F
+    envmap = envmap.permute(2, 0, 1).unsqueeze(0)
+    phi = torch.arccos(viewdirs[:, 2]).reshape(-1) - TINY_NUMBER
+    theta = torch.atan2(viewdirs[:, 1], viewdirs[:, 0]).reshape(-1)
+    grid = torch.stack(((-theta / np.pi), (phi / np.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)
+    return F.grid_sample(envmap, grid, align_corners=True).squeeze().permute(1, 0)
+
+
+# ----------------------------------------------------------------------------------------- visibility
+def _rand(shape, device):
+    return torch.rand(*shape, device=device)
+
+
+def _chunks(chunk_id, n_chunks):
+    return (None, 1) if chunk_id is None else (chunk_id, int(n_chunks))
+
+
+def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=8, testing=False, thr=1.0,
+                           bounding=False, argmax_vis=False, *, draws=None, chunk_id=None, n_chunks=1, stats=None):
+    """-> vis [L, n] (sg_render.py:111-195).  lgtSGLobes [L,3], lgtSGLambdas [L,1]."""
+    if bounding:
+        raise NotImplementedError("bounding=True (per-sample visibilities) has no caller in the reference")
+    dev = points.device
+    L = lgtSGLobes.shape[0]
+    n = points.shape[0]
+    cid, C = _chunks(chunk_id, n_chunks)
+    lgt = torch.zeros(L, 7, device=dev)
+    lgt[:, :3] = lgtSGLobes
+    lgt[:, 3:4] = lgtSGLambdas
+    if draws is not None and "dvis_theta" in draws:
+        u_t, u_p = draws["dvis_theta"], draws["dvis_phi"]
+    else:
+        u_t, u_p = _rand((C, L, nsamp), dev), _rand((C, L, nsamp), dev)
+    return _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats,
+                             lobes_prenormalised=True).t()
+
+
+def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats,
+                      lobes_prenormalised=False):
+    """-> [n, L].  lgt [L,7] raw light SGs."""
+    dev = points.device
+    if u_t.dim() == 2:
+        u_t, u_p = u_t[None], u_p[None]
+    assert u_t.shape[0] == C
+    _, L, nsamp = u_t.shape
+    if lobes_prenormalised:
+        # caller already applied lobe/(|lobe|+eps) once; rb_dvis_dirs applies it twice like the reference's call chain,
+        # so undo nothing: x/(|x|+eps) of an (almost) unit vector differs by 1e-6 -- keep the exact chain instead
+        lgt = lgt.clone()
+    dirs, wdir, wsum = ops.dvis_dirs(lgt, u_t.to(dev), u_p.to(dev), thr)
+    if isinstance(VisModel, VisNetwork):
+        sp = VisModel.packed_split()
+        A = ops.linear_64_256(ops.feat_pe10(points.float().contiguous()), sp["point"])
+        Bd = ops.linear_64_256(ops.feat_pe10(dirs), sp["dir"])
+        cnt = None
+        if stats is not None:
+            cnt = stats.setdefault("diffuse_vis_evals", torch.zeros(1, dtype=torch.int64, device=dev))
+        return ops.dvis_fused(normals.float().contiguous(), cid, A, Bd, dirs, wdir, wsum, sp, L, nsamp, argmax_vis, cnt)
+    return _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis)
+
+
+def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis):
+    """Any other VisModel callable (e.g. OctreeVisModel): directions/weights from the HIP kernel, the callable is
+    evaluated on the culled pairs in 2M batches like the reference."""
+    n = points.shape[0]
+    LS = L * nsamp
+    d = dirs.reshape(C, LS, 3)
+    c = torch.zeros(n, dtype=torch.long, device=points.device) if cid is None else cid.long()
+    dd = d[c]                                                   # [n, LS, 3]
+    front = (normals.unsqueeze(1) * dd).sum(-1) > TINY_NUMBER
+    pi_, di_ = front.nonzero(as_tuple=True)
+    logits = torch.zeros(pi_.shape[0], 2, device=points.device)
+    for s in range(0, pi_.shape[0], 2000000):
+        logits[s:s + 2000000] = VisModel(points[pi_[s:s + 2000000]], dd[pi_[s:s + 2000000], di_[s:s + 2000000]])
+    pv = logits.argmax(-1).float() if argmax_vis else torch.softmax(logits, -1)[..., 1]
+    vis = torch.zeros(n, LS, device=points.device)
+    vis[front] = pv
+    w = wdir.reshape(C, L, nsamp)[c]
+    return (vis.reshape(n, L, nsamp) * w).sum(-1) / wsum.reshape(C, L)[c]
+
+
+def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, cid, C):
+    """-> bvis [n] for the warped BRDF lobe of each point (lobe/lambda are recomputed from normal, view, roughness)."""
+    n, nsamp = u_t.shape
+    dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
+    if isinstance(VisModel, VisNetwork):
+        logits = ops.vis_mlp(ops.feat_vis(points.float().contiguous(), dirs, rep=nsamp), VisModel.packed_full())
+    else:
+        logits = VisModel(points.unsqueeze(1).expand(-1, nsamp, 3).reshape(-1, 3), dirs).float().contiguous()
+    return ops.spec_vis_reduce(logits, front, wts, n, nsamp, inv, argmax_vis, testing)
+
+
+def get_specular_visibility(points, normals, viewdirs, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=24, multi_view=False,
+                            testing=False, inv=False, argmax_vis=False, *, roughness=None, draws=None):
+    """Single-view branch of sg_render.py:198-301.  The HIP path derives the warped lobe from (normal, view,
+    roughness), so callers outside render_with_sg must pass `roughness`."""
+    if multi_view:
+        raise NotImplementedError("multi_view specular visibility is not on the hot path (MULTI_VIEW never set)")
+    if roughness is None:
+        raise NotImplementedError("pass roughness= (the warped BRDF lobe is recomputed on the device)")
+    n = points.shape[0]
+    if draws is None:
+        u_t, u_p = _rand((n, nsamp), points.device), _rand((n, nsamp), points.device)
+    else:
+        u_t, u_p = draws
+    return _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, None, 1)
+
+
+# ----------------------------------------------------------------------------------------- shading
+def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo, comp_vis=True,
+                   VisModel=None, fun_spec=False, lin_diff=False, testing=False, indir_integral=None, metallic=None,
+                   diffuse_vis=None, prefit=False, argmax_vis=False, *, draws=None, chunk_id=None, n_chunks=1,
+                   stats=None):
+    """sg_render.py:343-565 (single view).  lgtSGs [n,M,7] (or [M,7])."""
+    if fun_spec:
+        raise NotImplementedError("fun_spec=True (specular as a closure) is a training-only path")
+    if diffuse_vis is not None:
+        raise NotImplementedError("diffuse_vis (CESR shadow_net supervision) is not built yet")
+    if viewdirs.dim() == 3:
+        raise NotImplementedError("multi-view shading is not on the hot path")
+    dev = points.device
+    n = points.shape[0]
+    cid, C = _chunks(chunk_id, n_chunks)
+    draws = draws or {}
+    pts = points.float().contiguous()
+    nrm = normal.float().contiguous()
+    vd = viewdirs.float().contiguous()
+    rough = roughness.float().contiguous().reshape(-1)
+    f0 = float(specular_reflectance.reshape(-1)[0])
+    shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
+    lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
+    light_vis = None
+    if comp_vis:
+        nsamp = 32
+        u_t = draws.get("dvis_theta")
+        u_p = draws.get("dvis_phi")
+        if u_t is None:
+            L = lgt_first.shape[0]
+            u_t, u_p = _rand((C, L, nsamp), dev), _rand((C, L, nsamp), dev)
+        # first row's light for every point (sg_render.py:388-390)
+        light_vis = _diffuse_vis_core(pts, nrm, VisModel, lgt_first, u_t, u_p, 1.0, argmax_vis, cid, C, stats)
+    u_t, u_p = draws.get("svis_theta"), draws.get("svis_phi")
+    if u_t is None:
+        u_t, u_p = _rand((n, 8), dev), _rand((n, 8), dev)
+    bvis = _specular_vis_core(pts, nrm, vd, VisModel, rough, u_t.to(dev), u_p.to(dev), testing, not comp_vis, argmax_vis,
+                              cid, C)
+    lgt = lgt_first if shared else lgtSGs.float().contiguous()
+    rgb, spec, diff, shadow = ops.sg_shade(nrm, vd, lgt, f0, rough, diffuse_albedo, bvis, light_vis=light_vis,
+                                           metallic=metallic, indir_integral=indir_integral, lin_diff=lin_diff,
+                                           want_shadow=True)
+    return {"sg_rgb": rgb, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": shadow,
+            "supervise": torch.tensor(0.0, device=dev)}
+
+
+def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo,
+                       indir_integral=None, indir_lgtSGs=None, VisModel=None, fun_spec=False, lin_diff=False,
+                       testing=False, metallic=None, diffuse_vis=None, prefit=False, argmax_vis=False, *, draws=None,
+                       chunk_id=None, n_chunks=1, stats=None):
+    """sg_render.py:304-337: direct pass (light visibility) + indirect pass (per-point lobes, inverted specular
+    visibility, diffuse := indir_integral)."""
+    draws = draws or {}
+    d_dir = {k: draws[k] for k in ("dvis_theta", "dvis_phi") if k in draws}
+    if "svis_theta_dir" in draws:
+        d_dir.update(svis_theta=draws["svis_theta_dir"], svis_phi=draws["svis_phi_dir"])
+    ret = render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo,
+                         comp_vis=True, VisModel=VisModel, fun_spec=fun_spec, lin_diff=lin_diff, testing=testing,
+                         metallic=metallic, diffuse_vis=diffuse_vis, prefit=prefit, argmax_vis=argmax_vis, draws=d_dir,
+                         chunk_id=chunk_id, n_chunks=n_chunks, stats=stats)
+    zeros = torch.zeros_like(points)
+    ind = {"sg_rgb": zeros, "sg_diffuse_rgb": zeros, "sg_specular_rgb": zeros}
+    if indir_lgtSGs is not None:
+        d_ind = {}
+        if "svis_theta_ind" in draws:
+            d_ind.update(svis_theta=draws["svis_theta_ind"], svis_phi=draws["svis_phi_ind"])
+        ind = render_with_sg(points, normal, viewdirs, indir_lgtSGs, specular_reflectance, roughness, diffuse_albedo,
+                             comp_vis=False, VisModel=VisModel, fun_spec=fun_spec, lin_diff=lin_diff, testing=testing,
+                             indir_integral=indir_integral, metallic=metallic, diffuse_vis=None, argmax_vis=argmax_vis,
+                             draws=d_ind, chunk_id=chunk_id, n_chunks=n_chunks)
+    ret.update({"indir_rgb": ind["sg_rgb"], "indir_diffuse_rgb": ind["sg_diffuse_rgb"],
+                "indir_specular_rgb": ind["sg_specular_rgb"]})
+    return ret
