@@ -125,6 +125,61 @@ int rb_sg_shade(const float* normal, const float* view, const float* lgt, int pe
 /* y = x/(|x|+eps) (mode 0) or x/max(|x|,eps) (mode 1) on rows of 3 */
 int rb_normalize3(const float* x, long n, float eps, int mode, float* y, rb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Octree over the SDF zero set + lock-step sphere tracer.
+ * Replaces: utils/octree.py:124-199,217-265,377-438,459-471,493-592 (OctreeSDF build / query / cast /
+ * multi_step_cast / fast_volume_render / first_nonzero=torch_scatter.scatter_min), model/octree_tracing.py:31-60.
+ * Tables: node[B][8] floats = {min.xyz, bits(first_child int32, -1 leaf)}, {size.xyz, sdf_val}; nrm[B][3] unit
+ * gradient; children of a split node are contiguous; base grid cell (ix,iy,iz) = (ix*res[1]+iy)*res[2]+iz.
+ * root_min[3], root_size[3], res[3] are HOST arrays.
+ * Build steps (host loops over <= 4 levels; sdf/grad come from rb_sdf_mlp on `centre` rows):
+ *   base_grid -> { mark_split (flag, exclusive rank, *total = number of splits) -> subdivide } x levels -> store_cells.
+ * Cast: a lock-step batch is (a) one workgroup of rb_octree_cast_batched when it has <= 1024 rays -- R_total rays are
+ *   cut into consecutive batches of `batch` rays, origins[n_batches,3] (per_ray_origin=0) or [R_total,3];
+ *   sched (may be NULL): int32[n_batches, sched_cap, 2] receives (n_active, multi_samp) per iteration --
+ *   or (b) init / iter / finish launches for one batch of any size (counters: int32[>= max iterations + 2], zeroed).
+ * max_iter <= 0: primary rays (run until no ray is active); max_iter = 32: secondary rays (origin + 0.005 d,
+ *   break after max_iter+1 iterations, still-active rays are hits).  step: 0.001 primary, 0.005 / 0.01 secondary.
+ * clamp_dt = 10*min_step.  Outputs: x[R,3] = t*d + o, hit[R] uint8, t[R].
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_octree_base_grid(const float* root_min, const float* root_size, const int* res, float* node, float* centre,
+                        rb_stream_t stream);
+int rb_octree_mark_split(const float* node, long first, long count, const float* sdf, float thr, int* flag, int* rank,
+                         int* scan_tmp, int* total, rb_stream_t stream);
+int rb_octree_subdivide(float* node, float* centre, long first, long count, const int* flag, const int* rank,
+                        long new_first, rb_stream_t stream);
+int rb_octree_store_cells(float* node, float* nrm, long first, long count, const float* sdf, const float* grad,
+                          rb_stream_t stream);
+int rb_octree_cast_batched(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                           const int* res, const float* origins, int per_ray_origin, const float* dirs, long R_total,
+                           int batch, int max_iter, double step, float clamp_dt, float* x_out, unsigned char* hit_out,
+                           float* t_out, int* sched, int sched_cap, rb_stream_t stream);
+int rb_octree_cast_init(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                        const int* res, const float* origins, const float* dirs, long R, int max_iter, float* t,
+                        int* leaf, unsigned char* active, int* counters, rb_stream_t stream);
+int rb_octree_cast_iter(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                        const int* res, const float* origins, const float* dirs, long R, int max_iter, double step,
+                        int it_first, int it_count, float* t, int* leaf, unsigned char* active, int* counters,
+                        rb_stream_t stream);
+int rb_octree_cast_finish(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                          const int* res, const float* origins, const float* dirs, long R, int max_iter, float clamp_dt,
+                          const float* t, const int* leaf, float* x_out, unsigned char* hit_out, float* t_out,
+                          rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Ray generation / points / tone mapping.
+ * rb_camera_rays: get_camera_params + lift, 4x4 pose (utils/rend_util.py:51-97).  pose_host: 16 floats row-major
+ *   camera-to-world (HOST), K_host: 9 floats row-major intrinsics (HOST); uv[N,2] (x = column, y = row) -> dirs[N,3].
+ * rb_points_along: pts = o + t*d (implicit_differentiable_renderer.py:324); origins [N/batch,3] or per ray.
+ * rb_tonemap: ACESToneMapping hdr_mode 0 (model/color_correction.py:52-60,116-134): mode 0 hdr2ldr, 1 ldr2hdr,
+ *   2 ldr2hdr(x^2.2); rows of 3 channels, shift[n] (stride 1) or one value (stride 0), clamped to [1e-4,1].
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv, long N, float* dirs,
+                   rb_stream_t stream);
+int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,
+                    float* pts, rb_stream_t stream);
+int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,109 @@ def sg_shade(normal, view, lgt, f0, rough, albedo, bvis, light_vis=None, metalli
          ptr(_f32(indir_integral) if indir_integral is not None else None), c_int(1 if lin_diff else 0), c_long(n),
          ptr(rgb), ptr(spec), ptr(diff), ptr(shadow), stream_ptr())
     return rgb, spec, diff, shadow
+
+
+# ------------------------------------------------------------------------------------------------ octree
+def _host3(a, ctype):
+    import numpy as np
+    arr = np.ascontiguousarray(a, dtype=np.float32 if ctype is ctypes.c_float else np.int32)
+    return (ctype * 3)(*[arr[i].item() for i in range(3)])
+
+
+class OctreeTablesDev:
+    """Device octree tables in the layout of include/robir_hip.h + host root description."""
+
+    def __init__(self, node, nrm, B, root_min, root_size, res, min_step):
+        self.node, self.nrm, self.B = node, nrm, int(B)
+        self.root_min, self.root_size, self.res = root_min, root_size, res       # numpy float32[3], float32[3], int32[3]
+        self.min_step = float(min_step)
+
+    def args(self):
+        return (ptr(self.node), ptr(self.nrm), c_long(self.B), _host3(self.root_min, ctypes.c_float),
+                _host3(self.root_size, ctypes.c_float), _host3(self.res, ctypes.c_int))
+
+    @property
+    def clamp_dt(self):
+        return self.min_step * 10
+
+
+def octree_cast_batched(T, origins, per_ray_origin, dirs, batch, max_iter, step, sched_cap=0):
+    dirs = _f32(dirs)
+    origins = _f32(origins)
+    R = dirs.shape[0]
+    dev = dirs.device
+    x = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    hit = torch.empty(R, dtype=torch.uint8, device=dev)
+    t = torch.empty(R, dtype=torch.float32, device=dev)
+    nb = (R + batch - 1) // batch
+    sched = torch.zeros(nb, sched_cap, 2, dtype=torch.int32, device=dev) if sched_cap > 0 else None
+    call("rb_octree_cast_batched", *T.args(), ptr(origins), c_int(1 if per_ray_origin else 0), ptr(dirs), c_long(R),
+         c_int(batch), c_int(max_iter), ctypes.c_double(step), c_float(T.clamp_dt), ptr(x), ptr(hit), ptr(t), ptr(sched),
+         c_int(sched_cap), stream_ptr())
+    return x, hit.bool(), t, sched
+
+
+def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_total=4096):
+    """One lock-step batch of any size: origins/dirs [R,3]."""
+    dirs, origins = _f32(dirs), _f32(origins)
+    R = dirs.shape[0]
+    dev = dirs.device
+    t = torch.empty(R, dtype=torch.float32, device=dev)
+    leaf = torch.empty(R, dtype=torch.int32, device=dev)
+    active = torch.empty(R, dtype=torch.uint8, device=dev)
+    counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
+    a = T.args()
+    call("rb_octree_cast_init", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ptr(t), ptr(leaf), ptr(active),
+         ptr(counters), stream_ptr())
+    if max_iter > 0:
+        call("rb_octree_cast_iter", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step),
+             c_int(0), c_int(max_iter + 1), ptr(t), ptr(leaf), ptr(active), ptr(counters), stream_ptr())
+    else:
+        it = 0
+        while it < max_total:
+            call("rb_octree_cast_iter", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step),
+                 c_int(it), c_int(check_every), ptr(t), ptr(leaf), ptr(active), ptr(counters), stream_ptr())
+            it += check_every
+            if int(counters[it].item()) == 0:      # host sync once per `check_every` iterations
+                break
+    x = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    hit = torch.empty(R, dtype=torch.uint8, device=dev)
+    t_out = torch.empty(R, dtype=torch.float32, device=dev)
+    call("rb_octree_cast_finish", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), c_float(T.clamp_dt), ptr(t),
+         ptr(leaf), ptr(x), ptr(hit), ptr(t_out), stream_ptr())
+    return x, hit.bool(), t_out, counters
+
+
+def camera_rays(pose, K, uv):
+    """pose [4,4], K [3,3] host-side tensors/arrays; uv [N,2] device."""
+    import numpy as np
+    p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).reshape(16))
+    k = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(9))
+    uv = _f32(uv)
+    N = uv.shape[0]
+    dirs = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
+    call("rb_camera_rays", p.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), ptr(uv), c_long(N),
+         ptr(dirs), stream_ptr())
+    return dirs
+
+
+def points_along(origins, dirs, t, batch=None):
+    """origins [N,3] (per ray) or [N/batch,3]."""
+    origins, dirs, t = _f32(origins), _f32(dirs), _f32(t)
+    N = dirs.shape[0]
+    pts = torch.empty(N, 3, dtype=torch.float32, device=dirs.device)
+    per_ray = batch is None
+    call("rb_points_along", ptr(origins), c_int(1 if per_ray else 0), c_long(1 if per_ray else batch), ptr(dirs), ptr(t),
+         c_long(N), ptr(pts), stream_ptr())
+    return pts
+
+
+def tonemap(x, shift, mode):
+    x = _f32(x)
+    shift = _f32(shift).reshape(-1)
+    n = x.shape[0]
+    y = torch.empty_like(x)
+    stride = 0 if shift.numel() == 1 else 1
+    assert stride == 0 or shift.numel() == n
+    call("rb_tonemap", ptr(x), c_long(n), ptr(shift), c_int(stride), c_int(mode), ptr(y), stream_ptr())
+    return y
