@@ -180,6 +180,27 @@ int rb_points_along(const float* origins, int per_ray_origin, long batch, const 
                     float* pts, rb_stream_t stream);
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Secondary rays / NeuS compositing -- IDRNetwork.trace_radiance (implicit_differentiable_renderer.py:566-650),
+ * ImplicitNetworkMy.borrow_color / volume_render (model/neus_model.py:828-871), render_core weights
+ * (model/sdf_render.py:209-240).
+ * rb_sphere_dirs: u1,u2[n*nsamp] uniform draws -> dirs[n*nsamp,3]; back[n*nsamp] = (n.d < 0) with n = normal/max(|n|,1e-4);
+ *   cosw = relu(n.d); origins[n,3] = points + 0.005 n.
+ * rb_borrow_points: x[m*ns,3] = 2 p + dir t_k, dirs[m*ns,3] = dir = -view/|view|, tk[ns] device.
+ * rb_neus_composite: alpha_k = clip((sig(s_k inv_s) - sig(s_{k+1} inv_s) + 1e-5)/(sig(s_k inv_s) + 1e-5), lo, hi) [* mask],
+ *   (last sample uses s_{ns-1} twice), w_k = alpha_k prod_{j<k}(1 - alpha_j + eps); rgb[m,3] = sum w_k color_k
+ *   (color, mask, rgb, weights may be NULL).
+ * rb_trace_integrate: out[n,3] = sum_k rad cosw / max(#front-facing, 1e-4).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_sphere_dirs(const float* u1, const float* u2, const float* normals, const float* points, long n, int nsamp,
+                   float* dirs, unsigned char* back, float* cosw, float* origins, rb_stream_t stream);
+int rb_borrow_points(const float* points, const float* view, const float* tk, long m, int ns, float* x, float* dirs,
+                     rb_stream_t stream);
+int rb_neus_composite(const float* sdf, const float* color, const float* mask, long m, int ns, float inv_s, float lo,
+                      float hi, float eps, float* rgb, float* weights, rb_stream_t stream);
+int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char* back, long n, int nsamp, float* out,
+                       rb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,104 @@ __global__ void k_tonemap(const float* __restrict__ x, long n, const float* __re
   }
 }
 
+// ---- secondary-ray pieces (implicit_differentiable_renderer.py:583-641, neus_model.py:828-871)
+// uniform sphere directions from two uniform draws; back-face flag against the (unnormalised) normal;
+// secondary origin = x + 0.005 * n/|n|
+__global__ void k_sphere_dirs(const float* __restrict__ u1, const float* __restrict__ u2,
+                              const float* __restrict__ normals, const float* __restrict__ points, long n, int nsamp,
+                              float* __restrict__ dirs, unsigned char* __restrict__ back, float* __restrict__ cosw,
+                              float* __restrict__ origins) {
+  long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= n * nsamp) return;
+  const long i = j / nsamp;
+  const float pi = (float)3.14159265358979323846;
+  const float u = u1[j] * 2.f - 1.f;
+  const float t = u2[j] * pi * 2.f;
+  const float s = powf(1.f - u * u, 0.5f);
+  const float d[3] = {s * cosf(t), s * sinf(t), u};
+  float nn[3] = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+  const float ln = fmaxf(sqrtf(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]), 1e-4f);
+  nn[0] /= ln;
+  nn[1] /= ln;
+  nn[2] /= ln;
+  const float c = nn[0] * d[0] + nn[1] * d[1] + nn[2] * d[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dirs[3 * j + k] = d[k];
+  back[j] = c < 0.f ? 1 : 0;
+  cosw[j] = fmaxf(c, 0.f);
+  if (j % nsamp == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) origins[3 * i + k] = points[3 * i + k] + nn[k] * 0.005f;
+  }
+}
+
+// NeuS sample points of borrow_color: x = 2p + dir*t_k with dir = -view/|view| (neus_model.py:856-865)
+__global__ void k_borrow_points(const float* __restrict__ points, const float* __restrict__ view,
+                                const float* __restrict__ tk, long m, int ns, float* __restrict__ x,
+                                float* __restrict__ dirs) {
+  long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= m * ns) return;
+  const long i = j / ns;
+  const int k = (int)(j % ns);
+  const float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
+  const float ln = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float d = -v[c] / ln;
+    x[3 * j + c] = points[3 * i + c] * 2.f + d * tk[k];
+    dirs[3 * j + c] = d;
+  }
+}
+
+// NeuS alpha compositing of ns samples per ray (neus_model.py:828-854 / sdf_render.py:209-240):
+// alpha from consecutive-sample SDFs, clipped to [lo,hi], optional per-sample mask, weights = alpha * cumprod.
+__global__ void k_neus_composite(const float* __restrict__ sdf, const float* __restrict__ color,
+                                 const float* __restrict__ mask, long m, int ns, float inv_s, float lo, float hi,
+                                 float eps, float* __restrict__ rgb, float* __restrict__ weights) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  float T = 1.f, acc[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < ns; ++k) {
+    const float prv = sdf[i * ns + k];
+    const float nxt = sdf[i * ns + (k + 1 < ns ? k + 1 : ns - 1)];
+    const float sp = (k + 1 < ns) ? prv : sdf[i * ns + ns - 1];
+    const float c0 = 1.f / (1.f + expf(-(sp * inv_s)));
+    const float c1 = 1.f / (1.f + expf(-(nxt * inv_s)));
+    float a = ((c0 - c1) + 1e-5f) / (c0 + 1e-5f);
+    a = fminf(fmaxf(a, lo), hi);
+    if (mask) a = a * mask[i * ns + k];
+    const float w = a * T;
+    if (weights) weights[i * ns + k] = w;
+    if (color) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += color[(i * ns + k) * 3 + c] * w;
+    }
+    T = T * (1.f - a + eps);
+  }
+  if (rgb) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[3 * i + c] = acc[c];
+  }
+}
+
+// cosine-weighted hemisphere mean of the traced radiance (implicit_differentiable_renderer.py:639-641)
+__global__ void k_trace_integrate(const float* __restrict__ rad, const float* __restrict__ cosw,
+                                  const unsigned char* __restrict__ back, long n, int nsamp, float* __restrict__ out) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+  int cnt = 0;
+  for (int k = 0; k < nsamp; ++k) {
+    const long j = i * nsamp + k;
+    cnt += back[j] ? 0 : 1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += rad[3 * j + c] * cosw[j];
+  }
+  const float den = fmaxf((float)cnt, 1e-4f);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[3 * i + c] = acc[c] / den;
+}
+
 }  // namespace rb
 
 using namespace rb;
@@ -95,6 +193,41 @@ int rb_points_along(const float* origins, int per_ray_origin, long batch, const 
   hipLaunchKernelGGL(k_points_along, grid1d(N, 256), dim3(256), 0, (hipStream_t)stream, origins, per_ray_origin, batch,
                      dirs, t, N, pts);
   return check_launch("k_points_along");
+}
+
+int rb_sphere_dirs(const float* u1, const float* u2, const float* normals, const float* points, long n, int nsamp,
+                   float* dirs, unsigned char* back, float* cosw, float* origins, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(u1 && u2 && normals && points && dirs && back && cosw && origins, "null pointer");
+  hipLaunchKernelGGL(k_sphere_dirs, grid1d(n * nsamp, 256), dim3(256), 0, (hipStream_t)stream, u1, u2, normals, points, n,
+                     nsamp, dirs, back, cosw, origins);
+  return check_launch("k_sphere_dirs");
+}
+
+int rb_borrow_points(const float* points, const float* view, const float* tk, long m, int ns, float* x, float* dirs,
+                     rb_stream_t stream) {
+  if (m <= 0) return 0;
+  RB_REQUIRE(points && view && tk && x && dirs, "null pointer");
+  hipLaunchKernelGGL(k_borrow_points, grid1d(m * ns, 256), dim3(256), 0, (hipStream_t)stream, points, view, tk, m, ns, x,
+                     dirs);
+  return check_launch("k_borrow_points");
+}
+
+int rb_neus_composite(const float* sdf, const float* color, const float* mask, long m, int ns, float inv_s, float lo,
+                      float hi, float eps, float* rgb, float* weights, rb_stream_t stream) {
+  if (m <= 0) return 0;
+  RB_REQUIRE(sdf && (rgb == nullptr || color != nullptr), "null pointer");
+  hipLaunchKernelGGL(k_neus_composite, grid1d(m, 128), dim3(128), 0, (hipStream_t)stream, sdf, color, mask, m, ns, inv_s,
+                     lo, hi, eps, rgb, weights);
+  return check_launch("k_neus_composite");
+}
+
+int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char* back, long n, int nsamp, float* out,
+                       rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(rad && cosw && back && out, "null pointer");
+  hipLaunchKernelGGL(k_trace_integrate, grid1d(n, 128), dim3(128), 0, (hipStream_t)stream, rad, cosw, back, n, nsamp, out);
+  return check_launch("k_trace_integrate");
 }
 
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream) {

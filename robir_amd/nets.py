@@ -406,3 +406,137 @@ class NeuSModel(nn.Module):
         out, g = self.sdf_network.eval_points(x, full=True, grad=True)
         rgb = self.color_network(x, g, d, out[:, 1:])
         return rgb.view(shape), out[:, :1].reshape(shape)
+
+
+class ImplicitNetworkMy(nn.Module):
+    """neus_model.py:755-884: stage-2 wrapper around the NeuS model (points x2 in, all 257 outputs /2 out).
+    The constructor arguments of the conf (dims, multires, ...) are ignored exactly like the reference does; the NeuS
+    checkpoint named by confs_sg.env_path is loaded when that module is importable and the file exists."""
+
+    def __init__(self, feature_vector_size=None, d_in=None, d_out=None, dims=None, geometric_init=True, bias=1.0,
+                 skip_in=(), weight_norm=True, multires=0, bgr=False):
+        super().__init__()
+        self.neus_model = NeuSModel(mode="idr", hashing=False, embed="PE")
+        self.bgr = bgr
+        try:
+            from confs_sg.env_path import NEUS_LOG_DIR, NEUS_ITER      # reference-side global (confs_sg/env_path.py)
+            path = os.path.join(NEUS_LOG_DIR, "{:06d}.tar".format(NEUS_ITER))
+            if os.path.exists(path):
+                state = torch.load(path, map_location="cpu", weights_only=False)
+                self.neus_model.load_state_dict(state["model"], strict=False)
+        except ImportError:
+            pass
+
+    def normalize(self, x):
+        return x * 2.0
+
+    def forward(self, points, compute_grad=False):
+        if points.numel() == 0:
+            return torch.ones_like(points)
+        out, _ = self.neus_model.sdf_network.eval_points(points.reshape(-1, 3), 2.0, 0.5, full=True)
+        return out
+
+    def sdf_only(self, points):
+        """[M] stage-2 signed distance (last layer restricted to its first row)."""
+        return self.neus_model.sdf_network.eval_points(points.reshape(-1, 3), 2.0, 0.5, full=False)[0]
+
+    def color(self, points, normals, view_dirs, feature_vectors):
+        c = self.neus_model.color_network(points, normals, view_dirs, feature_vectors, x_scale=2.0)
+        return c.flip(-1) if self.bgr else c
+
+    def gradient(self, x):
+        if x.numel() == 0:
+            return torch.ones_like(x)
+        _, g = self.neus_model.sdf_network.eval_points(x.reshape(-1, 3), 2.0, 0.5, full=False, grad=True)
+        return g.unsqueeze(1)
+
+    def get_parameter_groups(self, **lr_dict):
+        res = []
+        if "color" in lr_dict:
+            res += [{"lr": lr_dict["color"], "params": self.neus_model.sdf_network.parameters()}]
+        if "sdf" in lr_dict:
+            res += [{"lr": lr_dict["sdf"], "params": self.neus_model.color_network.parameters()}]
+        return res
+
+    def volume_render(self, sdf, color):
+        """sdf [m,ns,1], color [m,ns,3] -> [m,3] (neus_model.py:828-854)."""
+        rgb, _ = ops.neus_composite(sdf.reshape(sdf.shape[0], -1).contiguous(), color.contiguous(),
+                                    self.neus_model.inv_s())
+        return rgb
+
+    def borrow_color(self, points, view_dirs):
+        tk = torch.linspace(-0.01, 0.05, 16).to(points.device)
+        x, d = ops.borrow_points(points, view_dirs, tk)
+        net = self.neus_model.sdf_network
+        out, g = net.eval_points(x, 1.0, 1.0, full=True, grad=True)
+        col = self.neus_model.color_network(x, g, d, out[:, 1:])
+        m = points.shape[0]
+        rgb, _ = ops.neus_composite(out[:, 0].reshape(m, 16).contiguous(), col.reshape(m, 16, 3), self.neus_model.inv_s())
+        return rgb
+
+    def batch_borrow_color(self, points, view_dirs, batch_size=8192):
+        if points.shape[0] == 0:
+            return torch.zeros_like(points)
+        with torch.no_grad():
+            outs = [self.borrow_color(points[i:i + batch_size].contiguous(), view_dirs[i:i + batch_size].contiguous())
+                    for i in range(0, points.shape[0], batch_size)]
+        return torch.cat(outs, 0)
+
+
+# ----------------------------------------------------------------------------------------- tone mapping
+class ACESToneMapping(nn.Module):
+    """color_correction.py:76-137, hdr_mode 0 (scale_aces pair)."""
+
+    def __init__(self, hdr_mode=0):
+        super().__init__()
+        if hdr_mode != 0:
+            raise NotImplementedError("only hdr_mode = 0 (every shipped conf) is built")
+        self.adapt_illum = nn.Parameter(torch.tensor(0.0))
+        self.hdr_mode = hdr_mode
+
+    def as_input(self):
+        return torch.clamp(self.adapt_illum * 10 + 0.5, 0, 1).view(1, 1)
+
+    def make_shift(self, shift):
+        if shift is None:
+            shift = self.as_input()
+        if not isinstance(shift, torch.Tensor):
+            shift = torch.tensor(shift, device=self.adapt_illum.device)
+        if shift.dim() == 0:
+            shift = shift[None]
+        return shift.detach().float()
+
+    def _apply_tm(self, x, raw_shift, mode):
+        shape = x.shape
+        xs = x.detach().float().reshape(-1, 3).contiguous()
+        sh = self.make_shift(raw_shift).reshape(-1).to(xs.device)
+        if sh.numel() != 1 and sh.numel() != xs.shape[0]:
+            sh = sh.expand(xs.shape[0]) if sh.numel() == 1 else sh.reshape(-1)
+        return ops.tonemap(xs, sh.contiguous(), mode).reshape(shape)
+
+    def hdr2ldr(self, x, raw_shift=None):
+        return self._apply_tm(x, raw_shift, 0)
+
+    def ldr2hdr(self, x, raw_shift=None):
+        return self._apply_tm(x, raw_shift, 1)
+
+    def fit_data(self, data):
+        raise NotImplementedError("Energy.gen_cache is a training-time pre-fit (out of scope, SURVEY.md section 2 #9)")
+
+
+class GammaCorrect(nn.Module):
+    """color_correction.py:7-28."""
+
+    def __init__(self, gamma=2.2, hdr_mode=0):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.tensor(float(gamma)))
+        self.indir_coef = nn.Parameter(torch.tensor(1.0))
+        self.dir_coef = nn.Parameter(torch.tensor(2.0))
+        self.coef = nn.Parameter(torch.tensor(1.0))
+        self.hdr_shift = ACESToneMapping(hdr_mode=hdr_mode)
+
+    def forward(self, x):
+        return torch.pow(x, 1 / self.gamma)
+
+    def inv(self, x):
+        return torch.pow(x, self.gamma)

@@ -306,3 +306,45 @@ def tonemap(x, shift, mode):
     assert stride == 0 or shift.numel() == n
     call("rb_tonemap", ptr(x), c_long(n), ptr(shift), c_int(stride), c_int(mode), ptr(y), stream_ptr())
     return y
+
+
+# ------------------------------------------------------------------------------------------------ secondary rays / NeuS
+def sphere_dirs(u1, u2, normals, points, nsamp):
+    u1, u2, normals, points = _f32(u1).reshape(-1), _f32(u2).reshape(-1), _f32(normals), _f32(points)
+    n = points.shape[0]
+    dev = points.device
+    dirs = torch.empty(n * nsamp, 3, dtype=torch.float32, device=dev)
+    back = torch.empty(n * nsamp, dtype=torch.uint8, device=dev)
+    cosw = torch.empty(n * nsamp, dtype=torch.float32, device=dev)
+    origins = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    call("rb_sphere_dirs", ptr(u1), ptr(u2), ptr(normals), ptr(points), c_long(n), c_int(nsamp), ptr(dirs), ptr(back),
+         ptr(cosw), ptr(origins), stream_ptr())
+    return dirs, back, cosw, origins
+
+
+def borrow_points(points, view, tk):
+    points, view, tk = _f32(points), _f32(view), _f32(tk)
+    m, ns = points.shape[0], tk.numel()
+    x = torch.empty(m * ns, 3, dtype=torch.float32, device=points.device)
+    d = torch.empty(m * ns, 3, dtype=torch.float32, device=points.device)
+    call("rb_borrow_points", ptr(points), ptr(view), ptr(tk), c_long(m), c_int(ns), ptr(x), ptr(d), stream_ptr())
+    return x, d
+
+
+def neus_composite(sdf, color, inv_s, lo=0.0, hi=1.0, eps=1e-7, mask=None, want_weights=False):
+    """sdf [m,ns]; color [m,ns,3] or None."""
+    sdf = _f32(sdf)
+    m, ns = sdf.shape
+    dev = sdf.device
+    rgb = torch.empty(m, 3, dtype=torch.float32, device=dev) if color is not None else None
+    w = torch.empty(m, ns, dtype=torch.float32, device=dev) if want_weights else None
+    call("rb_neus_composite", ptr(sdf), ptr(_f32(color) if color is not None else None),
+         ptr(_f32(mask) if mask is not None else None), c_long(m), c_int(ns), c_float(inv_s), c_float(lo), c_float(hi),
+         c_float(eps), ptr(rgb), ptr(w), stream_ptr())
+    return rgb, w
+
+
+def trace_integrate(rad, cosw, back, n, nsamp):
+    out = torch.empty(n, 3, dtype=torch.float32, device=rad.device)
+    call("rb_trace_integrate", ptr(_f32(rad)), ptr(cosw), ptr(back), c_long(n), c_int(nsamp), ptr(out), stream_ptr())
+    return out

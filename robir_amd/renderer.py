@@ -1,0 +1,289 @@
+"""Drop-in for model/implicit_differentiable_renderer.py:261-650 (IDRNetwork) on the HIP kernels, plus the
+MI355X-first batched renderer that bench.py times.
+
+IDRNetwork(conf): same sub-module names / state-dict keys / methods the stage runners reach for:
+  .implicit_network .ray_tracer .octree_ray_tracer .indirect_illum_network .visibility_network
+  .envmap_material_network .gamma .rendering_network, forward(), get_idr_render(), assignable get_sg_render,
+  trace_radiance().
+forward() treats the rays it is given as ONE lock-step batch for the octree tracer, like the reference.
+
+render_chunks(): the same arithmetic for MANY 1024-pixel chunks in one pass -- every kernel sees all chunks at once
+(tens of thousands of surface points instead of ~500), while the two chunk-global quantities of the reference
+(the octree tracer's active-ray schedule, utils/octree.py:545-549, and the specular-cone minimum,
+model/sg_render.py:222) stay per chunk.  Results are what the reference produces rendering the chunks one by one.
+
+Forward only (no autograd through the kernels).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, sg_render
+from .nets import (ImplicitNetworkMy, IndirctIllumNetwork, VisNetwork, EnvmapMaterialNetwork, GammaCorrect)
+from .octree_tracing import OctreeTracing
+
+TINY_NUMBER = 1e-6
+
+
+def _cfg(conf, key):
+    sub = conf.get_config(key)
+    return {k: sub[k] for k in sub.keys()} if hasattr(sub, "keys") else dict(sub)
+
+
+class IDRNetwork(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        if not conf.get_bool("use_neus"):
+            raise NotImplementedError("use_neus=False (legacy IDR ImplicitNetwork) is dead in every shipped conf")
+        self.feature_vector_size = conf.get_int("feature_vector_size")
+        rt = _cfg(conf, "ray_tracer")
+        self.octree_ray_tracer = OctreeTracing(**rt, max_iter=32)
+        if not conf.get_bool("use_octree"):
+            raise NotImplementedError("use_octree=False (model/ray_tracing.py RayTracing) is a 'next' item (SURVEY 8f)")
+        self.ray_tracer = OctreeTracing(**rt)
+        self.object_bounding_sphere = conf.get_float("ray_tracer.object_bounding_sphere")
+        self.implicit_network = ImplicitNetworkMy(self.feature_vector_size, **_cfg(conf, "implicit_network"))
+        self.rendering_network = self.implicit_network.color
+        self.indirect_illum_network = IndirctIllumNetwork(**_cfg(conf, "indirect_illum_network"),
+                                                          no_hdr=conf.get_int("hdr_mode") == -1)
+        self.visibility_network = VisNetwork(**_cfg(conf, "visibility_network"))
+        self.envmap_material_network = EnvmapMaterialNetwork(**_cfg(conf, "envmap_material_network"))
+        self.gamma = GammaCorrect(conf.get_float("gamma"), conf.get_int("hdr_mode"))
+        self.ray_tracer.bind(self.implicit_network)
+        self.octree_ray_tracer.bind(self.implicit_network)
+        self.no_normal = False          # PBR hook: use the NeuS normal instead of the Norm-stage normal map
+        self.testing = True             # PBR hook's `testing = not is_training`
+
+    # ------------------------------------------------------------------ per-hit pieces
+    def get_idr_render(self, points, view_dirs=None, normal_only=False):
+        """implicit_differentiable_renderer.py:481-497."""
+        g = self.implicit_network.gradient(points)
+        normals = g[:, 0, :]
+        if normal_only:
+            return normals
+        feature_vectors = self.implicit_network(points)[:, 1:]
+        view_dirs = ops.normalize3(view_dirs.contiguous(), 1e-6, 0)
+        return normals, self.rendering_network(points, normals, view_dirs, feature_vectors)
+
+    def get_sg_render(self, points, view_dirs, indir_lgtSGs, albedo_ratio=None, fun_spec=False, lin_diff=False,
+                      train_spec=False, indir_integral=None, draws=None, chunk_id=None, n_chunks=1, stats=None, **kwargs):
+        """The hook the PBR runner installs (training/train_pbr.py:348-396), restated; the reference's class default
+        (implicit_differentiable_renderer.py:499-529) cannot run (KeyError 'metallic')."""
+        draws = draws or {}
+        vd = ops.normalize3(view_dirs.float().contiguous(), 1e-6, 0)
+        normals = ops.normalize3(self.get_idr_render(points, normal_only=True).contiguous(), 1e-4, 1)
+        mat = self.envmap_material_network(points, train_spec=True,
+                                           noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
+        shading_normal = normals if self.no_normal else mat["sg_normal_map"]
+        ret = sg_render.render_with_all_sg(points=points, normal=shading_normal, viewdirs=vd, lgtSGs=mat["sg_lgtSGs"],
+                                           indir_integral=indir_integral * 2 * np.pi,
+                                           specular_reflectance=mat["sg_specular_reflectance"].abs(),
+                                           roughness=mat["sg_roughness"], diffuse_albedo=mat["sg_diffuse_albedo"],
+                                           indir_lgtSGs=indir_lgtSGs, VisModel=self.visibility_network, fun_spec=False,
+                                           lin_diff=False, testing=self.testing, metallic=None, draws=draws,
+                                           chunk_id=chunk_id, n_chunks=n_chunks, stats=stats)
+        ret.update({"normals": normals, "diffuse_albedo": mat["sg_diffuse_albedo"], "roughness": mat["sg_roughness"],
+                    "metallic": mat["sg_metallic"], "normal_map": mat["sg_normal_map"],
+                    "random_xi_roughness": mat["random_xi_roughness"], "random_xi_metallic": mat["random_xi_metallic"],
+                    "random_xi_diffuse_albedo": mat["random_xi_diffuse_albedo"]})
+        return ret
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input, trainstage="IDR", fun_spec=False, lin_diff=False, train_spec=False, draws=None, stats=None):
+        """implicit_differentiable_renderer.py:290-479, uv/pose/intrinsics input form, batch size 1."""
+        if "intrinsics" not in input:
+            raise NotImplementedError("points/dirs input form (from_light plotting) is not built yet")
+        uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
+        if uv.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (every runner uses 1)")
+        N = uv.shape[1]
+        return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), N,
+                            trainstage, fun_spec, lin_diff, draws, stats, input.get("albedo_ratio"))
+
+    def render_chunks(self, uv, pose, K, hdr_shift, chunk=1024, trainstage="Material", draws=None, stats=None):
+        """uv [N,2] for any number of consecutive `chunk`-pixel chunks (chunk <= 1024); pose [4,4], K [3,3];
+        hdr_shift [N,1].  draws: dict as synth.pbr_draws but with 'dvis_*' stacked [C,L,32]."""
+        N = uv.shape[0]
+        mask = torch.ones(N, dtype=torch.bool, device=uv.device)
+        return self._render(uv, pose, K, mask, hdr_shift, chunk, trainstage, False, False, draws, stats, None)
+
+    def _render(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
+                albedo_ratio):
+        dev = uv.device
+        N = uv.shape[0]
+        draws = draws or {}
+        pose_h = pose.detach().cpu().numpy()
+        cam = pose[:3, 3].float().reshape(1, 3).contiguous()
+        with torch.no_grad():
+            dirs = ops.camera_rays(pose_h, K.detach().cpu().numpy(), uv.float().contiguous())
+            if chunk <= 1024:
+                _, hit, dist = self.ray_tracer.sdf_octree.cast_chunks(cam, dirs, chunk=chunk)
+                n_chunks = (N + chunk - 1) // chunk
+            else:
+                _, hit, dist = self.ray_tracer(sdf=None, cam_loc=cam, object_mask=object_mask, ray_directions=dirs[None])
+                n_chunks = 1
+            points = ops.points_along(cam.expand(N, 3).contiguous(), dirs, dist)
+            sdf_output = self.implicit_network.sdf_only(points)[:, None]
+        ret = {"points": points, "sdf_output": sdf_output, "network_object_mask": hit, "object_mask": object_mask,
+               "ray_dirs": dirs}
+        idx = hit.nonzero()[:, 0]
+        n = idx.shape[0]
+        hp = points[idx].contiguous()
+        cid = (idx // chunk).to(torch.int32).contiguous() if n_chunks > 1 else None
+        indirect_sgs = torch.ones(N, self.indirect_illum_network.num_lgt_sgs, 7, device=dev)
+        indirect_sgs[:, :, -3:] = 0
+        indirect_integral = torch.ones(N, 3, device=dev)
+        if hdr_shift is not None:
+            if n > 0:
+                sgs_h, int_h = self.indirect_illum_network(hp, hdr_shift[idx].contiguous(), noise=draws.get("illum_randn"))
+                indirect_sgs[idx] = sgs_h
+                indirect_integral[idx] = int_h
+            ret["hdr_shift"] = hdr_shift
+        if trainstage == "Illum":
+            normals = torch.ones_like(points)
+            if n > 0:
+                m = self.envmap_material_network(hp, train_spec=False, train_norm=True,
+                                                 noise={"normal": draws.get("normal_randn")})
+                normals[idx] = m["sg_normal_map"]
+            ret.update({"indirect_sgs": indirect_sgs, "indir_integral": indirect_integral, "normals": normals})
+            return ret
+
+        ones3 = lambda: torch.ones(N, 3, device=dev)
+        ones1 = lambda: torch.ones(N, 1, device=dev)
+        out3 = {k: ones3() for k in ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb",
+                                     "indir_specular_rgb", "normals", "diffuse_albedo", "roughness", "normal_map",
+                                     "vis_shadow", "random_xi_roughness", "random_xi_diffuse_albedo")}
+        out1 = {k: ones1() for k in ("metallic", "random_xi_metallic", "acc", "final_t")}
+        bg = ones3()
+        if self.envmap_material_network.envmap is not None:
+            bg = sg_render.render_envmap(self.envmap_material_network.envmap, dirs)
+        if n > 0:
+            view = (-dirs[idx]).contiguous()
+            kw = {}
+            if getattr(self.get_sg_render, "__func__", None) is IDRNetwork.get_sg_render:
+                kw = dict(draws=draws, chunk_id=cid, n_chunks=n_chunks, stats=stats)   # our own hook understands these
+            r = self.get_sg_render(hp, view, sgs_h if hdr_shift is not None else indirect_sgs[idx],
+                                   albedo_ratio=albedo_ratio, fun_spec=fun_spec, lin_diff=lin_diff, train_spec=True,
+                                   indir_integral=int_h if hdr_shift is not None else indirect_integral[idx],
+                                   tex_uv=None, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
+            for k in out3:
+                v = r[k]
+                out3[k][idx] = v.expand(-1, 3) if v.shape[-1] == 1 else v
+            out1["metallic"][idx] = r["metallic"]
+            out1["random_xi_metallic"][idx] = r["random_xi_metallic"]
+        ret.update({"gradient_error": torch.tensor(0.0, device=dev), "bg_rgb": bg, "surface_mask": hit})
+        ret.update(out3)
+        ret.update(out1)
+        return ret
+
+    # ------------------------------------------------------------------ secondary rays
+    def trace_radiance(self, input, nsamp=16, test_dir=None, draws=None):
+        """implicit_differentiable_renderer.py:566-650.  draws: (u1, u2) uniform [n*nsamp] replacing the two
+        torch.rand calls of spherical_uniform."""
+        if test_dir is not None:
+            raise NotImplementedError("test_dir (debug option) is not built")
+        points, shift, mask = input["points"], input["hdr_shift"], input["network_object_mask"]
+        dev = points.device
+        N = points.shape[0]
+        trace = torch.zeros(N, nsamp, 3, device=dev)
+        gt_vis = torch.zeros(N, nsamp, 1, dtype=torch.bool, device=dev)
+        pred_vis = torch.zeros(N, nsamp, 2, device=dev)
+        indir_mask = torch.zeros(N, nsamp, 1, dtype=torch.bool, device=dev)
+        gt_int = torch.zeros(N, 3, device=dev)
+        idx = mask.nonzero()[:, 0]
+        n = idx.shape[0]
+        sdirs = torch.zeros(n, nsamp, 3, device=dev)
+        if n > 0:
+            o = points[idx].contiguous()
+            nr = input["normals"].detach()[idx].contiguous()
+            if draws is None:
+                u1, u2 = torch.rand(n * nsamp).to(dev), torch.rand(n * nsamp).to(dev)   # CPU generator, like the reference
+            else:
+                u1, u2 = draws
+            d, back, cosw, origins = ops.sphere_dirs(u1.to(dev), u2.to(dev), nr, o, nsamp)
+            sdirs = d.reshape(n, nsamp, 3)
+            with torch.no_grad():
+                sec_x, sec_hit, _ = self.octree_ray_tracer(sdf=None, cam_loc=origins, object_mask=None,
+                                                           ray_directions=sdirs)
+            rad = torch.zeros(n * nsamp, 3, device=dev)
+            hidx = sec_hit.nonzero()[:, 0]
+            if hidx.numel() > 0:
+                col = self.implicit_network.batch_borrow_color(sec_x[hidx].contiguous(), (-d[hidx]).contiguous())
+                sh = shift[idx][:, None, :].expand(-1, nsamp, 1).reshape(-1)[hidx].contiguous()
+                rad[hidx] = ops.tonemap(col, sh, 2)
+            bmask = back.bool()
+            rad[bmask] = 0.0
+            trace[idx] = rad.reshape(n, nsamp, 3)
+            pv = self.visibility_network(o.unsqueeze(1).expand(-1, nsamp, 3).reshape(-1, 3).contiguous(), d)
+            pred_vis[idx] = pv.reshape(n, nsamp, 2)
+            gt_vis[idx] = sec_hit.reshape(n, nsamp, 1)
+            indir_mask[idx] = (~bmask).reshape(n, nsamp, 1) & sec_hit.reshape(n, nsamp, 1)
+            gt_int[idx] = ops.trace_integrate(rad, cosw, back, n, nsamp)
+        return {"trace_radiance": trace, "sample_dirs": sdirs, "gt_vis": gt_vis, "pred_vis": pred_vis,
+                "indir_mask": indir_mask[..., 0], "gt_integral": gt_int}
+
+
+# ----------------------------------------------------------------------------------------- construction helpers
+class DictConf:
+    """Minimal pyhocon-like accessor (get_bool/get_int/get_float/get_config, `**conf.get_config(...)`) so the model
+    can be built without pyhocon (tests, bench).  With pyhocon installed the reference's conf objects work as well."""
+
+    def __init__(self, d):
+        self.d = d
+
+    def _get(self, key):
+        cur = self.d
+        for part in key.split("."):
+            cur = cur[part]
+        return cur
+
+    def get_bool(self, k):
+        return bool(self._get(k))
+
+    def get_int(self, k):
+        return int(self._get(k))
+
+    def get_float(self, k):
+        return float(self._get(k))
+
+    def get_config(self, k):
+        return DictConf(self._get(k))
+
+    def keys(self):
+        return self.d.keys()
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+
+def hotdog_conf():
+    """model{} section of confs_sg/hotdog.conf:65-123 (truck.conf is identical in this section)."""
+    return DictConf({
+        "gamma": 1.0, "hdr_mode": 0, "use_neus": True, "use_octree": True, "feature_vector_size": 256,
+        "implicit_network": {"d_in": 3, "d_out": 1, "dims": [512] * 8, "geometric_init": True, "bias": 0.6,
+                             "skip_in": [4], "weight_norm": True, "multires": 6},
+        "rendering_network": {"mode": "idr", "d_in": 9, "d_out": 3, "dims": [512] * 4, "weight_norm": True,
+                              "multires_view": 4},
+        "indirect_illum_network": {"multires": 10, "dims": [512] * 4, "num_lgt_sgs": 24},
+        "visibility_network": {"points_multires": 10, "dirs_multires": 10, "dims": [256] * 4},
+        "envmap_material_network": {"multires": 10, "brdf_encoder_dims": [512] * 4, "brdf_decoder_dims": [128, 128],
+                                    "num_lgt_sgs": 128, "upper_hemi": False, "specular_albedo": 0.05, "latent_dim": 32},
+        "ray_tracer": {"object_bounding_sphere": 1.0, "sdf_threshold": 5.0e-5, "line_search_step": 0.5,
+                       "line_step_iters": 3, "sphere_tracing_iters": 10, "n_steps": 100, "n_rootfind_steps": 32},
+    })
+
+
+def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True):
+    """IDRNetwork with the synthetic weights of robir_amd.synth (the configuration tests and bench.py use)."""
+    from . import synth
+    sd = synth.synth_state_dict(seed, variance=variance, sharp_light=sharp_light)
+    model = IDRNetwork(hotdog_conf())
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    model = model.to(device).eval()
+    if build_octrees:
+        model.ray_tracer.generate()
+        model.octree_ray_tracer.sdf_octree = type(model.ray_tracer.sdf_octree)(model.ray_tracer.sdf_octree.tables, 32)
+    return model

@@ -172,7 +172,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     nrm = normal.float().contiguous()
     vd = viewdirs.float().contiguous()
     rough = roughness.float().contiguous().reshape(-1)
-    f0 = float(specular_reflectance.reshape(-1)[0])
+    f0 = float(specular_reflectance.detach().reshape(-1)[0])
     shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
     lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
     light_vis = None

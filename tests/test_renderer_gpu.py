@@ -1,0 +1,158 @@
+"""IDRNetwork drop-in on the GPU: forward('Material'), the batched multi-chunk renderer, forward('Illum') +
+trace_radiance -- against the oracle (same octree tables, same draws) and the reference's golden outputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, bad_frac, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from robir_amd import renderer
+    return renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+
+
+@pytest.fixture(scope="module")
+def model_oracle_tables(dev, oracle_octree):
+    """Same weights, but tracing the octree the ORACLE built: isolates everything downstream of the cast."""
+    from robir_amd import renderer
+    from robir_amd.octree_tracing import OctreeSDF
+    m = renderer.build_synthetic_model(dev, seed=0, variance=0.3, build_octrees=False)
+    m.ray_tracer.sdf_octree = OctreeSDF.from_oracle_tables(oracle_octree, dev, -1)
+    m.octree_ray_tracer.sdf_octree = OctreeSDF.from_oracle_tables(oracle_octree, dev, 32)
+    return m
+
+
+def _inputs(dev, c, H=64, W=64):
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(H, W)
+    sl = slice(c * 1024, (c + 1) * 1024)
+    return (torch.from_numpy(uv[sl]).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev), uv, pose, K, sl)
+
+
+FIELDS = ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb", "indir_specular_rgb",
+          "vis_shadow", "diffuse_albedo", "roughness", "metallic", "normals", "normal_map", "random_xi_roughness",
+          "random_xi_metallic", "random_xi_diffuse_albedo")
+
+
+def test_forward_material_vs_oracle_same_tables(dev, model_oracle_tables, oracle_sd, oracle_octree):
+    from robir_amd import synth
+    from robir_oracle import renderer as orend
+    c = 1
+    uv_d, pose_d, K_d, uv, pose, K, sl = _inputs(dev, c)
+    hdr = torch.full((1024, 1), 0.5)
+    # hit count of this chunk from the oracle cast (needed to size the draws)
+    dirs, cam = orend.camera_rays(torch.from_numpy(uv[sl])[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
+    from robir_oracle import octree as ooct
+    _, hit, _ = ooct.trace(oracle_octree, cam, dirs, -1)
+    n_hit = int(hit.sum())
+    dr = synth.pbr_draws(0, n_hit, chunk_id=c)
+    drt = {k: torch.from_numpy(v) for k, v in dr.items()}
+    stats_o = {}
+    ref = orend.forward(oracle_sd, oracle_octree, torch.from_numpy(uv[sl])[None], torch.from_numpy(pose)[None],
+                        torch.from_numpy(K)[None], torch.ones(1, 1024, dtype=torch.bool), hdr, drt, "Material",
+                        testing=True, stats=stats_o)
+    stats = {}
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr.to(dev)}
+    out = model_oracle_tables(inp, trainstage="Material", train_spec=True,
+                              draws={k: v.to(dev) for k, v in drt.items()}, stats=stats)
+    torch.cuda.synchronize()
+    assert bool((out["network_object_mask"].cpu() == ref["network_object_mask"]).all())
+    # the n.d > 1e-6 cull may flip for a direction whose cosine is within an ulp of the threshold
+    assert abs(int(stats["diffuse_vis_evals"]) - stats_o["diffuse_vis_evals"]) <= 4
+    assert rel_err(out["points"].cpu(), ref["points"]) <= 1e-6
+    assert rel_err(out["sdf_output"].cpu(), ref["sdf_output"]) <= 1e-4
+    # chained stages (materials -> illum SGs -> visibility -> shading): each stage is within 1e-4 on identical
+    # inputs (test_sg_gpu / test_mlp_gpu); the chain compounds fp32 noise, so: 99.8 % of entries within 2e-4, all < 1e-3
+    for k in FIELDS:
+        assert bad_frac(out[k].cpu(), ref[k], 2e-4) <= 0.002, (k, bad_frac(out[k].cpu(), ref[k], 2e-4))
+        assert rel_err(out[k].cpu(), ref[k]) <= 1e-3, (k, rel_err(out[k].cpu(), ref[k]))
+    # every key / shape / dtype of the reference's return dict
+    g = load_golden("forward_material_c1")
+    for k in g:
+        if k.startswith("out_"):
+            name = k[4:]
+            assert name in out, name
+            assert tuple(out[name].shape) == tuple(g[k].shape), (name, out[name].shape, g[k].shape)
+
+
+def test_forward_material_vs_reference_golden(dev, model):
+    """End to end with the device-built octree against the reference's own output (looser: PE amplifies the ~1e-6
+    hit-position noise of two independently built octrees 512-fold -- DESIGN.md 'Parity tolerances')."""
+    g = load_golden("forward_material_c1")
+    c = int(g["chunk"])
+    uv_d, pose_d, K_d, *_ = _inputs(dev, c)
+    draws = {k[5:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("draw_")}
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+           "hdr_shift": torch.from_numpy(g["hdr_shift"]).expand(1024, 1).contiguous().to(dev)}
+    out = model(inp, trainstage="Material", train_spec=True, draws=draws)
+    assert int((out["network_object_mask"].cpu().numpy() != g["out_network_object_mask"]).sum()) <= 2
+    same = torch.from_numpy(g["out_network_object_mask"]) == out["network_object_mask"].cpu()
+    for k in ("points", "sdf_output", "ray_dirs"):
+        assert bad_frac(out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 1e-4) <= 0.002, k
+    for k in FIELDS:
+        assert bad_frac(out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 2e-3) <= 0.003, k
+
+
+def test_batched_chunks_equal_per_chunk_forward(dev, model):
+    """render_chunks over 3 chunks == three forward() calls (chunk-global quantities stay per chunk)."""
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(64, 64)
+    pose_d, K_d = torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    hdr = torch.full((3072, 1), 0.5, device=dev)
+    uv_d = torch.from_numpy(uv[:3072]).to(dev)
+    # hits per chunk (to size the draws) from a draw-free Illum pass
+    pre = model.render_chunks(uv_d, pose_d, K_d, hdr, trainstage="Illum",
+                              draws={"illum_randn": None, "normal_randn": None})
+    hit = pre["network_object_mask"].cpu()
+    counts = [int(hit[i * 1024:(i + 1) * 1024].sum()) for i in range(3)]
+    per = [synth.pbr_draws(0, counts[i], chunk_id=i) for i in range(3)]
+    cat = {k: torch.from_numpy(np.concatenate([p[k] for p in per])).to(dev) for k in per[0] if not k.startswith("dvis")}
+    for k in ("dvis_theta", "dvis_phi"):
+        cat[k] = torch.from_numpy(np.stack([p[k] for p in per])).to(dev)
+    big = model.render_chunks(uv_d, pose_d, K_d, hdr, draws=cat)
+    for i in range(3):
+        sl = slice(i * 1024, (i + 1) * 1024)
+        inp = {"uv": uv_d[None, sl], "pose": pose_d[None], "intrinsics": K_d[None],
+               "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr[sl]}
+        one = model(inp, trainstage="Material", train_spec=True,
+                    draws={k: torch.from_numpy(v).to(dev) for k, v in per[i].items()})
+        for k in FIELDS + ("points", "sdf_output"):
+            e = rel_err(big[k][sl].cpu(), one[k].cpu())
+            assert e <= 1e-6, (i, k, e)
+
+
+def test_illum_and_trace_radiance_vs_golden(dev, model_oracle_tables):
+    g = load_golden("trace_radiance")
+    c = int(g["chunk"])
+    uv_d, pose_d, K_d, *_ = _inputs(dev, c)
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+           "hdr_shift": torch.from_numpy(g["in_hdr_shift"]).to(dev)}
+    ill = model_oracle_tables(inp, trainstage="Illum", draws={"illum_randn": torch.from_numpy(g["illum_noise"]).to(dev),
+                                                              "normal_randn": torch.from_numpy(g["normal_noise"]).to(dev)})
+    mask = torch.from_numpy(g["in_mask"])
+    assert int((ill["network_object_mask"].cpu() != mask).sum()) <= 2
+    assert bad_frac(ill["normals"].cpu(), g["in_normals"], 2e-3) <= 0.005
+    assert bad_frac(ill["indirect_sgs"].cpu(), g["illum_sgs"], 2e-3) <= 0.01
+    # trace_radiance fed with the REFERENCE's forward output (stage parity)
+    fwd = {"points": torch.from_numpy(g["in_points"]).to(dev), "hdr_shift": torch.from_numpy(g["in_hdr_shift"]).to(dev),
+           "network_object_mask": mask.to(dev), "normals": torch.from_numpy(g["in_normals"]).to(dev)}
+    out = model_oracle_tables.trace_radiance(fwd, nsamp=int(g["nsamp"]),
+                                             draws=(torch.from_numpy(g["u1"]), torch.from_numpy(g["u2"])))
+    assert rel_err(out["sample_dirs"].cpu(), g["out_sample_dirs"]) <= 1e-5
+    assert int((out["gt_vis"].cpu().numpy() != g["out_gt_vis"]).sum()) <= 4
+    assert rel_err(out["pred_vis"].cpu(), g["out_pred_vis"]) <= 1e-4
+    assert bad_frac(out["trace_radiance"].cpu(), g["out_trace_radiance"], 1e-3) <= 0.002
+    assert bad_frac(out["gt_integral"].cpu(), g["out_gt_integral"], 1e-3) <= 0.005
+    assert bool((out["indir_mask"].cpu().numpy() == g["out_indir_mask"]).mean() > 0.999)
