@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--chunks-per-batch", type=int, default=125, help="1024-pixel chunks rendered per kernel pass")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3"],
+                    help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
+                         "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
     return ap.parse_args()
 
 
@@ -149,8 +152,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from robir_amd import ops, renderer, synth
+    from robir_amd import ops, renderer, synth, sg_render
     from robir_amd.parallel import all_gather_tiles
+    if "ROBIR_VIS_PRECISION" not in os.environ:
+        sg_render.VIS_PRECISION = args.vis_precision
+    precision = sg_render.VIS_PRECISION
     t0 = time.time()
     model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
     torch.cuda.synchronize()
@@ -200,7 +206,8 @@ def main():
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if precision == "fp32" else "f32 (visibility hidden layers: 3x f16 hi/lo-split MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "hotdog-like synthetic 800x800 full PBR forward (BASELINE.json configs[3]): "
                                    "625 lock-step chunks of 1024 px per view, one view per GPU",
                        "image": [H, W], "chunk": CHUNK, "chunks_per_pass": args.chunks_per_batch,
@@ -208,7 +215,8 @@ def main():
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "parallelism": f"ray-shard x{world} (views)"},
             "roofline": {"bound": "mfma", "kernel": "k_dvis_fused (light-SG visibility MLP)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "precision": precision,
+                         "frac_of_f16x3_bound": (achieved / (2500.0 / 3.0)) if precision == "f16x3" else None,
                          "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                          "flops_per_eval": 2 * VIS_MACS_PER_EVAL},
         }

@@ -36,6 +36,10 @@ const char* rb_last_error(void);
  * k_perm (device int32[k_pad], may be NULL): packed input column k reads source column k_perm[k] (-1: zero).
  * ------------------------------------------------------------------------------------------------------------ */
 long rb_packed_layer_floats(int n_pad, int k_pad);
+/* split-precision packing: weights (and bias) scaled by 2^scale_log2, stored as hi/lo half pairs; k_pad % 32 == 0;
+ * same size as the fp32 packing. */
+int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, int scale_log2,
+                     float* out, rb_stream_t stream);
 int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
                   float w_scale, float* out, rb_stream_t stream);
 
@@ -94,12 +98,16 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  * rb_dvis_fused: one workgroup per point.  A[n,256] = W0[:, :63].PE10(p)+b0 and Bd[C*L*nsamp,256] = W0[:,63:].PE10(d)
  *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
  *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
+ *   precision 0: hidden layers on the f32-input MFMA (exact fp32 fma chain), Whid from rb_pack_layer;
+ *   precision 1: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
+ *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2.
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream);
 int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                   const float* wdir, const float* wsum, const float* Whid, const float* wlast, const float* blast, int L,
-                  int nsamp, int argmax_vis, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+                  int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
+                  unsigned long long* eval_count, rb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BRDF-lobe ("specular") visibility -- get_specular_visibility, single-view branch, model/sg_render.py:198-301.

@@ -72,33 +72,42 @@ struct WStream {
     cur = 0;
     tid = tid_;
   }
+  // Chunk copies are branch-free: a ragged tail (CF4 not a multiple of 256) is handled by clamping the element
+  // index, so surplus threads re-copy the last element (same value to the same address: benign).  A per-element
+  // `if (idx < CF4)` would make hipcc branch around every load and serialise them (cdna_hip_programming.md 4c).
+  template <int CF4>
+  __device__ __forceinline__ int elem(int i) const {
+    const int idx = i * WG_THREADS + tid;
+    if constexpr (CF4 % WG_THREADS == 0) {
+      return idx;
+    } else {
+      return ((i + 1) * WG_THREADS <= CF4) ? idx : (idx < CF4 ? idx : CF4 - 1);
+    }
+  }
   // Synchronously place the very first chunk of a pass into buffer `cur`.
   template <int CF4>
   __device__ __forceinline__ void prime(const f4* __restrict__ src) {
 #pragma unroll
     for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
-      int idx = i * WG_THREADS + tid;
-      if (idx < CF4) lds[cur * BUF_F4 + idx] = src[idx];
+      const int idx = elem<CF4>(i);
+      lds[cur * BUF_F4 + idx] = src[idx];
     }
     __syncthreads();
   }
   template <int CF4>
   __device__ __forceinline__ void prefetch(const f4* __restrict__ src) {
 #pragma unroll
-    for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
-      int idx = i * WG_THREADS + tid;
-      if (idx < CF4) stage[i] = src[idx];
-    }
+    for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) stage[i] = src[elem<CF4>(i)];
+    // keep the loads HERE (ahead of the chunk's MFMAs): without the fence hipcc sinks them next to the ds_writes of
+    // commit(), exposing the full L2 latency once per chunk
+    __builtin_amdgcn_sched_barrier(0);
   }
   // Store the staged chunk into the other buffer, then make it the current one (one barrier per chunk).
   template <int CF4>
   __device__ __forceinline__ void commit() {
     if constexpr (CF4 > 0) {
 #pragma unroll
-      for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) {
-        int idx = i * WG_THREADS + tid;
-        if (idx < CF4) lds[(cur ^ 1) * BUF_F4 + idx] = stage[i];
-      }
+      for (int i = 0; i < (CF4 + WG_THREADS - 1) / WG_THREADS; ++i) lds[(cur ^ 1) * BUF_F4 + elem<CF4>(i)] = stage[i];
     }
     __syncthreads();
     cur ^= 1;
@@ -188,6 +197,108 @@ __device__ __forceinline__ void activate_softplus_jvp(const float (&z)[NT][N / 4
       float v = is_val ? act_fn<ACT_SOFTPLUS100>(zv) : z[t][i] * softplus100_grad(zv);
       h[t][i] = v * scale;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-precision ("f16x3") dense layer: fp32 operands are carried as hi + lo half pairs,
+//   x*w ~= xh*wh + xh*wl + xl*wh        (dropped xl*wl term ~ 2^-22 relative; products exact, fp32 accumulate)
+// on v_mfma_f32_16x16x32_f16 (16x the MAC rate of the f32-input MFMA -> ~5x net).  Same transposed chaining:
+// the 32 k-slots of one MFMA are (lane group g, slot j) <-> neuron 32*kb + (j<4 ? 4g+j : 16+4g+j-4), i.e. the
+// accumulator registers of output blocks 2kb and 2kb+1 of the previous layer, so activations again stay in
+// registers (as packed half pairs).  A and B use the same (g, j) -> k map, which is all the instruction requires.
+//   chunk jb = [16 bias floats, pre-scaled by 2^s] ++ [kb][hi|lo][lane][8 halves]  (same byte size as the fp32 chunk)
+// Weights are pre-scaled by 2^s (power of two: exact) so that their lo parts stay clear of the f16 subnormal
+// floor; the caller multiplies the result by 2^-s.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// Two fp32 values -> (packed hi halves, packed lo halves) with lo = v - float(hi).  One v_cvt_pkrtz per pair:
+// round-toward-zero only changes how the value is divided between hi and lo (|lo| <= 2^-10 |v|, stored to 2^-21 |v|).
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const h2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  const h2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Operands are kept as 32-bit registers (two halves each): x[t][kb][q], q = 0..3 <-> half slots 2q, 2q+1.
+// The layer writes raw fp32 accumulators (still scaled by 2^s) to out: they live in the accumulator half of the
+// register file while the packed operands live in the VGPR half; relu_split() turns them into the next operands.
+template <int K, int N, int NT, int NEXTK, class WS>
+__device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl, const f4* __restrict__ wnext,
+                                               const unsigned (&in_hi)[NT][K / 32][4],
+                                               const unsigned (&in_lo)[NT][K / 32][4], float (&out)[NT][N / 4],
+                                               int lane) {
+  constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb) {
+    if (jb + 1 < NJB) {
+      ws.template prefetch<CF4>(wl + (jb + 1) * CF4);
+    } else {
+      if constexpr (NCF4 > 0) ws.template prefetch<NCF4>(wnext);
+    }
+    const f4* cw = ws.chunk();
+    const u4* ch = reinterpret_cast<const u4*>(cw + 4);
+    f4 acc_m[NT], acc_c[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc_m[t] = cw[g];
+      acc_c[t] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // all weight operands of the chunk are fetched from LDS up front (2*KB ds_read_b128 in flight): a one-ahead
+    // fetch leaves the matrix pipe idle for an LDS round trip after every 6 MFMAs (measured: 2.2x slower)
+    u4 wreg[2 * KB];
+#pragma unroll
+    for (int i = 0; i < 2 * KB; ++i) wreg[i] = ch[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const h8 wh = __builtin_bit_cast(h8, wreg[kb * 2]);
+      const h8 wlo = __builtin_bit_cast(h8, wreg[kb * 2 + 1]);
+      h8 xh[NT], xl[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        xh[t] = __builtin_bit_cast(h8, u4{in_hi[t][kb][0], in_hi[t][kb][1], in_hi[t][kb][2], in_hi[t][kb][3]});
+        xl[t] = __builtin_bit_cast(h8, u4{in_lo[t][kb][0], in_lo[t][kb][1], in_lo[t][kb][2], in_lo[t][kb][3]});
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc_m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc_m[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc_c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[t], acc_c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc_c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[t], acc_c[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f4 a = acc_m[t] + acc_c[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][jb * 4 + r] = a[r];
+    }
+    if (jb + 1 < NJB) {
+      ws.template commit<CF4>();
+    } else {
+      ws.template commit<NCF4>();
+    }
+  }
+}
+
+// relu(z * unscale) of a whole layer (C layout, N neurons) -> packed hi/lo operands of the next layer:
+// output block jb = 2kb + e, reg r  ->  k-block kb, 32-bit register 2e + r/2.
+template <int N, int NT>
+__device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float unscale, unsigned (&hi)[NT][N / 32][4],
+                                           unsigned (&lo)[NT][N / 32][4]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int kb = 0; kb < N / 32; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
+        split_pair(fmaxf(z[t][i] * unscale, 0.f), fmaxf(z[t][i + 1] * unscale, 0.f), hi[t][kb][q], lo[t][kb][q]);
+      }
 }
 
 // Load the B-layout input registers of one 16-sample tile from a row-major feature matrix X[M][KP]

@@ -74,11 +74,12 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
 
 constexpr int DV_MAX_DIRS = 4096;
 
+template <bool H3>
 __global__ __launch_bounds__(256, 1) void k_dvis_fused(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
     const float* __restrict__ wsum, const f4* __restrict__ Whid, const float* __restrict__ wlast,
-    const float* __restrict__ blast, int L, int nsamp, int argmax_vis, float* __restrict__ vis_out,
+    const float* __restrict__ blast, int L, int nsamp, int argmax_vis, float w_unscale, float* __restrict__ vis_out,
     unsigned long long* __restrict__ eval_count) {
   __shared__ f4 lds_w[2 * chunk_f4(256)];
   __shared__ float vis_tab[DV_MAX_DIRS];
@@ -122,28 +123,62 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
   const int rounds = (S + 127) / 128;
   if (rounds > 0) ws.prime<chunk_f4(256)>(Whid);
   for (int rd = 0; rd < rounds; ++rd) {
-    float h[2][64], z[2][64];
+    float z[2][64];    // pre-activation of the last hidden layer (fp32 path: every layer)
     int jj[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int si = rd * 128 + wave * 32 + t * 16 + (lane & 15);
       jj[t] = si < S ? (int)idx_list[si] : -1;
-      const int j = jj[t] < 0 ? 0 : jj[t];
-      const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
-#pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
-        const f4 bv = brow[kb * 4];
-        const f4 av = a_row[kb * 4 + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[t][kb * 4 + r] = fmaxf(av[r] + bv[r], 0.f);
-      }
     }
+    if constexpr (!H3) {
+      float h[2][64];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = jj[t] < 0 ? 0 : jj[t];
+        const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+          const f4 bv = brow[kb * 4];
+          const f4 av = a_row[kb * 4 + g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[t][kb * 4 + r] = fmaxf(av[r] + bv[r], 0.f);
+        }
+      }
 #pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-      const f4* wl = Whid + l * LF;
-      const f4* wn = (l < 2) ? wl + LF : Whid;  // wrap: the next round starts again at hidden layer 0
-      dense_layer<256, 256, 2, 256>(ws, wl, wn, h, z, lane, true);
-      activate<256, 2, ACT_RELU>(z, h);
+      for (int l = 0; l < 3; ++l) {
+        const f4* wl = Whid + l * LF;
+        const f4* wn = (l < 2) ? wl + LF : Whid;  // wrap: the next round starts again at hidden layer 0
+        dense_layer<256, 256, 2, 256>(ws, wl, wn, h, z, lane, true);
+        if (l < 2) activate<256, 2, ACT_RELU>(z, h);
+      }
+    } else {
+      // split-precision hidden stack: activations travel as packed hi/lo halves, accumulators are fp32
+      unsigned xh[2][8][4], xl[2][8][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int j = jj[t] < 0 ? 0 : jj[t];
+        const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+          const f4 bv = brow[kb * 4];
+          const f4 av = a_row[kb * 4 + g];
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f),
+                       xh[t][kb / 2][(kb & 1) * 2 + q], xl[t][kb / 2][(kb & 1) * 2 + q]);
+        }
+      }
+#pragma unroll 1
+      for (int l = 0; l < 3; ++l) {
+        const f4* wl = Whid + l * LF;
+        const f4* wn = (l < 2) ? wl + LF : Whid;
+        if (l > 0) relu_split<256, 2>(z, w_unscale, xh, xl);
+        dense_layer_h3<256, 256, 2, 256>(ws, wl, wn, xh, xl, z, lane);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) z[t][i] = z[t][i] * w_unscale;
     }
     // 256 -> 2 head on the VALU: each lane owns 64 of the 256 activations of its sample
 #pragma unroll
@@ -155,8 +190,9 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
         const f4 wb = w_last[64 + kb * 4 + g];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          l0 += h[t][kb * 4 + r] * wa[r];
-          l1 += h[t][kb * 4 + r] * wb[r];
+          const float hv = fmaxf(z[t][kb * 4 + r], 0.f);
+          l0 += hv * wa[r];
+          l1 += hv * wb[r];
         }
       }
       l0 += __shfl_xor(l0, 16);
@@ -204,12 +240,20 @@ int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta
 
 int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                   const float* wdir, const float* wsum, const float* Whid, const float* wlast, const float* blast, int L,
-                  int nsamp, int argmax_vis, float* vis_out, unsigned long long* eval_count, rb_stream_t stream) {
+                  int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
+                  unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
+  RB_REQUIRE(precision == 0 || precision == 1, "precision: 0 = fp32 MFMA, 1 = f16x3 split");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
-  hipLaunchKernelGGL(k_dvis_fused, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd,
-                     dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, vis_out, eval_count);
+  if (precision == 0) {
+    hipLaunchKernelGGL(k_dvis_fused<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
+                       Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count);
+  } else {
+    hipLaunchKernelGGL(k_dvis_fused<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
+                       Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,
+                       ldexpf(1.0f, -scale_log2), vis_out, eval_count);
+  }
   return check_launch("k_dvis_fused");
 }
 

@@ -150,15 +150,20 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0):
     return dirs, wdir, wsum
 
 
-def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None):
+def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,
+               precision="fp32"):
+    """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain) or 'f16x3' (split-precision, ~2^-22 relative)."""
     normals = _f32(normals)
+    h3 = precision == "f16x3"
+    assert h3 or precision == "fp32", precision
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
         assert chunk_id.dtype == torch.int32
     call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
-         ptr(split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L), c_int(nsamp),
-         c_int(1 if argmax_vis else 0), ptr(out), ptr(eval_count), stream_ptr())
+         ptr(split["hidden_h3"] if h3 else split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L),
+         c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(1 if h3 else 0), c_int(split["h3_scale_log2"] if h3 else 0),
+         ptr(out), ptr(eval_count), stream_ptr())
     return out
 
 

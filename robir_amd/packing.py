@@ -50,6 +50,27 @@ def pack_layers(layers, device):
     return blob
 
 
+H3_SCALE_LOG2 = 8      # weights * 2^8 before the hi/lo half split (keeps lo parts out of the f16 subnormal range)
+
+
+def pack_layers_h3(layers, device, scale_log2=H3_SCALE_LOG2):
+    """Split-precision (f16x3) packing of 256-wide hidden layers: list of dict(W, b, n_pad, k_pad)."""
+    L = _lib.lib()
+    sizes = [int(L.rb_packed_layer_floats(l["n_pad"], l["k_pad"])) for l in layers]
+    blob = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    off, keep = 0, []
+    for l, sz in zip(layers, sizes):
+        W = l["W"].to(device=device, dtype=torch.float32).contiguous()
+        b = l["b"].to(device=device, dtype=torch.float32).contiguous() if l.get("b") is not None else None
+        keep += [W, b]
+        _lib.call("rb_pack_layer_h3", _lib.ptr(W), _lib.ptr(b), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
+                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), ctypes.c_int(scale_log2),
+                  ctypes.c_void_p(blob[off:off + sz].data_ptr()), _lib.stream_ptr())
+        off += sz
+    torch.cuda.current_stream().synchronize()
+    return blob
+
+
 def _t(sd, k):
     v = sd[k]
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
@@ -70,11 +91,13 @@ def pack_vis_split(sd, device):
     W0, b0 = _t(sd, VIS + "0.weight").float(), _t(sd, VIS + "0.bias").float()
     wp = pack_layers([dict(W=W0[:, :63].contiguous(), b=b0, n_pad=256, k_pad=64)], device)
     wd = pack_layers([dict(W=W0[:, 63:].contiguous(), b=None, n_pad=256, k_pad=64)], device)
-    hid = pack_layers([dict(W=_t(sd, VIS + "%d.weight" % (2 * i)), b=_t(sd, VIS + "%d.bias" % (2 * i)), n_pad=256,
-                            k_pad=256) for i in (1, 2, 3)], device)
+    hl = [dict(W=_t(sd, VIS + "%d.weight" % (2 * i)), b=_t(sd, VIS + "%d.bias" % (2 * i)), n_pad=256, k_pad=256)
+          for i in (1, 2, 3)]
+    hid = pack_layers(hl, device)
+    hid_h3 = pack_layers_h3(hl, device)
     w_last = _t(sd, VIS + "8.weight").to(device=device, dtype=torch.float32).contiguous()      # [2,256]
     b_last = _t(sd, VIS + "8.bias").to(device=device, dtype=torch.float32).contiguous()        # [2]
-    return dict(point=wp, dir=wd, hidden=hid, w_last=w_last, b_last=b_last)
+    return dict(point=wp, dir=wd, hidden=hid, hidden_h3=hid_h3, h3_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last)
 
 
 def pack_sdf(sd, device, full=True):

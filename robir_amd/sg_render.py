@@ -20,6 +20,10 @@ from . import ops
 from .nets import VisNetwork
 
 TINY_NUMBER = 1e-6
+# Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
+# chain); "f16x3" = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative error).
+import os as _os
+VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "fp32")
 
 
 # ----------------------------------------------------------------------------------------- small public helpers
@@ -101,7 +105,8 @@ def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis,
         cnt = None
         if stats is not None:
             cnt = stats.setdefault("diffuse_vis_evals", torch.zeros(1, dtype=torch.int64, device=dev))
-        return ops.dvis_fused(normals.float().contiguous(), cid, A, Bd, dirs, wdir, wsum, sp, L, nsamp, argmax_vis, cnt)
+        return ops.dvis_fused(normals.float().contiguous(), cid, A, Bd, dirs, wdir, wsum, sp, L, nsamp, argmax_vis, cnt,
+                              precision=VIS_PRECISION)
     return _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis)
 
 

@@ -23,8 +23,17 @@ def vis_net(dev, synth_weights):
     return v.to(dev).eval()
 
 
+@pytest.fixture(params=["fp32", "f16x3"])
+def precision(request):
+    from robir_amd import sg_render
+    old = sg_render.VIS_PRECISION
+    sg_render.VIS_PRECISION = request.param
+    yield request.param
+    sg_render.VIS_PRECISION = old
+
+
 @pytest.mark.parametrize("tag", ["init", "sharp"])
-def test_render_with_all_sg_golden(dev, vis_net, tag):
+def test_render_with_all_sg_golden(dev, vis_net, tag, precision):
     from robir_amd import sg_render
     g = load_golden("sg_" + tag)
     t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if v.dtype.kind == "f"}
@@ -40,7 +49,7 @@ def test_render_with_all_sg_golden(dev, vis_net, tag):
         assert rel_err(out[k].cpu(), g["out_" + k]) <= TOL, (k, rel_err(out[k].cpu(), g["out_" + k]))
 
 
-def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd):
+def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd, precision):
     """Fused kernel against the oracle on more points than one block row, two chunks with different draws."""
     from robir_amd import sg_render, synth
     from robir_oracle import nets as on, sg as osg
@@ -60,6 +69,7 @@ def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd):
     for c, sl in ((0, slice(0, 20)), (1, slice(20, 37))):
         ref = osg.diffuse_visibility(pts[sl], nrm[sl], vis_fn, lobe, lam, u[0, c], u[1, c]).t()
         assert rel_err(out[sl], ref) <= TOL, (c, rel_err(out[sl], ref))
+        print(f"[{precision}] chunk {c}: max rel err vs oracle {rel_err(out[sl], ref):.3e}")
 
 
 def test_generic_vismodel_callable(dev, vis_net):

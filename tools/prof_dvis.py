@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Stand-alone driver of the fused light-visibility kernel for rocprofv3 (kernel trace or --pmc passes):
+`python tools/prof_dvis.py [fp32|f16x3] [n_chunks]` renders n_chunks 1024-px chunks of the 800x800 synthetic view
+up to the visibility stage only."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from robir_amd import ops, renderer, sg_render, synth  # noqa: E402
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+n_chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+dev = torch.device("cuda:0")
+model = renderer.build_synthetic_model(dev)
+uv, pose, K = synth.synth_camera(800, 800)
+first = 300 * 800 // 1024
+sl = slice(first * 1024, (first + n_chunks) * 1024)
+uv_d = torch.from_numpy(uv[sl]).to(dev)
+dirs = ops.camera_rays(pose, K, uv_d)
+cam = torch.from_numpy(pose[:3, 3]).to(dev).reshape(1, 3)
+_, hit, dist = model.ray_tracer.sdf_octree.cast_chunks(cam, dirs, chunk=1024)
+pts = ops.points_along(cam.expand(dirs.shape[0], 3).contiguous(), dirs, dist)
+idx = hit.nonzero()[:, 0]
+hp = pts[idx].contiguous()
+cid = (idx // 1024).to(torch.int32).contiguous()
+nrm = ops.normalize3(model.implicit_network.gradient(hp)[:, 0, :].contiguous(), 1e-4, 1)
+lgt = model.envmap_material_network.lgtSGs.detach()
+g = torch.Generator(device=dev).manual_seed(1)
+u = torch.rand(2, n_chunks, 128, 32, device=dev, generator=g)
+sg_render.VIS_PRECISION = prec
+stats = {}
+for it in range(3):
+    out = sg_render._diffuse_vis_core(hp, nrm, model.visibility_network, lgt, u[0], u[1], 1.0, False, cid, n_chunks, stats)
+torch.cuda.synchronize()
+ev = int(stats["diffuse_vis_evals"]) // 3
+print(f"{prec}: {hp.shape[0]} points, {ev} evals per launch, out mean {float(out.mean()):.6f}")
