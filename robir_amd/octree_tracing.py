@@ -84,8 +84,9 @@ class OctreeSDF:
         return cls(tables, max_iter)
 
     @classmethod
-    def from_oracle_tables(cls, T, device, max_iter=-1):
-        """Upload tables built by oracle/robir_oracle/octree.py (tests: isolates cast parity from build parity)."""
+    def from_host_tables(cls, T, device, max_iter=-1):
+        """Upload octree tables held on the host: any object with box_min/box_size [B,3], child [B,8], is_split [B],
+        sdf_val [B], sdf_nrm [B,3], root_min/root_size [3], base_index [nx,ny,nz], min_step (e.g. a tree built elsewhere)."""
         B = T.box_min.shape[0]
         node = torch.zeros(B, 8, dtype=torch.float32)
         node[:, 0:3] = T.box_min

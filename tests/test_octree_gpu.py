@@ -30,7 +30,7 @@ def dev_octree(neus):
 
 def _oracle_dev(oracle_octree, dev, max_iter=-1):
     from robir_amd.octree_tracing import OctreeSDF
-    return OctreeSDF.from_oracle_tables(oracle_octree, dev, max_iter)
+    return OctreeSDF.from_host_tables(oracle_octree, dev, max_iter)
 
 
 def test_build_matches_oracle(dev_octree, oracle_octree):
