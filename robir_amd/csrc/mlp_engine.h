@@ -301,6 +301,138 @@ __device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float un
       }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined weight ring for the split-precision hidden stack (fused light-visibility kernel).
+// A chunk = 16 output neurons x K=256 (bias + hi/lo half fragments, chunk_f4(256) float4s).  The chunk stream of the
+// whole hidden stack (NCHUNK chunks, cyclic) runs through a 3-slot LDS ring:
+//   chunk c's MFMAs (first half)   | ds_write chunk c+1 (global data fetched during chunk c-1) -> slot (c+1)%3
+//                                  | issue global loads of chunk c+2
+//   MFMAs (third quarter)          | lgkmcnt(0) + s_barrier  (chunk c+1 now visible; its slot was last read for
+//                                  |                          chunk c-2, which every wave left before barrier c-1)
+//   ds_read first half of c+1      | MFMAs (last quarter)    | ds_read second half of c+1
+// so neither the L2 latency of the weight stream, nor the LDS write/read round trip, nor the barrier sit between the
+// last MFMA of one chunk and the first MFMA of the next (PMC before: matrix pipe 37 % busy, 37 % parked in waits).
+// ---------------------------------------------------------------------------------------------------------
+template <int NT, int NCHUNK>
+struct H3Ring {
+  static constexpr int K = 256, KB = K / 32, CF4 = chunk_f4(K);
+  static constexpr int NST = (CF4 + WG_THREADS - 1) / WG_THREADS;
+  f4* lds;               // 3 * CF4 float4s
+  const f4* W;           // NCHUNK chunks, contiguous
+  int tid, lane, g;
+  int c;                 // chunk whose weights sit in wreg (0..NCHUNK-1)
+  int slot;              // LDS slot of chunk c
+  u4 wreg[2 * KB];
+  f4 bias;
+  f4 stage[NST];
+
+  __device__ __forceinline__ int elem(int i) const {
+    const int idx = i * WG_THREADS + tid;
+    return ((i + 1) * WG_THREADS <= CF4) ? idx : (idx < CF4 ? idx : CF4 - 1);
+  }
+  __device__ __forceinline__ void load_stage(int chunk) {
+    const f4* src = W + (long)chunk * CF4;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) stage[i] = src[elem(i)];
+  }
+  __device__ __forceinline__ void store_stage(int s) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) lds[s * CF4 + elem(i)] = stage[i];
+  }
+  __device__ __forceinline__ void read_w(int s, int first, int count) {
+    const u4* ch = reinterpret_cast<const u4*>(lds + s * CF4 + 4);
+#pragma unroll
+    for (int i = 0; i < 2 * KB; ++i)
+      if (i >= first && i < first + count) wreg[i] = ch[i * 64 + lane];
+  }
+  // chunk 0 -> slot 0 (synchronously), chunk 1 -> stage registers, weights of chunk 0 -> wreg
+  __device__ __forceinline__ void start(f4* lds_base, const f4* weights, int tid_) {
+    lds = lds_base;
+    W = weights;
+    tid = tid_;
+    lane = tid_ & 63;
+    g = lane >> 4;
+    c = 0;
+    slot = 0;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    load_stage(1 % NCHUNK);
+    bias = lds[g];
+    read_w(0, 0, 2 * KB);
+  }
+  // One chunk: res[t] (f4, C layout of 16 output neurons) = bias + W_chunk . x
+  // CH = number of accumulator chains per tile: 1 (everything into the result register), 2 (hi*hi | corrections),
+  // 3 (hi*hi | hi*lo | lo*hi).  Chosen by measurement (tools/prof_dvis.py --variants).
+  template <int CH>
+  __device__ __forceinline__ void chunk(const unsigned (&xh)[NT][KB][4], const unsigned (&xl)[NT][KB][4], f4 (&res)[NT]) {
+    f4 acc[NT][CH];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = bias;
+#pragma unroll
+      for (int i = 1; i < CH; ++i) acc[t][i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto mfma_kb = [&](int kb) {
+      const h8 wh = __builtin_bit_cast(h8, wreg[kb * 2]);
+      const h8 wlo = __builtin_bit_cast(h8, wreg[kb * 2 + 1]);
+      h8 a[NT], b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
+        b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
+      }
+      constexpr int IA = CH >= 2 ? 1 : 0, IB = CH >= 3 ? 2 : IA;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t][0], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][IA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][IA], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][IB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t][IB], 0, 0, 0);
+    };
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    const int c2 = (c + 2) % NCHUNK;
+    // ---- phase 1: first half of the MFMAs
+#pragma unroll
+    for (int kb = 0; kb < KB / 2; ++kb) mfma_kb(kb);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: stage chunk c+1 into its ring slot, start fetching chunk c+2
+    store_stage(nslot);
+    load_stage(c2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 3: third quarter
+#pragma unroll
+    for (int kb = KB / 2; kb < 3 * KB / 4; ++kb) mfma_kb(kb);
+    __builtin_amdgcn_sched_barrier(0);
+    // raw barrier: only the LDS writes must have landed; the global loads of chunk c+2 stay in flight across it
+    // (__syncthreads() would add s_waitcnt vmcnt(0) and expose the L2 latency every chunk)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 4: first half of chunk c+1's weights (their registers are free), bias of c+1
+    const f4 nbias = lds[nslot * CF4 + g];
+    read_w(nslot, 0, KB);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 5: last quarter
+#pragma unroll
+    for (int kb = 3 * KB / 4; kb < KB; ++kb) mfma_kb(kb);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 6: second half of chunk c+1's weights; result
+    read_w(nslot, KB, KB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f4 r = acc[t][0];
+      if constexpr (CH == 2) r = r + acc[t][1];
+      if constexpr (CH == 3) r = r + (acc[t][1] + acc[t][2]);
+      res[t] = r;
+    }
+    bias = nbias;
+    slot = nslot;
+    c = (c + 1 == NCHUNK) ? 0 : c + 1;
+  }
+};
+
 // Load the B-layout input registers of one 16-sample tile from a row-major feature matrix X[M][KP]
 // (KP = padded feature count, multiple of 16).  Rows >= M read as zeros.
 template <int KP>

@@ -74,14 +74,14 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
 
 constexpr int DV_MAX_DIRS = 4096;
 
-template <bool H3>
+template <bool H3, int CH>
 __global__ __launch_bounds__(256, 1) void k_dvis_fused(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
     const float* __restrict__ wsum, const f4* __restrict__ Whid, const float* __restrict__ wlast,
     const float* __restrict__ blast, int L, int nsamp, int argmax_vis, float w_unscale, float* __restrict__ vis_out,
     unsigned long long* __restrict__ eval_count) {
-  __shared__ f4 lds_w[2 * chunk_f4(256)];
+  __shared__ f4 lds_w[(H3 ? 3 : 2) * chunk_f4(256)];
   __shared__ float vis_tab[DV_MAX_DIRS];
   __shared__ unsigned short idx_list[DV_MAX_DIRS];
   __shared__ f4 a_row[64];
@@ -117,11 +117,16 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
   if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
 
   WStream<256> ws;
-  ws.init(lds_w, tid);
+  H3Ring<2, 48> ring;
   constexpr long LF = (long)16 * chunk_f4(256);
   const float b0 = blast[0], b1 = blast[1];
   const int rounds = (S + 127) / 128;
-  if (rounds > 0) ws.prime<chunk_f4(256)>(Whid);
+  if constexpr (H3) {
+    if (rounds > 0) ring.start(lds_w, Whid, tid);
+  } else {
+    ws.init(lds_w, tid);
+    if (rounds > 0) ws.prime<chunk_f4(256)>(Whid);
+  }
   for (int rd = 0; rd < rounds; ++rd) {
     float z[2][64];    // pre-activation of the last hidden layer (fp32 path: every layer)
     int jj[2];
@@ -170,10 +175,16 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
       }
 #pragma unroll 1
       for (int l = 0; l < 3; ++l) {
-        const f4* wl = Whid + l * LF;
-        const f4* wn = (l < 2) ? wl + LF : Whid;
         if (l > 0) relu_split<256, 2>(z, w_unscale, xh, xl);
-        dense_layer_h3<256, 256, 2, 256>(ws, wl, wn, xh, xl, z, lane);
+#pragma unroll
+        for (int jb = 0; jb < 16; ++jb) {
+          f4 res[2];
+          ring.template chunk<CH>(xh, xl, res);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[t][jb * 4 + r] = res[t][r];
+        }
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -243,16 +254,25 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                   int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
                   unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(precision == 0 || precision == 1, "precision: 0 = fp32 MFMA, 1 = f16x3 split");
+  RB_REQUIRE(precision >= 0 && precision <= 3, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
-    hipLaunchKernelGGL(k_dvis_fused<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
+    hipLaunchKernelGGL((k_dvis_fused<false, 1>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
                        Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count);
   } else {
-    hipLaunchKernelGGL(k_dvis_fused<true>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
-                       Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,
-                       ldexpf(1.0f, -scale_log2), vis_out, eval_count);
+#define RB_LAUNCH_H3(CH)                                                                                              \
+  hipLaunchKernelGGL((k_dvis_fused<true, CH>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
+                     n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
+                     ldexpf(1.0f, -scale_log2), vis_out, eval_count)
+    if (precision == 1) {
+      RB_LAUNCH_H3(2);
+    } else if (precision == 2) {
+      RB_LAUNCH_H3(1);
+    } else {
+      RB_LAUNCH_H3(3);
+    }
+#undef RB_LAUNCH_H3
   }
   return check_launch("k_dvis_fused");
 }

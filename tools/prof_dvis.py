@@ -31,6 +31,27 @@ nrm = ops.normalize3(model.implicit_network.gradient(hp)[:, 0, :].contiguous(), 
 lgt = model.envmap_material_network.lgtSGs.detach()
 g = torch.Generator(device=dev).manual_seed(1)
 u = torch.rand(2, n_chunks, 128, 32, device=dev, generator=g)
+if prec == "variants":
+    import itertools
+    names = ["f16x3", "f16x3-1chain", "f16x3-3chain", "fp32"]
+    times = {k: [] for k in names}
+    for rep in range(4):
+        for k in names:
+            sg_render.VIS_PRECISION = k
+            sp = model.visibility_network.packed_split()
+            A = ops.linear_64_256(ops.feat_pe10(hp), sp["point"])
+            d_, w_, ws_ = ops.dvis_dirs(lgt, u[0], u[1], 1.0)
+            Bd = ops.linear_64_256(ops.feat_pe10(d_), sp["dir"])
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            o = ops.dvis_fused(nrm, cid, A, Bd, d_, w_, ws_, sp, 128, 32, False, None, precision=k)
+            e.record()
+            torch.cuda.synchronize()
+            times[k].append(s.elapsed_time(e))
+    for k in names:
+        print(k, " ".join(f"{t:.2f}" for t in times[k]), "ms  (min %.2f)" % min(times[k]))
+    sys.exit(0)
 sg_render.VIS_PRECISION = prec
 stats = {}
 for it in range(3):
