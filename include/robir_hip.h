@@ -209,6 +209,36 @@ int rb_neus_composite(const float* sdf, const float* color, const float* mask, l
 int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char* back, long n, int nsamp, float* out,
                        rb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * NeuS ray-march with hierarchical sampling -- the non-MLP steps of render_neus (model/sdf_render.py:263-374):
+ * rb_neus_coarse_z  z[R,n] = near + (far-near)*lin[n]                                   (:279-283)
+ * rb_ray_points     pts[R*n,3] = o + d*z (dirs[R*n,3] = d per sample, may be NULL)      (:313, :192-196)
+ * rb_neus_upsample  up_sample + sample_pdf(det=True): z_new[R,n_new]; u[n_new] = the deterministic quantiles;
+ *                   wtmp[R,n] scratch                                                   (:70-114, :37-67)
+ * rb_neus_merge     cat_z_vals: merge ascending z lists, sdf follows (sdf_new NULL on the last step, sdf_out may be NULL) (:117-132)
+ * rb_neus_mid_z     zmid = z + dz/2, last dz = sample_dist                              (:186-189)
+ * rb_neus_finish    render_core compositing + render_neus epilogue: alpha from consecutive mid-point SDFs
+ *                   (sdf = column 0 of an [R*n, sdf_stride] matrix), inside-sphere mask, weights, white background,
+ *                   normal (set to 1 where acc > 0.8, sic), dist clipped to [near,far];
+ *                   gerr[2] += (sum relax*(|grad|-1)^2, sum relax)                      (:203-260, :354-374)
+ * rb_surface_points / rb_surface_finish: NormalTrainRunner.get_neus_surface (training/train_normal.py:239-286).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_neus_coarse_z(const float* near, const float* far, const float* lin, long R, int n, float* z, rb_stream_t stream);
+int rb_ray_points(const float* o, const float* d, const float* z, long R, int n, float* pts, float* dirs,
+                  rb_stream_t stream);
+int rb_neus_upsample(const float* o, const float* d, const float* z, const float* sdf, long R, int n, int n_new,
+                     float inv_s, float radius, const float* u, float* wtmp, float* z_new, rb_stream_t stream);
+int rb_neus_merge(const float* z_old, const float* sdf_old, int n, const float* z_new, const float* sdf_new, int m,
+                  long R, float* z_out, float* sdf_out, rb_stream_t stream);
+int rb_neus_mid_z(const float* z, long R, int n, float sample_dist, float* zmid, rb_stream_t stream);
+int rb_neus_finish(const float* sdf, long sdf_stride, const float* color, const float* grad, const float* pts,
+                   const float* zmid, const float* near, const float* far, long R, int n, float inv_s, float radius,
+                   int white, float* rgb, float* dist, float* acc, float* normal, float* weights, float* gerr,
+                   rb_stream_t stream);
+int rb_surface_points(const float* p, const float* dir, const float* tk, long m, int ns, float* xs, rb_stream_t stream);
+int rb_surface_finish(const float* sdf, const float* grad, const float* xs, const float* p, const float* pred_n, long m,
+                      int ns, float s, float* x_out, float* n_out, float* gerr, rb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""Drop-in for the reference's model/sdf_render.py (NeuS ray-march with hierarchical sampling, :263-374) and for
+NormalTrainRunner.get_neus_surface (training/train_normal.py:239-286) on the HIP kernels.
+
+render_neus(rays, model, cos_anneal_ratio, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, ...)
+supports the configuration every shipped config uses: n_outside = 0, is_eval / perturb = 0, lindisp = False.
+`model` is robir_amd.nets.NeuSModel (sdf / sdf+feat+gradient / colour run on the MFMA kernels)."""
+import collections
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import call, ptr, stream_ptr
+
+c_long, c_int, c_float = ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+Rays = collections.namedtuple("Rays", ("origins", "directions", "viewdirs", "radii", "lossmult", "near", "far"))
+
+
+def _f(t):
+    return t.float().contiguous()
+
+
+def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
+                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False):
+    if n_outside != 0 or lindisp or not (is_eval or perturb == 0):
+        raise NotImplementedError("HIP render_neus: n_outside=0, lindisp=False, is_eval=True (deterministic sampling)")
+    o, d = _f(rays.origins), _f(rays.directions)
+    near, far = _f(rays.near).reshape(-1), _f(rays.far).reshape(-1)
+    R, dev = o.shape[0], o.device
+    net = model.sdf_network
+    sample_dist = 2.0 / n_samples
+    radius = float(model.radius())
+    S = stream_ptr
+
+    lin = torch.linspace(0.0, 1.0, n_samples).to(dev)
+    z = torch.empty(R, n_samples, device=dev)
+    call("rb_neus_coarse_z", ptr(near), ptr(far), ptr(lin), c_long(R), c_int(n_samples), ptr(z), S())
+
+    def points(zz, want_dirs=False):
+        n = zz.shape[1]
+        pts = torch.empty(R * n, 3, device=dev)
+        dd = torch.empty(R * n, 3, device=dev) if want_dirs else None
+        call("rb_ray_points", ptr(o), ptr(d), ptr(zz), c_long(R), c_int(n), ptr(pts), ptr(dd), S())
+        return pts, dd
+
+    if n_importance > 0:
+        per = n_importance // up_sample_steps
+        u = torch.linspace(0.0 + 0.5 / per, 1.0 - 0.5 / per, steps=per).to(dev)
+        sdf = net.eval_points(points(z)[0], full=False)[0].reshape(R, n_samples)
+        for i in range(up_sample_steps):
+            n = z.shape[1]
+            wtmp = torch.empty(R, n, device=dev)
+            zn = torch.empty(R, per, device=dev)
+            call("rb_neus_upsample", ptr(o), ptr(d), ptr(z), ptr(sdf), c_long(R), c_int(n), c_int(per),
+                 c_float(64 * 2 ** i), c_float(radius), ptr(u), ptr(wtmp), ptr(zn), S())
+            last = i + 1 == up_sample_steps
+            sn = None if last else net.eval_points(points(zn)[0], full=False)[0].reshape(R, per).contiguous()
+            z2 = torch.empty(R, n + per, device=dev)
+            s2 = None if last else torch.empty(R, n + per, device=dev)
+            call("rb_neus_merge", ptr(z), ptr(sdf), c_int(n), ptr(zn), ptr(sn), c_int(per), c_long(R), ptr(z2), ptr(s2), S())
+            z = z2
+            sdf = s2 if not last else sdf
+    n = z.shape[1]
+    zmid = torch.empty(R, n, device=dev)
+    call("rb_neus_mid_z", ptr(z), c_long(R), c_int(n), c_float(sample_dist), ptr(zmid), S())
+    pts, dirs = points(zmid, want_dirs=True)
+    out, grad = net.eval_points(pts, full=True, grad=True)               # [M,257], [M,3]
+    col = model.color_network(pts, grad, dirs, out[:, 1:])
+    rgb, dist, acc = torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+    nrm, w = torch.empty(R, 3, device=dev), torch.empty(R, n, device=dev)
+    gerr = torch.zeros(2, device=dev)
+    call("rb_neus_finish", ptr(out), c_long(257), ptr(col), ptr(grad), ptr(pts), ptr(zmid), ptr(near), ptr(far), c_long(R),
+         c_int(n), c_float(model.inv_s()), c_float(radius), c_int(1 if white_bkgd else 0), ptr(rgb), ptr(dist), ptr(acc),
+         ptr(nrm), ptr(w), ptr(gerr), S())
+    return {"rgb": rgb, "dist": dist, "acc": acc, "grad_error": gerr[0] / (gerr[1] + 1e-5), "grad": nrm, "weights": w}
+
+
+def get_neus_surface(implicit_network, points, view_dirs, pred_normals, n_samp=32, dist=0.05):
+    """NormalTrainRunner.get_neus_surface: -> (final_x [m,3], final_normal [m,3], gradient_error)."""
+    p, v, pn = _f(points), _f(view_dirs), _f(pred_normals)
+    m, dev = p.shape[0], p.device
+    tk = torch.linspace(0, dist, n_samp).to(dev)
+    xs = torch.empty(m * n_samp, 3, device=dev)
+    call("rb_surface_points", ptr(p), ptr(v), ptr(tk), c_long(m), c_int(n_samp), ptr(xs), stream_ptr())
+    sdf, grad = implicit_network.neus_model.sdf_network.eval_points(xs, 2.0, 0.5, full=False, grad=True)
+    s = float(torch.exp(implicit_network.neus_model.deviation_network.variance.detach() * 10.0))   # unclipped here
+    x_out, n_out = torch.empty(m, 3, device=dev), torch.empty(m, 3, device=dev)
+    gerr = torch.zeros(2, device=dev)
+    call("rb_surface_finish", ptr(sdf), ptr(grad), ptr(xs), ptr(p), ptr(pn), c_long(m), c_int(n_samp), c_float(s),
+         ptr(x_out), ptr(n_out), ptr(gerr), stream_ptr())
+    return x_out, n_out, gerr[0] / (gerr[1] + 1e-5)
