@@ -81,6 +81,12 @@ int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_
 int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream);
 /* raw[M,24,6] -> lgt_sgs[M,24,7] (implicit_differentiable_renderer.py:208-218). */
 int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
+/* CESR-stage nets (training/train_cesr.py:106-110; SDFNetwork with multires 0, model/neus_model.py:312-417):
+ * kind 0: normal_net X[M,64] (PE10 | 0) -> Y[M,3];   kind 1: shadow_net X[M,192] ([PE10 | one-hot 128 | 0]) -> Y[M,2];
+ * kind 2: shadow_net on (point, label) pairs: X = Xp[M/n_label,64] point features, row = point*n_label + label,
+ *         the one-hot block is synthesised in registers -> Y[M,2].
+ * Wp packed [K0P->512, 512->512 x2, 512->N3P, 528->512 (cols [lin3 | input]), 512->512 x3, 512->16]. */
+int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
 /* SparseAE (model/sg_envmap_material.py:40-99): encoder X[M,64] -> raw latent[M,32]
  * (packed [64->512, 512->512 x3, 512->32]); latent = act(raw*(1-var)) [+ lat2 = latent + noise*noise_scale];
  * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus. */
@@ -130,6 +136,8 @@ int rb_sg_shade(const float* normal, const float* view, const float* lgt, int pe
                 const float* rough, const float* albedo, const float* metallic, const float* light_vis,
                 const float* bvis, const float* indir_integral, int lin_diff, long n, float* out_rgb, float* out_spec,
                 float* out_diff, float* out_shadow, rb_stream_t stream);
+/* render_envmap_sg (model/sg_render.py:26-42): rgb[n,3] = sum_k |mu_k| exp(|lambda_k| (d . lobe_k/|lobe_k| - 1)), lgt[M,7] */
+int rb_envmap_sg(const float* lgt, int M, const float* dirs, long n, float* rgb, rb_stream_t stream);
 /* y = x/(|x|+eps) (mode 0) or x/max(|x|,eps) (mode 1) on rows of 3 */
 int rb_normalize3(const float* x, long n, float eps, int mode, float* y, rb_stream_t stream);
 

@@ -336,6 +336,52 @@ def main():
              hdr_shift=hdr_in, **{"draw_" + k: v for k, v in dr.items()},
              **{"out_" + k: ref[k].detach() for k in ref if isinstance(ref[k], torch.Tensor)})
 
+        # ------------------------------------------------------------------ CESR hook (shadow_net / normal_net), chunk 1
+        from training.train_cesr import ClusteredAlbedoTrainRunner
+        from model.neus_model import SDFNetwork as RefSDFNetwork
+        cesr_np = synth.synth_cesr_nets(seed)
+        shadow_net = RefSDFNetwork(63 + 128, 2, 512, 8, [4], 0)
+        normal_net = RefSDFNetwork(63, 3, 512, 8, [4], 0)
+        shadow_net.load_state_dict({k: torch.from_numpy(v) for k, v in cesr_np["shadow_net"].items()})
+        normal_net.load_state_dict({k: torch.from_numpy(v) for k, v in cesr_np["normal_net"].items()})
+        cesr_conf = types.SimpleNamespace(get_bool=lambda k: False)
+        runner = types.SimpleNamespace(model=net, train_spec=True, is_training=False, cur_iter=100000, conf=cesr_conf,
+                                       shadow_embed=get_embedder(10)[0], shadow_net=shadow_net, normal_net=normal_net,
+                                       prefit_option=lambda: "explore", white_light=False)
+        net.get_sg_render = types.MethodType(ClusteredAlbedoTrainRunner.get_sg_render, runner)
+        c = 1
+        sl = slice(c * 1024, (c + 1) * 1024)
+        n_hit = int(prim[c][1].sum())
+        dr = synth.pbr_draws(seed + 5, n_hit, chunk_id=c, nsamp_diffuse=8)
+        q = [("randn", dr["illum_randn"]), ("randn", dr["spec_randn"]), ("randn", dr["normal_randn"]),
+             ("rand", dr["dvis_theta"]), ("rand", dr["dvis_phi"]), ("rand", dr["svis_theta_dir"]),
+             ("rand", dr["svis_phi_dir"]), ("rand", dr["svis_theta_ind"]), ("rand", dr["svis_phi_ind"])]
+        inp = {"uv": uv_t[:, sl], "pose": pose_t, "intrinsics": K_t, "object_mask": obj_mask[:, sl],
+               "hdr_shift": hdr_in.expand(1024, 1)}
+        t0 = time.time()
+        with DrawQueue(q):
+            ref = net(inp, trainstage="Material", fun_spec=False, lin_diff=True, train_spec=True)
+        t_ref = time.time() - t0
+        drt = {k: torch.from_numpy(v) for k, v in dr.items()}
+        cesr_t = ({k: torch.from_numpy(v) for k, v in cesr_np["shadow_net"].items()},
+                  {k: torch.from_numpy(v) for k, v in cesr_np["normal_net"].items()})
+        mine = orend.forward(sd, Tref, uv_t[:, sl], pose_t, K_t, obj_mask[:, sl], hdr_in.expand(1024, 1), drt,
+                             "Material", testing=True, cesr=cesr_t)
+        ck = ["sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "vis_shadow", "normal_map", "diffuse_albedo",
+              "roughness", "gradient_error"]
+        report("forward_cesr_c1", n_hit=n_hit, ref_s=t_ref, **{k: relerr(mine[k], ref[k].detach()) for k in ck})
+        save("forward_cesr_c1", weights=wsum, H=H, W=W, chunk=c, n_hit=n_hit, hdr_shift=hdr_in,
+             **{"draw_" + k: v for k, v in dr.items()},
+             **{"out_" + k: ref[k].detach() for k in ref if isinstance(ref[k], torch.Tensor)})
+        # the two nets alone
+        xs_n = torch.from_numpy(g.standard_normal((64, 63)).astype(np.float32))
+        xs_s = torch.cat([xs_n, torch.eye(128)[torch.arange(64) % 128]], -1)
+        ref_n, ref_s = normal_net(xs_n).detach(), shadow_net(xs_s).detach()
+        report("cesr_nets", normal=relerr(on.softplus_net512(cesr_t[1], xs_n), ref_n),
+               shadow=relerr(on.softplus_net512(cesr_t[0], xs_s), ref_s))
+        save("cesr_nets", x_normal=xs_n, x_shadow=xs_s, y_normal=ref_n, y_shadow=ref_s)
+        install_pbr_hook(net)
+
         # ------------------------------------------------------------------ forward('Illum') + trace_radiance(nsamp=8)
         c = 1
         sl = slice(c * 1024, (c + 1) * 1024)

@@ -172,3 +172,17 @@ def normal_map_only(sd, pts, normal_noise):
                          torch.sigmoid, None)
     unit = lambda v: v / torch.clamp(v.norm(dim=-1, keepdim=True), 1e-4)
     return unit(nm), unit(nm_r)
+
+
+# ------------------------------------------------------------------ CESR-stage nets
+def softplus_net512(sd, x):
+    """SDFNetwork(d_in, d_out, 512, 8, skip [4], multires=0) (neus_model.py:312-417 without positional encoding),
+    as the CESR runner builds shadow_net / normal_net (training/train_cesr.py:106-110).  sd: keys lin{l}.weight_v/_g/bias."""
+    h = x
+    for l in range(9):
+        if l == 4:
+            h = torch.cat([h, x], 1) / math.sqrt(2.0)
+        h = F.linear(h, wn_weight(sd, "lin%d." % l), sd["lin%d.bias" % l])
+        if l < 8:
+            h = F.softplus(h, beta=100)
+    return h

@@ -83,9 +83,39 @@ def pbr_sg_render(sd, points, view_dirs, indir_sgs, indir_integral, draws, testi
     return out
 
 
+def cesr_sg_render(sd, shadow_sd, normal_sd, points, view_dirs, indir_sgs, indir_integral, draws, testing=True,
+                   cur_iter=100000, prefit="explore", argmax_vis=False, stats=None):
+    """ClusteredAlbedoTrainRunner.get_sg_render (train_cesr.py:465-544).  draws['dvis_*'] are [128, 8] here."""
+    from .encoding import pe
+    vd = view_dirs / (view_dirs.norm(dim=-1, keepdim=True) + 1e-6)
+    nrm = nets.implicit_gradient(sd, points)
+    nrm = nrm / torch.clamp(nrm.norm(dim=-1, keepdim=True), 1e-4)
+    mat = nets.materials(sd, points, draws["spec_randn"], draws["normal_randn"])
+    emb = pe(points, 10)
+    n = points.shape[0]
+    x = torch.cat([emb[:, None, :].expand(-1, 128, -1), torch.eye(128)[None].expand(n, -1, -1)], -1)
+    dvis = torch.softmax(nets.softplus_net512(shadow_sd, x.reshape(-1, 191)), -1)[..., 1]
+    nnew = nets.softplus_net512(normal_sd, emb)
+    nnew = nnew / torch.clamp(nnew.norm(dim=-1, keepdim=True), 1e-4)
+    alb = mat["sg_diffuse_albedo"]
+    out = sg.render_with_all_sg(points, nnew if cur_iter > 1000 else mat["sg_normal_map"], vd, mat["sg_lgtSGs"],
+                                mat["sg_specular_reflectance"].abs(), mat["sg_roughness"], alb, draws,
+                                indir_integral=indir_integral * 2 * math.pi, indir_lgt_sgs=indir_sgs,
+                                vis_fn=lambda p, d: nets.vis_logits(sd, p, d), lin_diff=True, testing=testing,
+                                metallic=None, argmax_vis=argmax_vis, stats=stats, diffuse_vis=dvis, prefit=prefit)
+    out["sg_rgb"] = out["sg_diffuse_rgb"] * alb / math.pi + out["sg_specular_rgb"]
+    out["indir_rgb"] = out["indir_diffuse_rgb"] * alb / math.pi + out["indir_specular_rgb"]
+    sup = out["supervise"] + ((mat["sg_normal_map"] - nnew) ** 2).mean()
+    out.update({"normals": nrm, "diffuse_albedo": alb, "roughness": mat["sg_roughness"], "metallic": mat["sg_metallic"],
+                "normal_map": nnew, "gradient_error": sup, "random_xi_roughness": mat["random_xi_roughness"],
+                "random_xi_metallic": mat["random_xi_metallic"],
+                "random_xi_diffuse_albedo": mat["random_xi_diffuse_albedo"]})
+    return out
+
+
 # ----------------------------------------------------------------------------- forward
 def forward(sd, tables, uv, pose, K, object_mask, hdr_shift, draws, trainstage="Material", testing=True,
-            trace_log=None, stats=None):
+            trace_log=None, stats=None, cesr=None):
     """IDRNetwork.forward, uv/pose/intrinsics input form (implicit_differentiable_renderer.py:290-479)
     for one chunk of N pixels (B = 1).  tables: primary octree.  draws: see robir_amd.synth.pbr_draws
     (row counts = number of hit rays of this chunk)."""
@@ -117,8 +147,13 @@ def forward(sd, tables, uv, pose, K, object_mask, hdr_shift, draws, trainstage="
     out.update({"metallic": one1(), "random_xi_metallic": one1(), "acc": one1(), "final_t": one1(),
                 "gradient_error": torch.tensor(0.0)})
     if n > 0:
-        r = pbr_sg_render(sd, points[hit], -dirs[hit], indir_sgs[hit], indir_int[hit], draws, testing=testing,
-                          stats=stats)
+        if cesr is None:
+            r = pbr_sg_render(sd, points[hit], -dirs[hit], indir_sgs[hit], indir_int[hit], draws, testing=testing,
+                              stats=stats)
+        else:       # cesr = (shadow_sd, normal_sd): the CESR runner's hook instead of the PBR one
+            r = cesr_sg_render(sd, cesr[0], cesr[1], points[hit], -dirs[hit], indir_sgs[hit], indir_int[hit], draws,
+                               testing=testing, stats=stats)
+            out["gradient_error"] = out["gradient_error"] + r["gradient_error"]
         for k in names3[:-1]:
             v = r[k]
             out[k][hit] = v.expand(-1, 3) if v.shape[-1] == 1 else v

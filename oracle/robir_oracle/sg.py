@@ -119,13 +119,21 @@ def specular_visibility(points, normals, viewdirs, vis_fn, lobes, lambdas, u_the
     return (vis * w).sum(-1) / (w.sum(-1) + TINY)
 
 
+def kl_divergence(x, mu=0.05):
+    """utils/utils.py:14-17."""
+    rho_hat = torch.mean(x, 0)
+    rho = torch.full_like(rho_hat, mu)
+    return torch.mean(rho * torch.log(rho / (rho_hat + 1e-4)) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat + 1e-4)))
+
+
 def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws,
                    comp_vis=True, vis_fn=None, lin_diff=False, testing=False, indir_integral=None, metallic=None,
-                   argmax_vis=False, stats=None):
+                   argmax_vis=False, stats=None, diffuse_vis=None, prefit=False):
     """render_with_sg, single-view, diffuse_vis=None, fun_spec=False (sg_render.py:343-565).
     lgt_sgs [n,M,7].  draws: dict with 'dvis_theta','dvis_phi' [M,32] (comp_vis only) and
     'svis_theta','svis_phi' [n,8]."""
     n, M = lgt_sgs.shape[0], lgt_sgs.shape[1]
+    supervise = torch.tensor(0.0)
     l_lobe = lgt_sgs[..., :3] / (lgt_sgs[..., :3].norm(dim=-1, keepdim=True) + TINY)
     l_lam = lgt_sgs[..., 3:4].abs()
     l_mu0 = lgt_sgs[..., -3:].abs()
@@ -142,6 +150,12 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
             lv, _, cnt = lv
             stats["diffuse_vis_evals"] = stats.get("diffuse_vis_evals", 0) + cnt
         light_vis = lv.permute(1, 0).unsqueeze(-1).expand(n, M, 3)
+        if diffuse_vis is not None:                                          # CESR (sg_render.py:393-403)
+            pred = diffuse_vis.reshape(-1, M, 1).expand(n, M, 3)
+            factor = {"warmup": 0.1, "project": 0.2}.get(prefit, 1.0)
+            supervise = kl_divergence((light_vis - pred).abs()[..., 0], 0.01) * factor
+            if prefit != "warmup":
+                light_vis = pred
         vis_shadow = (light_vis * l_mu0).sum(1) / torch.clamp(l_mu0.sum(1), 1e-4)
 
     # ---------------- specular (sg_render.py:414-500)
@@ -185,12 +199,13 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
     diff = diff.sum(-2).clamp(min=0.0)
     if indir_integral is not None:
         diff = indir_integral if lin_diff else indir_integral * (diffuse_albedo / math.pi)
-    return {"sg_rgb": spec + diff, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": vis_shadow}
+    return {"sg_rgb": spec + diff, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": vis_shadow,
+            "supervise": supervise}
 
 
 def render_with_all_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws,
                        indir_integral=None, indir_lgt_sgs=None, vis_fn=None, lin_diff=False, testing=False,
-                       metallic=None, argmax_vis=False, stats=None):
+                       metallic=None, argmax_vis=False, stats=None, diffuse_vis=None, prefit=False):
     """render_with_all_sg (sg_render.py:304-337): direct pass (128 lobes, visibility) + indirect pass
     (per-point 24 lobes, no light visibility, inverted specular visibility, diffuse := integral)."""
     n = normal.shape[0]
@@ -200,7 +215,7 @@ def render_with_all_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, 
                 "svis_theta": draws["svis_theta_dir"], "svis_phi": draws["svis_phi_dir"]}
     ret = render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo,
                          d_direct, comp_vis=True, vis_fn=vis_fn, lin_diff=lin_diff, testing=testing,
-                         metallic=metallic, argmax_vis=argmax_vis, stats=stats)
+                         metallic=metallic, argmax_vis=argmax_vis, stats=stats, diffuse_vis=diffuse_vis, prefit=prefit)
     z = torch.zeros_like(points)
     ind = {"sg_rgb": z, "sg_diffuse_rgb": z, "sg_specular_rgb": z}
     if indir_lgt_sgs is not None:

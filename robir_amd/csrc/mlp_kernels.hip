@@ -532,6 +532,87 @@ __global__ __launch_bounds__(256, 1) void k_ae_decode(const float* __restrict__ 
   }
 }
 
+// ---- 512-wide SDFNetwork-style nets of the CESR stage (training/train_cesr.py:106-110):
+//   shadow_net = SDFNetwork(63+128 -> 2, 512 x 8, skip [4], multires 0)   input [PE10(x) | one-hot light-lobe label]
+//   normal_net = SDFNetwork(63 -> 3,     512 x 8, skip [4], multires 0)   input PE10(x)
+// (model/neus_model.py:312-417 with multires = 0: no internal encoding).  Softplus(beta=100), skip concat /sqrt(2).
+// K0P = padded input width (192 / 64), N3P = padded width of lin3 (336 / 464), K4 = N3P + K0P = 528 for both.
+// ONEHOT: rows are (point, label) pairs, label = row % n_label; the kernel reads PE features of point row / n_label
+// from Xp[n,64] and synthesises the one-hot part in registers (never materialised: it would be 98 KB per point).
+template <int K0P, int N3P, bool ONEHOT>
+__global__ __launch_bounds__(256, 1) void k_softplus512(const float* __restrict__ X, long M, int n_label,
+                                                         const f4* __restrict__ Wp, int n_out, float* __restrict__ Y) {
+  constexpr int K4 = N3P + K0P;
+  static_assert(K4 == 528, "both CESR nets give a 528-wide skip layer");
+  __shared__ f4 lds[2 * chunk_f4(528)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  WStream<528> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<512, 512>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<K0P, 512>();
+  const f4* w3 = w1 + 2 * LF;
+  const f4* w4 = w3 + layer_f4<512, N3P>();
+  const f4* w5 = w4 + layer_f4<K4, 512>();
+  const f4* w8 = w5 + 3 * LF;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const float inv_sqrt2 = 0.70710678118654752440f;
+  float x0[1][K0P / 4], h[1][128], z[1][128];
+  if constexpr (ONEHOT) {
+    const bool ok = row < M;
+    const long pt = ok ? row / n_label : 0;
+    const int label = ok ? (int)(row % n_label) : -1;
+    const f4* p = reinterpret_cast<const f4*>(X + pt * 64) + g;
+#pragma unroll
+    for (int kb = 0; kb < K0P / 16; ++kb) {
+      f4 v = (kb < 4 && ok) ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kb * 16 + 4 * g + r;
+        float e = v[r];
+        if (k == 63) e = 0.f;                       // column 63 of Xp is padding; the one-hot block starts here
+        if (k >= 63 && k - 63 == label) e = 1.f;
+        x0[0][kb * 4 + r] = e;
+      }
+    }
+  } else {
+    load_features<K0P>(X, row, M, lane, x0[0]);
+  }
+  ws.prime<chunk_f4(K0P)>(w0);
+  dense_layer<K0P, 512, 1, 512>(ws, w0, w1, x0, z, lane, true);
+  activate<512, 1, ACT_SOFTPLUS100>(z, h);
+#pragma unroll 1
+  for (int l = 0; l < 2; ++l) {
+    dense_layer<512, 512, 1, 512>(ws, w1 + l * LF, w1 + (l + 1) * LF, h, z, lane, true);
+    activate<512, 1, ACT_SOFTPLUS100>(z, h);
+  }
+  {
+    float hs[1][K4 / 4];
+    {
+      float z3[1][N3P / 4];
+      dense_layer<512, N3P, 1, K4>(ws, w3, w4, h, z3, lane, true);
+#pragma unroll
+      for (int i = 0; i < N3P / 4; ++i) hs[0][i] = act_fn<ACT_SOFTPLUS100>(z3[0][i]) * inv_sqrt2;
+    }
+#pragma unroll
+    for (int i = 0; i < K0P / 4; ++i) hs[0][N3P / 4 + i] = x0[0][i] * inv_sqrt2;
+    dense_layer<K4, 512, 1, 512>(ws, w4, w5, hs, z, lane, true);
+  }
+  activate<512, 1, ACT_SOFTPLUS100>(z, h);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    dense_layer<512, 512, 1, 512>(ws, w5 + l * LF, w5 + (l + 1) * LF, h, z, lane, true);
+    activate<512, 1, ACT_SOFTPLUS100>(z, h);
+  }
+  float o[1][4];
+  dense_layer<512, 16, 1, 0>(ws, w8, nullptr, h, o, lane, true);
+  if (row < M && g == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < n_out) Y[row * n_out + r] = o[0][r];
+  }
+}
+
 // ---- small element-wise pieces of the auto-encoders / indirect-illumination head
 // latent = act(raw * (1 - var));  act: 0 sigmoid, 1 softplus(beta=1, threshold 20)   (sg_envmap_material.py:74-99)
 // writes lat[M,32]; if lat2 != null also lat2 = lat + noise*noise_scale (smooth_on_latent branch)
@@ -694,6 +775,24 @@ int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_
   RB_REQUIRE(X && Wp && raw, "null pointer");
   hipLaunchKernelGGL(k_wide_mlp<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, raw);
   return check_launch("k_wide_mlp<illum>");
+}
+
+int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && Y, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid1d(M, 64), block(256);
+  const f4* W = (const f4*)Wp;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((k_softplus512<64, 464, false>), grid, block, 0, s, X, M, 1, W, 3, Y); break;
+    case 1: hipLaunchKernelGGL((k_softplus512<192, 336, false>), grid, block, 0, s, X, M, 1, W, 2, Y); break;
+    case 2:
+      RB_REQUIRE(n_label >= 1 && n_label <= 128, "n_label must be 1..128");
+      hipLaunchKernelGGL((k_softplus512<192, 336, true>), grid, block, 0, s, X, M, n_label, W, 2, Y);
+      break;
+    default: return rb::fail("rb_cesr_net", "kind: 0 normal_net, 1 shadow_net (dense rows), 2 shadow_net (point x one-hot label)");
+  }
+  return check_launch("k_softplus512");
 }
 
 int rb_ae_encode(const float* X, long M, const float* Wp, float* raw_latent, rb_stream_t stream) {

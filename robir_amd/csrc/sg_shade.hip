@@ -272,6 +272,26 @@ __global__ __launch_bounds__(256) void k_sg_shade(const float* __restrict__ norm
   }
 }
 
+// render_envmap_sg (sg_render.py:26-42): rgb[i] = sum_k |mu_k| exp(|lambda_k| (d_i . lobe_k/|lobe_k| - 1)); no eps in the norm
+__global__ void k_envmap_sg(const float* __restrict__ lgt, int M, const float* __restrict__ dirs, long n,
+                            float* __restrict__ rgb) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < M; ++k) {
+    const float* s = lgt + k * 7;
+    V3 l = v3(s[0], s[1], s[2]);
+    const float ln = norm3(l);
+    l = v3(l.x / ln, l.y / ln, l.z / ln);
+    const float e = expf(fabsf(s[3]) * (dot3(d, l) - 1.f));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += fabsf(s[4 + c]) * e;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[3 * i + c] = acc[c];
+}
+
 // x / (|x| + eps) (mode 0) or x / max(|x|, eps) (mode 1), rows of 3
 __global__ void k_normalize3(const float* __restrict__ x, long n, float eps, int mode, float* __restrict__ y) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -289,6 +309,13 @@ __global__ void k_normalize3(const float* __restrict__ x, long n, float eps, int
 using namespace rb;
 
 extern "C" {
+
+int rb_envmap_sg(const float* lgt, int M, const float* dirs, long n, float* rgb, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(lgt && dirs && rgb && M >= 1, "null pointer");
+  hipLaunchKernelGGL(k_envmap_sg, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, lgt, M, dirs, n, rgb);
+  return check_launch("k_envmap_sg");
+}
 
 int rb_normalize3(const float* x, long n, float eps, int mode, float* y, rb_stream_t stream) {
   if (n <= 0) return 0;

@@ -290,13 +290,24 @@ def _wn_linear(k_in, n_out):
 
 
 class SDFNetwork(nn.Module):
-    """neus_model.py:312-438 for the configuration NeuSModel instantiates (d_in 3, 257 out, 256x8, skip 4, PE10)."""
+    """neus_model.py:312-438.  Three shapes are compiled:
+      (d_in 3,   d_out 257, 256 x 8, skip [4], multires 10)  -- the NeuS SDF network (default arguments)
+      (d_in 63,  d_out 3,   512 x 8, skip [4], multires 0)   -- CESR normal_net  (training/train_cesr.py:109)
+      (d_in 191, d_out 2,   512 x 8, skip [4], multires 0)   -- CESR shadow_net  (training/train_cesr.py:107)"""
 
-    def __init__(self):
+    def __init__(self, d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5, scale=1,
+                 geometric_init=True, weight_norm=True, inside_outside=False, embed="Default"):
         super().__init__()
-        dims = [63] + [256] * 8 + [257]
-        for l in range(9):
-            out = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
+        key = (d_in, d_out, d_hidden, n_layers, tuple(skip_in), multires)
+        kinds = {(3, 257, 256, 8, (4,), 10): "neus", (63, 3, 512, 8, (4,), 0): "normal", (191, 2, 512, 8, (4,), 0): "shadow"}
+        if key not in kinds or not weight_norm or scale != 1:
+            raise NotImplementedError(f"SDFNetwork{key}: the HIP kernels are compiled for {list(kinds)}")
+        self.kind = kinds[key]
+        self.d_in = d_in
+        first = 63 if self.kind == "neus" else d_in
+        dims = [first] + [d_hidden] * n_layers + [d_out]
+        for l in range(n_layers + 1):
+            out = dims[l + 1] - dims[0] if l + 1 in skip_in else dims[l + 1]
             setattr(self, "lin%d" % l, _wn_linear(dims[l], out))
         self.scale = 1
         self._packed = _Packed()
@@ -304,26 +315,43 @@ class SDFNetwork(nn.Module):
     def _sd(self, sd):
         return {"implicit_network.neus_model.sdf_network." + k: v for k, v in sd.items()}
 
-    def packed(self, full):
-        return self._packed.get("full" if full else "sdf", self,
-                                lambda sd: packing.pack_sdf(self._sd(sd), _dev(self), full=full))
+    def packed(self, full=True):
+        if self.kind == "neus":
+            return self._packed.get("full" if full else "sdf", self,
+                                    lambda sd: packing.pack_sdf(self._sd(sd), _dev(self), full=full))
+        return self._packed.get("w512", self, lambda sd: packing.pack_softplus512(
+            {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
 
     def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False):
-        """x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx."""
+        """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx."""
+        assert self.kind == "neus"
         x = x.float().contiguous()
         M = x.shape[0]
         mode = (1 if full else 0) + (2 if grad else 0)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
         return ops.sdf_mlp(X, M, self.packed(full), mode, out_scale, out_scale * in_scale)
 
-    def forward(self, inputs):
+    def eval_point_labels(self, Xp, n_label=128):
+        """shadow_net on every (point, one-hot label) pair: Xp [n,64] PE10 features -> logits [n*n_label, 2]."""
+        assert self.kind == "shadow"
+        return ops.cesr_net(Xp, Xp.shape[0] * n_label, 2, self.packed(), n_label)
+
+    def forward(self, inputs, var=0.0001, chunk=1024):
         if inputs.numel() == 0:
             return torch.ones_like(inputs)
         shape = list(inputs.shape[:-1]) + [-1]
-        out, _ = self.eval_points(inputs.reshape(-1, 3))
-        return out.reshape(shape)
+        if self.kind == "neus":
+            out, _ = self.eval_points(inputs.reshape(-1, 3))
+            return out.reshape(shape)
+        flat = inputs.reshape(-1, self.d_in).float()
+        M = flat.shape[0]
+        kp = 64 if self.kind == "normal" else 192
+        X = torch.zeros(M, kp, device=flat.device)
+        X[:, :self.d_in] = flat
+        return ops.cesr_net(X, M, 0 if self.kind == "normal" else 1, self.packed()).reshape(shape)
 
     def sdf(self, x):
+        assert self.kind == "neus"
         out, _ = self.eval_points(x.reshape(-1, 3), full=False)
         return out[:, None]
 
@@ -331,6 +359,7 @@ class SDFNetwork(nn.Module):
         return self.forward(x)
 
     def gradient(self, x):
+        assert self.kind == "neus"
         _, g = self.eval_points(x.reshape(-1, 3), full=False, grad=True)
         return g.unsqueeze(1)
 

@@ -354,3 +354,20 @@ def trace_integrate(rad, cosw, back, n, nsamp):
     out = torch.empty(n, 3, dtype=torch.float32, device=rad.device)
     call("rb_trace_integrate", ptr(_f32(rad)), ptr(cosw), ptr(back), c_long(n), c_int(nsamp), ptr(out), stream_ptr())
     return out
+
+
+def envmap_sg(lgt, dirs):
+    lgt, dirs = _f32(lgt), _f32(dirs)
+    n = dirs.shape[0]
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dirs.device)
+    call("rb_envmap_sg", ptr(lgt), c_int(lgt.shape[0]), ptr(dirs), c_long(n), ptr(rgb), stream_ptr())
+    return rgb
+
+
+def cesr_net(X, M, kind, blob, n_label=1):
+    """kind 0 normal_net (X[M,64] -> [M,3]); 1 shadow_net dense rows (X[M,192] -> [M,2]);
+    2 shadow_net on (point, label) pairs (X = point features [M/n_label,64], M rows -> [M,2])."""
+    n_out = 3 if kind == 0 else 2
+    Y = torch.empty(M, n_out, dtype=torch.float32, device=X.device)
+    call("rb_cesr_net", ptr(_f32(X)), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), stream_ptr())
+    return Y

@@ -151,3 +151,23 @@ def pack_sparse_ae(sd, prefix, device):
         b = _t(sd, prefix + ".brdf_decoder_layer.%d.bias" % (2 * i))
         dec.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
     return pack_layers(enc, device), pack_layers(dec, device)
+
+
+def pack_softplus512(sd, prefix, k_in, device):
+    """512 x 8 SDFNetwork-style net of the CESR stage (multires 0, skip [4]); k_in = 63 (normal_net) or 191 (shadow_net).
+    [K0P->512, 512->512 x2, 512->N3P, 528->512 (cols [lin3 | input]), 512->512 x3, 512->16]."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(prefix)}
+    k0p = _pad16(k_in)
+    n3 = 512 - k_in
+    n3p = _pad16(n3)
+    assert n3p + k0p == 528
+    ls = []
+    for l in range(9):
+        W = _fold_wn(sdt, prefix + "lin%d." % l)
+        b = sdt[prefix + "lin%d.bias" % l].float()
+        n_pad, k_pad, perm = _pad16(W.shape[0]), _pad16(W.shape[1]), None
+        if l == 4:
+            k_pad = 528
+            perm = [k if k < n3 else -1 for k in range(n3p)] + [n3 + j if j < k_in else -1 for j in range(k0p)]
+        ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
+    return pack_layers(ls, device)

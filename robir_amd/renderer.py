@@ -94,7 +94,7 @@ class IDRNetwork(nn.Module):
     def forward(self, input, trainstage="IDR", fun_spec=False, lin_diff=False, train_spec=False, draws=None, stats=None):
         """implicit_differentiable_renderer.py:290-479, uv/pose/intrinsics input form, batch size 1."""
         if "intrinsics" not in input:
-            raise NotImplementedError("points/dirs input form (from_light plotting) is not built yet")
+            return self._forward_points_dirs(input, trainstage, fun_spec, lin_diff, draws, stats)
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
         if uv.shape[0] != 1:
             raise NotImplementedError("batch size 1 (every runner uses 1)")
@@ -109,11 +109,36 @@ class IDRNetwork(nn.Module):
         mask = torch.ones(N, dtype=torch.bool, device=uv.device)
         return self._render(uv, pose, K, mask, hdr_shift, chunk, trainstage, False, False, draws, stats, None)
 
+    def _forward_points_dirs(self, input, trainstage, fun_spec, lin_diff, draws, stats):
+        """Second input form (implicit_differentiable_renderer.py:306-322): per-ray origins `points` and directions
+        `dirs`; rays outside `object_mask` are not traced (dist 0, no hit).  One lock-step batch."""
+        o = input["points"].reshape(-1, 3).float()
+        d = input["dirs"].reshape(-1, 3).float().contiguous()
+        N = o.shape[0]
+        mask = input["object_mask"].reshape(-1) if "object_mask" in input else torch.ones(N, dtype=torch.bool, device=o.device)
+        return self._render(None, None, None, mask, input.get("hdr_shift"), N, trainstage, fun_spec, lin_diff, draws, stats,
+                            input.get("albedo_ratio"), origins=o.contiguous(), dirs_in=d)
+
     def _render(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
-                albedo_ratio):
+                albedo_ratio, origins=None, dirs_in=None):
+        draws = draws or {}
+        if origins is not None:
+            dev, N = origins.device, origins.shape[0]
+            with torch.no_grad():
+                dirs = dirs_in
+                hit = torch.zeros(N, dtype=torch.bool, device=dev)
+                dist = torch.zeros(N, device=dev)
+                sel = object_mask.nonzero()[:, 0]
+                if sel.numel() > 0:
+                    _, h, t = self.ray_tracer.sdf_octree.cast_full(origins[sel].contiguous(), dirs[sel].contiguous())
+                    hit[sel], dist[sel] = h, t
+                n_chunks = 1
+                points = ops.points_along(origins, dirs, dist)
+                sdf_output = self.implicit_network.sdf_only(points)[:, None]
+            return self._shade(points, sdf_output, hit, object_mask, dirs, hdr_shift, chunk, n_chunks, trainstage, fun_spec,
+                               lin_diff, draws, stats, albedo_ratio)
         dev = uv.device
         N = uv.shape[0]
-        draws = draws or {}
         pose_h = pose.detach().cpu().numpy()
         cam = pose[:3, 3].float().reshape(1, 3).contiguous()
         with torch.no_grad():
@@ -126,6 +151,12 @@ class IDRNetwork(nn.Module):
                 n_chunks = 1
             points = ops.points_along(cam.expand(N, 3).contiguous(), dirs, dist)
             sdf_output = self.implicit_network.sdf_only(points)[:, None]
+        return self._shade(points, sdf_output, hit, object_mask, dirs, hdr_shift, chunk, n_chunks, trainstage, fun_spec,
+                           lin_diff, draws, stats, albedo_ratio)
+
+    def _shade(self, points, sdf_output, hit, object_mask, dirs, hdr_shift, chunk, n_chunks, trainstage, fun_spec, lin_diff,
+               draws, stats, albedo_ratio):
+        dev, N = points.device, points.shape[0]
         ret = {"points": points, "sdf_output": sdf_output, "network_object_mask": hit, "object_mask": object_mask,
                "ray_dirs": dirs}
         idx = hit.nonzero()[:, 0]
@@ -157,13 +188,15 @@ class IDRNetwork(nn.Module):
                                      "vis_shadow", "random_xi_roughness", "random_xi_diffuse_albedo")}
         out1 = {k: ones1() for k in ("metallic", "random_xi_metallic", "acc", "final_t")}
         bg = ones3()
+        gerr = torch.tensor(0.0, device=dev)
         if self.envmap_material_network.envmap is not None:
             bg = sg_render.render_envmap(self.envmap_material_network.envmap, dirs)
         if n > 0:
             view = (-dirs[idx]).contiguous()
             kw = {}
-            if getattr(self.get_sg_render, "__func__", None) is IDRNetwork.get_sg_render:
-                kw = dict(draws=draws, chunk_id=cid, n_chunks=n_chunks, stats=stats)   # our own hook understands these
+            if (getattr(self.get_sg_render, "__func__", None) is IDRNetwork.get_sg_render
+                    or getattr(self.get_sg_render, "robir_native", False)):
+                kw = dict(draws=draws, chunk_id=cid, n_chunks=n_chunks, stats=stats)   # our own hooks understand these
             r = self.get_sg_render(hp, view, sgs_h if hdr_shift is not None else indirect_sgs[idx],
                                    albedo_ratio=albedo_ratio, fun_spec=fun_spec, lin_diff=lin_diff, train_spec=True,
                                    indir_integral=int_h if hdr_shift is not None else indirect_integral[idx],
@@ -173,7 +206,9 @@ class IDRNetwork(nn.Module):
                 out3[k][idx] = v.expand(-1, 3) if v.shape[-1] == 1 else v
             out1["metallic"][idx] = r["metallic"]
             out1["random_xi_metallic"][idx] = r["random_xi_metallic"]
-        ret.update({"gradient_error": torch.tensor(0.0, device=dev), "bg_rgb": bg, "surface_mask": hit})
+            if "gradient_error" in r:
+                gerr = gerr + r["gradient_error"]
+        ret.update({"gradient_error": gerr, "bg_rgb": bg, "surface_mask": hit})
         ret.update(out3)
         ret.update(out1)
         return ret
@@ -223,6 +258,49 @@ class IDRNetwork(nn.Module):
             gt_int[idx] = ops.trace_integrate(rad, cosw, back, n, nsamp)
         return {"trace_radiance": trace, "sample_dirs": sdirs, "gt_vis": gt_vis, "pred_vis": pred_vis,
                 "indir_mask": indir_mask[..., 0], "gt_integral": gt_int}
+
+
+class CESRHook:
+    """ClusteredAlbedoTrainRunner.get_sg_render (training/train_cesr.py:465-544) restated for the HIP path:
+    shadow_net evaluated for each of the 128 one-hot light-lobe labels per point, normal_net, linear-diffuse shading
+    (`lin_diff=True`) recombined with the albedo.  Install with `model.get_sg_render = CESRHook(model, ...)`."""
+
+    robir_native = True
+
+    def __init__(self, model, shadow_net, normal_net, is_training=False, cur_iter=100000, prefit="explore",
+                 argmax_vis=False):
+        self.model, self.shadow_net, self.normal_net = model, shadow_net, normal_net
+        self.is_training, self.cur_iter, self.prefit, self.argmax_vis = is_training, cur_iter, prefit, argmax_vis
+
+    def __call__(self, points, view_dirs, indir_lgtSGs, albedo_ratio=None, fun_spec=False, lin_diff=False,
+                 train_spec=False, indir_integral=None, draws=None, chunk_id=None, n_chunks=1, stats=None, **kwargs):
+        m = self.model
+        draws = draws or {}
+        vd = ops.normalize3(view_dirs.float().contiguous(), 1e-6, 0)
+        normals = ops.normalize3(m.get_idr_render(points, normal_only=True).contiguous(), 1e-4, 1)
+        mat = m.envmap_material_network(points, train_spec=True,
+                                        noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
+        Xp = ops.feat_pe10(points.float().contiguous())
+        logits = self.shadow_net.eval_point_labels(Xp, 128)
+        diffuse_vis = torch.softmax(logits, -1)[..., 1]
+        normal_new = ops.normalize3(ops.cesr_net(Xp, Xp.shape[0], 0, self.normal_net.packed()), 1e-4, 1)
+        albedo = mat["sg_diffuse_albedo"]
+        ret = sg_render.render_with_all_sg(points=points, normal=normal_new if self.cur_iter > 1000 else mat["sg_normal_map"],
+                                           viewdirs=vd, lgtSGs=mat["sg_lgtSGs"], indir_integral=indir_integral * 2 * np.pi,
+                                           specular_reflectance=mat["sg_specular_reflectance"].abs(),
+                                           roughness=mat["sg_roughness"], diffuse_albedo=albedo,
+                                           indir_lgtSGs=indir_lgtSGs, VisModel=m.visibility_network, fun_spec=False,
+                                           lin_diff=True, testing=not self.is_training, metallic=None,
+                                           diffuse_vis=diffuse_vis, prefit=self.prefit, argmax_vis=self.argmax_vis,
+                                           draws=draws, chunk_id=chunk_id, n_chunks=n_chunks, stats=stats)
+        ret["sg_rgb"] = ret["sg_diffuse_rgb"] * albedo / np.pi + ret["sg_specular_rgb"]
+        ret["indir_rgb"] = ret["indir_diffuse_rgb"] * albedo / np.pi + ret["indir_specular_rgb"]
+        supervise = ret["supervise"] + ((mat["sg_normal_map"] - normal_new) ** 2).mean()
+        ret.update({"normals": normals, "diffuse_albedo": albedo, "roughness": mat["sg_roughness"],
+                    "metallic": mat["sg_metallic"], "normal_map": normal_new, "gradient_error": supervise,
+                    "random_xi_roughness": mat["random_xi_roughness"], "random_xi_metallic": mat["random_xi_metallic"],
+                    "random_xi_diffuse_albedo": mat["random_xi_diffuse_albedo"]})
+        return ret
 
 
 # ----------------------------------------------------------------------------------------- construction helpers

@@ -32,11 +32,10 @@ def norm_axis(x):
 
 
 def render_envmap_sg(lgtSGs, viewdirs):
-    """sum_k mu_k exp(lambda_k (d.lobe_k - 1)) (sg_render.py:26-42) -- logging helper, evaluated with torch ops."""
-    viewdirs = viewdirs.to(lgtSGs.device).unsqueeze(-2)
-    lobes = lgtSGs[..., :3] / torch.norm(lgtSGs[..., :3], dim=-1, keepdim=True)
-    lam, mu = torch.abs(lgtSGs[..., 3:4]), torch.abs(lgtSGs[..., -3:])
-    return torch.sum(mu * torch.exp(lam * (torch.sum(viewdirs * lobes, dim=-1, keepdim=True) - 1.0)), dim=-2)
+    """sum_k mu_k exp(lambda_k (d.lobe_k - 1)) (sg_render.py:26-42)."""
+    shape = list(viewdirs.shape[:-1]) + [3]
+    d = viewdirs.to(lgtSGs.device).reshape(-1, 3).float().contiguous()
+    return ops.envmap_sg(lgtSGs.detach().float().contiguous(), d).reshape(shape)
 
 
 def compute_envmap(lgtSGs, H, W, upper_hemi=False):
@@ -157,6 +156,13 @@ def get_specular_visibility(points, normals, viewdirs, VisModel, lgtSGLobes, lgt
     return _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, None, 1)
 
 
+def _kl_divergence(x, mu):
+    """utils/utils.py:14-17."""
+    rho_hat = torch.mean(x, 0)
+    rho = torch.full_like(rho_hat, mu)
+    return torch.mean(rho * torch.log(rho / (rho_hat + 1e-4)) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat + 1e-4)))
+
+
 # ----------------------------------------------------------------------------------------- shading
 def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo, comp_vis=True,
                    VisModel=None, fun_spec=False, lin_diff=False, testing=False, indir_integral=None, metallic=None,
@@ -165,8 +171,6 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     """sg_render.py:343-565 (single view).  lgtSGs [n,M,7] (or [M,7])."""
     if fun_spec:
         raise NotImplementedError("fun_spec=True (specular as a closure) is a training-only path")
-    if diffuse_vis is not None:
-        raise NotImplementedError("diffuse_vis (CESR shadow_net supervision) is not built yet")
     if viewdirs.dim() == 3:
         raise NotImplementedError("multi-view shading is not on the hot path")
     dev = points.device
@@ -181,8 +185,9 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
     lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
     light_vis = None
+    supervise = torch.tensor(0.0, device=dev)
     if comp_vis:
-        nsamp = 32
+        nsamp = 32 if diffuse_vis is None else 8          # sg_render.py:389
         u_t = draws.get("dvis_theta")
         u_p = draws.get("dvis_phi")
         if u_t is None:
@@ -190,6 +195,14 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
             u_t, u_p = _rand((C, L, nsamp), dev), _rand((C, L, nsamp), dev)
         # first row's light for every point (sg_render.py:388-390)
         light_vis = _diffuse_vis_core(pts, nrm, VisModel, lgt_first, u_t, u_p, 1.0, argmax_vis, cid, C, stats)
+        if diffuse_vis is not None:
+            # CESR: the shadow net's prediction replaces the sampled visibility in shading except during warm-up;
+            # the sampled one only feeds the KL supervision term (sg_render.py:393-403; a loss, evaluated with torch ops)
+            pred = diffuse_vis.reshape(-1, lgt_first.shape[0]).float().contiguous()
+            factor = {"warmup": 0.1, "project": 0.2}.get(prefit, 1.0)
+            supervise = _kl_divergence((light_vis - pred).abs(), 0.01) * factor
+            if prefit != "warmup":
+                light_vis = pred
     u_t, u_p = draws.get("svis_theta"), draws.get("svis_phi")
     if u_t is None:
         u_t, u_p = _rand((n, 8), dev), _rand((n, 8), dev)
@@ -199,8 +212,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     rgb, spec, diff, shadow = ops.sg_shade(nrm, vd, lgt, f0, rough, diffuse_albedo, bvis, light_vis=light_vis,
                                            metallic=metallic, indir_integral=indir_integral, lin_diff=lin_diff,
                                            want_shadow=True)
-    return {"sg_rgb": rgb, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": shadow,
-            "supervise": torch.tensor(0.0, device=dev)}
+    return {"sg_rgb": rgb, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": shadow, "supervise": supervise}
 
 
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo,

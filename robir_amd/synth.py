@@ -141,6 +141,25 @@ def _sparse_ae(sd, seed, prefix, in_dim, out_dim):
         _relu_linear(sd, seed, prefix + ".brdf_decoder_layer.%d" % (2 * i), dims[i], dims[i + 1])
 
 
+def synth_cesr_nets(seed=0):
+    """State dicts of the CESR runner's shadow_net (191 -> 2) and normal_net (63 -> 3): SDFNetwork(.., 512, 8, [4], 0)
+    (training/train_cesr.py:106-110).  He-style normal weights with g = 0.9..1.1 |v| (weight norm exercised)."""
+    out = {}
+    for name, k_in, n_out in (("shadow_net", 191, 2), ("normal_net", 63, 3)):
+        sd = {}
+        dims = [k_in] + [512] * 8 + [n_out]
+        for l in range(9):
+            o = dims[l + 1] - dims[0] if l + 1 == 4 else dims[l + 1]
+            key = f"{name}.lin{l}"
+            v = _normal(seed, key + ".v", (o, dims[l]), 0.0, math.sqrt(2.0) / math.sqrt(dims[l]))
+            nrm = np.linalg.norm(v.astype(np.float64), axis=1, keepdims=True)
+            sd[f"lin{l}.weight_v"] = v
+            sd[f"lin{l}.weight_g"] = (nrm * _rng(seed, key + ".g").uniform(0.9, 1.1, (o, 1))).astype(np.float32)
+            sd[f"lin{l}.bias"] = _uniform(seed, key + ".b", (o,), 0.01 if l < 8 else 0.5)
+        out[name] = sd
+    return out
+
+
 def neus_state_dict(sd):
     """The sub-dict a stage-1 NeuS checkpoint ({step:06d}.tar -> 'model') would hold."""
     pre = "implicit_network.neus_model."

@@ -1,0 +1,77 @@
+"""CESR-stage hook on the GPU (BASELINE.json config 5 arithmetic): shadow_net / normal_net kernels and the full
+forward with the CESR get_sg_render, against the reference's golden outputs and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, bad_frac, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cesr_nets(dev):
+    from robir_amd import nets, synth
+    c = synth.synth_cesr_nets(0)
+    shadow = nets.SDFNetwork(63 + 128, 2, 512, 8, [4], 0)
+    normal = nets.SDFNetwork(63, 3, 512, 8, [4], 0)
+    shadow.load_state_dict({k: torch.from_numpy(v) for k, v in c["shadow_net"].items()})
+    normal.load_state_dict({k: torch.from_numpy(v) for k, v in c["normal_net"].items()})
+    return shadow.to(dev).eval(), normal.to(dev).eval()
+
+
+def test_cesr_nets_golden(dev, cesr_nets):
+    shadow, normal = cesr_nets
+    g = load_golden("cesr_nets")
+    assert rel_err(normal(torch.from_numpy(g["x_normal"]).to(dev)).cpu(), g["y_normal"]) <= 1e-4
+    assert rel_err(shadow(torch.from_numpy(g["x_shadow"]).to(dev)).cpu(), g["y_shadow"]) <= 1e-4
+
+
+def test_shadow_onehot_equals_dense(dev, cesr_nets):
+    """(point, label) form with the one-hot block synthesised in registers == dense rows [PE | one-hot]."""
+    from robir_amd import ops
+    shadow, _ = cesr_nets
+    g = np.random.Generator(np.random.PCG64(3))
+    pts = torch.from_numpy((g.standard_normal((21, 3)) * 0.25).astype(np.float32)).to(dev)
+    Xp = ops.feat_pe10(pts)
+    a = shadow.eval_point_labels(Xp, 128).cpu()
+    dense = torch.cat([Xp[:, None, :63].expand(-1, 128, -1), torch.eye(128, device=dev)[None].expand(21, -1, -1)], -1)
+    b = shadow(dense.reshape(-1, 191)).cpu()
+    assert rel_err(a, b) <= 1e-6
+
+
+def test_forward_cesr_vs_oracle_and_golden(dev, cesr_nets, oracle_sd, oracle_octree):
+    from robir_amd import renderer, synth
+    from robir_amd.octree_tracing import OctreeSDF
+    from robir_oracle import renderer as orend
+    shadow, normal = cesr_nets
+    m = renderer.build_synthetic_model(dev, build_octrees=False)
+    m.ray_tracer.sdf_octree = OctreeSDF.from_host_tables(oracle_octree, dev, -1)
+    m.get_sg_render = renderer.CESRHook(m, shadow, normal, is_training=False, cur_iter=100000, prefit="explore")
+    g = load_golden("forward_cesr_c1")
+    uv, pose, K = synth.synth_camera(int(g["H"]), int(g["W"]))
+    sl = slice(1024, 2048)
+    draws = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("draw_")}
+    hdr = torch.from_numpy(g["hdr_shift"]).expand(1024, 1).contiguous()
+    c = synth.synth_cesr_nets(0)
+    ref = orend.forward(oracle_sd, oracle_octree, torch.from_numpy(uv)[None, sl], torch.from_numpy(pose)[None],
+                        torch.from_numpy(K)[None], torch.ones(1, 1024, dtype=torch.bool), hdr, draws, "Material",
+                        testing=True, cesr=({k: torch.from_numpy(v) for k, v in c["shadow_net"].items()},
+                                            {k: torch.from_numpy(v) for k, v in c["normal_net"].items()}))
+    inp = {"uv": torch.from_numpy(uv[sl]).to(dev)[None], "pose": torch.from_numpy(pose).to(dev)[None],
+           "intrinsics": torch.from_numpy(K).to(dev)[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr.to(dev)}
+    out = m(inp, trainstage="Material", lin_diff=True, train_spec=True, draws={k: v.to(dev) for k, v in draws.items()})
+    assert bool((out["network_object_mask"].cpu() == ref["network_object_mask"]).all())
+    for k in ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "vis_shadow", "normal_map", "diffuse_albedo",
+              "roughness"):
+        assert bad_frac(out[k].cpu(), ref[k], 2e-4) <= 0.005, (k, bad_frac(out[k].cpu(), ref[k], 2e-4))
+        assert rel_err(out[k].cpu(), ref[k]) <= 1e-3, (k, rel_err(out[k].cpu(), ref[k]))
+    assert rel_err(out["gradient_error"].cpu(), ref["gradient_error"]) <= 1e-3
+    for k in ("sg_rgb", "vis_shadow", "normal_map"):                       # reference's own output (independent octree)
+        assert bad_frac(out[k].cpu(), g["out_" + k], 2e-3) <= 0.003, k

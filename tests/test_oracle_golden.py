@@ -153,3 +153,25 @@ def test_render_neus(synth_weights, tag):
     for k, tol in (("rgb", 1e-4), ("dist", 1e-4), ("acc", 2e-4), ("grad", 2e-4), ("grad_error", 1e-4)):
         assert rel_err(out[k], g["out_" + k]) <= tol, k
     assert bad_frac(out["weights"], g["out_weights"], 5e-3) <= 0.01      # per-sample weights: inv_s-amplified noise
+
+
+def test_cesr_nets_and_forward(oracle_sd, oracle_octree):
+    """CESR hook (shadow_net on 128 one-hot labels per point, normal_net, linear-diffuse shading) vs the reference."""
+    from robir_amd import synth
+    from robir_oracle import nets, renderer
+    c = synth.synth_cesr_nets(0)
+    shadow = {k: torch.from_numpy(v) for k, v in c["shadow_net"].items()}
+    normal = {k: torch.from_numpy(v) for k, v in c["normal_net"].items()}
+    g = load_golden("cesr_nets")
+    assert rel_err(nets.softplus_net512(normal, torch.from_numpy(g["x_normal"])), g["y_normal"]) <= TOL
+    assert rel_err(nets.softplus_net512(shadow, torch.from_numpy(g["x_shadow"])), g["y_shadow"]) <= TOL
+    g = load_golden("forward_cesr_c1")
+    uv, pose, K = synth.synth_camera(int(g["H"]), int(g["W"]))
+    sl = slice(1024, 2048)
+    draws = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("draw_")}
+    out = renderer.forward(oracle_sd, oracle_octree, torch.from_numpy(uv)[None, sl], torch.from_numpy(pose)[None],
+                           torch.from_numpy(K)[None], torch.ones(1, 1024, dtype=torch.bool),
+                           torch.from_numpy(g["hdr_shift"]).expand(1024, 1), draws, "Material", testing=True,
+                           cesr=(shadow, normal))
+    for k in ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "vis_shadow", "normal_map", "diffuse_albedo"):
+        assert bad_frac(out[k], g["out_" + k], 2e-3) <= 0.003, k
