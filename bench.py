@@ -144,13 +144,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # ROBIR_SHARE_GPU=1 + ROBIR_DIST_BACKEND=gloo: all ranks on cuda:0 (lets the multi-rank code path be exercised on a
+    # 1-GPU box; RCCL refuses two ranks on one device).  Normal runs: one rank per GPU over RCCL ("nccl" on ROCm).
+    if os.environ.get("ROBIR_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("ROBIR_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from robir_amd import ops, renderer, synth, sg_render
     from robir_amd.parallel import all_gather_tiles
@@ -175,6 +183,7 @@ def main():
         return all_gather_tiles(tiles) if world > 1 else tiles
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -303,6 +303,29 @@ class CESRHook:
         return ret
 
 
+class NormHook:
+    """NormalTrainRunner.get_sg_render (training/train_normal.py:347-398): no shading in the Norm stage -- NeuS normal,
+    materials, the normal map carried in the `diffuse_albedo` slot, constant radiance outputs."""
+
+    robir_native = True
+
+    def __init__(self, model):
+        self.model = model
+
+    def __call__(self, points, view_dirs, indir_lgtSGs, albedo_ratio=None, fun_spec=False, lin_diff=False,
+                 train_spec=False, indir_integral=None, draws=None, **kwargs):
+        draws = draws or {}
+        normals = self.model.get_idr_render(points, normal_only=True)              # un-normalised, like the reference
+        mat = self.model.envmap_material_network(points, train_spec=True,
+                                                 noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
+        z, o = torch.zeros_like(points), torch.ones_like(points)
+        return {"normals": normals, "sg_rgb": o, "indir_rgb": z, "sg_diffuse_rgb": z, "sg_specular_rgb": z,
+                "indir_diffuse_rgb": z, "indir_specular_rgb": z, "vis_shadow": z,
+                "diffuse_albedo": mat["sg_normal_map"], "roughness": mat["sg_roughness"], "metallic": mat["sg_metallic"],
+                "normal_map": mat["sg_normal_map"], "random_xi_roughness": mat["random_xi_roughness"],
+                "random_xi_metallic": mat["random_xi_metallic"], "random_xi_diffuse_albedo": mat["random_xi_normal"]}
+
+
 # ----------------------------------------------------------------------------------------- construction helpers
 class DictConf:
     """Minimal pyhocon-like accessor (get_bool/get_int/get_float/get_config, `**conf.get_config(...)`) so the model
