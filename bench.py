@@ -224,7 +224,12 @@ def main():
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "parallelism": f"ray-shard x{world} (views)"},
             "roofline": {"bound": "mfma", "kernel": "k_dvis_fused (light-SG visibility MLP)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "precision": precision,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         # HBM bytes per launch: 31 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE
+                         # (x2 gfx950 correction) + WRITE_SIZE on this kernel (profiles/r01_dvis_f16x3_pmc.md), scaled to
+                         # this launch's pair count; 0.3 % of the HBM roofline -- the bound is the matrix pipe
+                         "traffic": 31.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                         "precision": precision,
                          "frac_of_f16x3_bound": (achieved / (2500.0 / 3.0)) if precision == "f16x3" else None,
                          "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                          "flops_per_eval": 2 * VIS_MACS_PER_EVAL},

@@ -128,8 +128,9 @@ class SparseAE(nn.Module):
             return v.to(device=dev, dtype=torch.float32).contiguous()
         return None
 
-    def run(self, X, noise=None, X_noisy=None):
-        """X [n,64] padded features.  smooth_on_latent: noise [n,32]; else X_noisy [n,64] = features of the perturbed input."""
+    def run(self, X, noise=None, X_noisy=None, need_first=True):
+        """X [n,64] padded features.  smooth_on_latent: noise [n,32]; else X_noisy [n,64] = features of the perturbed input.
+        need_first=False skips the un-perturbed pass (the indirect-illumination integral only uses the second output)."""
         enc, dec = self._blobs()
         dev = X.device
         sig_out = self.out_act is not None
@@ -138,8 +139,10 @@ class SparseAE(nn.Module):
         if self.smooth_on_latent:
             lat, lat2 = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code(), noise, 0.01)
         else:
-            lat, _ = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code())
             lat2, _ = ops.ae_latent(ops.ae_encode(X_noisy, enc), self._var(dev), self._latent_act_code())
+            if not need_first:
+                return None, ops.ae_decode(lat2, dec, self.out_dim, sig_out)
+            lat, _ = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code())
         return ops.ae_decode(lat, dec, self.out_dim, sig_out), ops.ae_decode(lat2, dec, self.out_dim, sig_out)
 
     def forward(self, values, noise=None):
@@ -189,7 +192,7 @@ class IndirctIllumNetwork(nn.Module):
         if noise is None:
             noise = torch.randn(n, 64, device=dev)
         Xn = ops.axpy(X, noise.float().contiguous(), 0.02)
-        _, second = self.integral_layer.run(X, X_noisy=Xn)
+        _, second = self.integral_layer.run(X, X_noisy=Xn, need_first=False)
         return sgs, second.abs()
 
 

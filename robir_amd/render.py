@@ -1,0 +1,90 @@
+"""Full-image forward rendering entry point (the 'serve' path; cf. the reference's scripts/relight.py:33-117 and
+PBRTrainRunner.plot_to_disk, training/train_pbr.py:235-311): all chunks of one view through IDRNetwork.render_chunks,
+optionally under a new light (EnvmapMaterialNetwork.load_light), tone-mapped to LDR.
+
+    python -m robir_amd.render --synthetic --size 800 --out /tmp/view.npz
+    python -m robir_amd.render --neus-ckpt logs/.../200000.tar --stage-ckpt exps/.../ModelParameters/latest.pth \
+        --cameras data/hotdog/transforms_test.json --index 0 --size 800 --light envmaps/envmap3 --out view.npz
+"""
+import argparse
+import json
+import math
+
+import numpy as np
+import torch
+
+
+def blender_camera(transforms_json, index, H, W):
+    """SynDataset conventions (datasets/syn_dataset.py:25-84): focal from camera_angle_x, translation / 2."""
+    meta = json.load(open(transforms_json))
+    focal = 0.5 * W / math.tan(0.5 * float(meta["camera_angle_x"]))
+    pose = np.array(meta["frames"][index]["transform_matrix"], dtype=np.float32)
+    pose[:3, 3] /= 2.0
+    K = np.array([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]], np.float32)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    return np.stack([xs, ys], -1).reshape(-1, 2), pose, K
+
+
+def load_stage_checkpoint(model, path):
+    """{'epoch', 'model_state_dict'} written by the stage runners (training/train_pbr.py:215-233)."""
+    sd = torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"]
+    return model.load_state_dict(sd, strict=False)
+
+
+def render_view(model, uv, pose, K, chunks_per_pass=125, chunk=1024, hdr_shift=None):
+    dev = next(model.parameters()).device
+    uv_d = torch.from_numpy(uv).to(dev)
+    pose_d, K_d = torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    N = uv_d.shape[0]
+    shift = model.gamma.hdr_shift.as_input().detach() if hdr_shift is None else torch.tensor([[hdr_shift]], device=dev)
+    hdr = shift.expand(N, 1).contiguous()
+    per = chunks_per_pass * chunk
+    keys = ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "vis_shadow", "normal_map", "network_object_mask", "bg_rgb")
+    acc = {k: [] for k in keys}
+    for s in range(0, N, per):
+        o = model.render_chunks(uv_d[s:s + per], pose_d, K_d, hdr[s:s + per], chunk=chunk)
+        for k in keys:
+            acc[k].append(o[k])
+    out = {k: torch.cat(v) for k, v in acc.items()}
+    tm = model.gamma.hdr_shift
+    hit = out["network_object_mask"][:, None]
+    pred = tm.hdr2ldr(out["sg_rgb"] + out["indir_rgb"], shift)
+    out["pred_rgb"] = torch.where(hit, pred, out["bg_rgb"])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--neus-ckpt")
+    ap.add_argument("--stage-ckpt")
+    ap.add_argument("--cameras")
+    ap.add_argument("--index", type=int, default=0)
+    ap.add_argument("--light", help="directory holding sg_128.npy (and optionally <dir>.exr)")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    from . import renderer, synth
+    dev = torch.device("cuda:0")
+    H = W = a.size
+    if a.synthetic:
+        model = renderer.build_synthetic_model(dev)
+        uv, pose, K = synth.synth_camera(H, W)
+    else:
+        model = renderer.IDRNetwork(renderer.hotdog_conf())
+        state = torch.load(a.neus_ckpt, map_location="cpu", weights_only=False)
+        model.implicit_network.neus_model.load_state_dict(state["model"], strict=False)
+        if a.stage_ckpt:
+            load_stage_checkpoint(model, a.stage_ckpt)
+        model = model.to(dev).eval()
+        model.ray_tracer.generate()
+        uv, pose, K = blender_camera(a.cameras, a.index, H, W)
+    if a.light:
+        model.envmap_material_network.load_light(a.light)
+    out = render_view(model, uv, pose, K)
+    np.savez_compressed(a.out, **{k: v.detach().cpu().numpy().reshape(H, W, -1) for k, v in out.items()})
+    print("wrote", a.out, "hit fraction %.3f" % float(out["network_object_mask"].float().mean()))
+
+
+if __name__ == "__main__":
+    main()

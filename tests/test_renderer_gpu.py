@@ -156,3 +156,43 @@ def test_illum_and_trace_radiance_vs_golden(dev, model_oracle_tables):
     assert bad_frac(out["trace_radiance"].cpu(), g["out_trace_radiance"], 1e-3) <= 0.002
     assert bad_frac(out["gt_integral"].cpu(), g["out_gt_integral"], 1e-3) <= 0.005
     assert bool((out["indir_mask"].cpu().numpy() == g["out_indir_mask"]).mean() > 0.999)
+
+
+def test_points_dirs_form_equals_uv_form(dev, model):
+    """forward({'points','dirs'}) (implicit_differentiable_renderer.py:306-322) on the camera's own rays == uv form."""
+    from robir_amd import synth, ops
+    uv, pose, K = synth.synth_camera(64, 64)
+    sl = slice(1024, 2048)
+    uv_d, pose_d, K_d = torch.from_numpy(uv[sl]).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    hdr = torch.full((1024, 1), 0.5, device=dev)
+    n0 = model.render_chunks(uv_d, pose_d, K_d, hdr, trainstage="Illum", draws={})["network_object_mask"].sum().item()
+    dr = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(0, int(n0), chunk_id=1).items()}
+    a = model({"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+               "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr},
+              trainstage="Material", train_spec=True, draws=dr)
+    dirs = ops.camera_rays(pose, K, uv_d)
+    cam = pose_d[:3, 3].reshape(1, 3).expand(1024, 3).contiguous()
+    b = model({"points": cam[None], "dirs": dirs[None], "hdr_shift": hdr}, trainstage="Material", train_spec=True, draws=dr)
+    assert bool((a["network_object_mask"] == b["network_object_mask"]).all())
+    for k in ("points", "sg_rgb", "indir_rgb", "vis_shadow", "normal_map"):
+        assert rel_err(a[k].cpu(), b[k].cpu()) <= 1e-6, k
+
+
+def test_norm_hook_and_render_view(dev, model):
+    from robir_amd import renderer, render, synth
+    uv, pose, K = synth.synth_camera(96, 96)
+    out = render.render_view(model, uv, pose, K, chunks_per_pass=4)
+    assert out["pred_rgb"].shape == (96 * 96, 3) and bool(torch.isfinite(out["pred_rgb"][out["network_object_mask"]]).all())
+    old = model.get_sg_render
+    try:
+        model.get_sg_render = renderer.NormHook(model)
+        uv_d = torch.from_numpy(uv[:1024]).to(dev)
+        o = model({"uv": uv_d[None], "pose": torch.from_numpy(pose).to(dev)[None], "intrinsics": torch.from_numpy(K).to(dev)[None],
+                   "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+                   "hdr_shift": torch.full((1024, 1), 0.5, device=dev)}, trainstage="Material", train_spec=True)
+        hit = o["network_object_mask"]
+        assert rel_err(o["diffuse_albedo"][hit].cpu(), o["normal_map"][hit].cpu()) == 0.0
+        assert float(o["sg_rgb"].min()) == 1.0 and float(o["indir_rgb"][hit].abs().max()) == 0.0
+    finally:
+        model.__dict__.pop("get_sg_render", None)
+        assert model.get_sg_render.__func__ is renderer.IDRNetwork.get_sg_render
