@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--chunks-per-batch", type=int, default=125, help="1024-pixel chunks rendered per kernel pass")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3"],
+    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
     return ap.parse_args()
@@ -230,7 +230,7 @@ def main():
                          # this launch's pair count; 0.3 % of the HBM roofline -- the bound is the matrix pipe
                          "traffic": 31.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
                          "precision": precision,
-                         "frac_of_f16x3_bound": (achieved / (2500.0 / 3.0)) if precision == "f16x3" else None,
+                         "frac_of_f16x3_bound": (achieved / (2500.0 / 3.0)) if precision.startswith("f16x3") else None,
                          "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                          "flops_per_eval": 2 * VIS_MACS_PER_EVAL},
         }

@@ -74,8 +74,8 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
 
 constexpr int DV_MAX_DIRS = 4096;
 
-template <bool H3, int CH>
-__global__ __launch_bounds__(256, 1) void k_dvis_fused(
+template <bool H3, int CH, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
     const float* __restrict__ wsum, const f4* __restrict__ Whid, const float* __restrict__ wlast,
@@ -117,10 +117,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
   if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
 
   WStream<256> ws;
-  H3Ring<2, 48> ring;
+  H3Ring<NT, 48> ring;
   constexpr long LF = (long)16 * chunk_f4(256);
   const float b0 = blast[0], b1 = blast[1];
-  const int rounds = (S + 127) / 128;
+  constexpr int RS = 64 * NT;   // samples per workgroup round
+  const int rounds = (S + RS - 1) / RS;
   if constexpr (H3) {
     if (rounds > 0) ring.start(lds_w, Whid, tid);
   } else {
@@ -128,17 +129,17 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
     if (rounds > 0) ws.prime<chunk_f4(256)>(Whid);
   }
   for (int rd = 0; rd < rounds; ++rd) {
-    float z[2][64];    // pre-activation of the last hidden layer (fp32 path: every layer)
-    int jj[2];
+    float z[NT][64];    // pre-activation of the last hidden layer (fp32 path: every layer)
+    int jj[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int si = rd * 128 + wave * 32 + t * 16 + (lane & 15);
+    for (int t = 0; t < NT; ++t) {
+      const int si = rd * RS + wave * (16 * NT) + t * 16 + (lane & 15);
       jj[t] = si < S ? (int)idx_list[si] : -1;
     }
     if constexpr (!H3) {
-      float h[2][64];
+      float h[NT][64];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int j = jj[t] < 0 ? 0 : jj[t];
         const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
 #pragma unroll
@@ -153,14 +154,14 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
       for (int l = 0; l < 3; ++l) {
         const f4* wl = Whid + l * LF;
         const f4* wn = (l < 2) ? wl + LF : Whid;  // wrap: the next round starts again at hidden layer 0
-        dense_layer<256, 256, 2, 256>(ws, wl, wn, h, z, lane, true);
-        if (l < 2) activate<256, 2, ACT_RELU>(z, h);
+        dense_layer<256, 256, NT, 256>(ws, wl, wn, h, z, lane, true);
+        if (l < 2) activate<256, NT, ACT_RELU>(z, h);
       }
     } else {
       // split-precision hidden stack: activations travel as packed hi/lo halves, accumulators are fp32
-      unsigned xh[2][8][4], xl[2][8][4];
+      unsigned xh[NT][8][4], xl[NT][8][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int j = jj[t] < 0 ? 0 : jj[t];
         const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
 #pragma unroll
@@ -175,25 +176,25 @@ __global__ __launch_bounds__(256, 1) void k_dvis_fused(
       }
 #pragma unroll 1
       for (int l = 0; l < 3; ++l) {
-        if (l > 0) relu_split<256, 2>(z, w_unscale, xh, xl);
+        if (l > 0) relu_split<256, NT>(z, w_unscale, xh, xl);
 #pragma unroll
         for (int jb = 0; jb < 16; ++jb) {
-          f4 res[2];
+          f4 res[NT];
           ring.template chunk<CH>(xh, xl, res);
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[t][jb * 4 + r] = res[t][r];
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 64; ++i) z[t][i] = z[t][i] * w_unscale;
     }
     // 256 -> 2 head on the VALU: each lane owns 64 of the 256 activations of its sample
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       float l0 = 0.f, l1 = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {
@@ -254,23 +255,25 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                   int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
                   unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(precision >= 0 && precision <= 3, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
+  RB_REQUIRE(precision >= 0 && precision <= 4, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
-    hipLaunchKernelGGL((k_dvis_fused<false, 1>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
+    hipLaunchKernelGGL((k_dvis_fused<false, 1, 2>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
                        Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count);
   } else {
-#define RB_LAUNCH_H3(CH)                                                                                              \
-  hipLaunchKernelGGL((k_dvis_fused<true, CH>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
+#define RB_LAUNCH_H3(CH, NT)                                                                                          \
+  hipLaunchKernelGGL((k_dvis_fused<true, CH, NT>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
                      n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
                      ldexpf(1.0f, -scale_log2), vis_out, eval_count)
     if (precision == 1) {
-      RB_LAUNCH_H3(2);
+      RB_LAUNCH_H3(2, 2);
     } else if (precision == 2) {
-      RB_LAUNCH_H3(1);
+      RB_LAUNCH_H3(1, 2);
+    } else if (precision == 3) {
+      RB_LAUNCH_H3(3, 2);
     } else {
-      RB_LAUNCH_H3(3);
+      RB_LAUNCH_H3(2, 1);       // one tile per wave, two workgroups per CU
     }
 #undef RB_LAUNCH_H3
   }

@@ -21,9 +21,10 @@ from .nets import VisNetwork
 
 TINY_NUMBER = 1e-6
 # Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
-# chain); "f16x3" = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative error).
+# chain); "f16x3" (default) = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative error,
+# measured parity identical to "fp32": tests/test_sg_gpu.py runs both); "f16x3-nt2*" = register-blocking variants.
 import os as _os
-VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "fp32")
+VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3")
 
 
 # ----------------------------------------------------------------------------------------- small public helpers
