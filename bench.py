@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 VIS_MACS_PER_EVAL = 229376          # 126*256 + 3*256*256 + 256*2
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
 H = W = 800
 CHUNK = 1024
 
@@ -211,6 +212,22 @@ def main():
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
     if rank == 0:
+        h3 = precision.startswith("f16x3")
+        # peak of the pipe the dominant kernel runs on, per ALGORITHMIC flop: exact mode = dense f32-input MFMA;
+        # f16x3 = dense f16 MFMA (2.5 PFLOP/s) / 3 products per algorithmic multiply-add
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else PEAK_FP32_MFMA_TFLOPS
+        roofline = {"bound": "mfma", "kernel": "k_dvis_fused (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak,
+                    # HBM bytes per launch: 31 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
+                    # correction) + WRITE_SIZE on this kernel (profiles/r01_dvis_f16x3_pmc.md), scaled to this launch's pair
+                    # count: 0.3 % of the HBM roofline -- the bound is the matrix pipe
+                    "traffic": 31.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                    "precision": precision,
+                    "peak_note": ("dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)" if h3
+                                  else "dense f32-input MFMA"),
+                    "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                    "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
+                    "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
         line = {
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,17 +239,7 @@ def main():
                        "image": [H, W], "chunk": CHUNK, "chunks_per_pass": args.chunks_per_batch,
                        "hit_fraction": round(hit_frac, 4), "octree_build_s": round(build_s, 2),
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "parallelism": f"ray-shard x{world} (views)"},
-            "roofline": {"bound": "mfma", "kernel": "k_dvis_fused (light-SG visibility MLP)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         # HBM bytes per launch: 31 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE
-                         # (x2 gfx950 correction) + WRITE_SIZE on this kernel (profiles/r01_dvis_f16x3_pmc.md), scaled to
-                         # this launch's pair count; 0.3 % of the HBM roofline -- the bound is the matrix pipe
-                         "traffic": 31.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
-                         "precision": precision,
-                         "frac_of_f16x3_bound": (achieved / (2500.0 / 3.0)) if precision.startswith("f16x3") else None,
-                         "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
-                         "flops_per_eval": 2 * VIS_MACS_PER_EVAL},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline_chunks, uv, pose, K)

@@ -1,4 +1,4 @@
-// Wave-resident fp32 MLP engine for gfx950 (MI355X, CDNA4).
+// Wave-resident MLP engine for gfx950 (MI355X, CDNA4): exact-fp32 MFMA layers, and a split-precision (f16x3) variant.
 //
 // Every small MLP on RobIR's per-ray hot path (visibility, SDF, colour, indirect illumination, the sparse
 // auto-encoders) is evaluated "transposed":  H_out^T = W . H_in^T  with  v_mfma_f32_16x16x4_f32
@@ -152,8 +152,6 @@ __device__ __forceinline__ void dense_layer(WS& ws, const f4* __restrict__ wl, c
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int c = (NCH == 2) ? (kb & 1) : 0;
           acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], in[t][kb * 4 + r], acc[t][c], 0, 0, 0);
         }
@@ -182,23 +180,6 @@ __device__ __forceinline__ void activate(const float (&z)[NT][N / 4], float (&h)
     for (int i = 0; i < N / 4; ++i) h[t][i] = act_fn<ACT>(z[t][i]);
 }
 
-// Forward-mode tangent propagation through Softplus(beta=100): lanes are (value, d/dx, d/dy, d/dz) quads.
-// value lane: h = softplus(z); tangent lanes: h = z_t * softplus'(z_value), z_value broadcast inside the quad.
-template <int N, int NT>
-__device__ __forceinline__ void activate_softplus_jvp(const float (&z)[NT][N / 4], float (&h)[NT][N / 4], int lane,
-                                                      float scale) {
-  const bool is_val = (lane & 3) == 0;
-  const int src = lane & ~3;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < N / 4; ++i) {
-      float zv = __shfl(z[t][i], src);
-      float v = is_val ? act_fn<ACT_SOFTPLUS100>(zv) : z[t][i] * softplus100_grad(zv);
-      h[t][i] = v * scale;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Split-precision ("f16x3") dense layer: fp32 operands are carried as hi + lo half pairs,
 //   x*w ~= xh*wh + xh*wl + xl*wh        (dropped xl*wl term ~ 2^-22 relative; products exact, fp32 accumulate)
@@ -224,66 +205,7 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, uns
 }
 
 // Operands are kept as 32-bit registers (two halves each): x[t][kb][q], q = 0..3 <-> half slots 2q, 2q+1.
-// The layer writes raw fp32 accumulators (still scaled by 2^s) to out: they live in the accumulator half of the
-// register file while the packed operands live in the VGPR half; relu_split() turns them into the next operands.
-template <int K, int N, int NT, int NEXTK, class WS>
-__device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl, const f4* __restrict__ wnext,
-                                               const unsigned (&in_hi)[NT][K / 32][4],
-                                               const unsigned (&in_lo)[NT][K / 32][4], float (&out)[NT][N / 4],
-                                               int lane) {
-  constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
-  const int g = lane >> 4;
-#pragma unroll
-  for (int jb = 0; jb < NJB; ++jb) {
-    if (jb + 1 < NJB) {
-      ws.template prefetch<CF4>(wl + (jb + 1) * CF4);
-    } else {
-      if constexpr (NCF4 > 0) ws.template prefetch<NCF4>(wnext);
-    }
-    const f4* cw = ws.chunk();
-    const u4* ch = reinterpret_cast<const u4*>(cw + 4);
-    f4 acc_m[NT], acc_c[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc_m[t] = cw[g];
-      acc_c[t] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    // all weight operands of the chunk are fetched from LDS up front (2*KB ds_read_b128 in flight): a one-ahead
-    // fetch leaves the matrix pipe idle for an LDS round trip after every 6 MFMAs (measured: 2.2x slower)
-    u4 wreg[2 * KB];
-#pragma unroll
-    for (int i = 0; i < 2 * KB; ++i) wreg[i] = ch[i * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const h8 wh = __builtin_bit_cast(h8, wreg[kb * 2]);
-      const h8 wlo = __builtin_bit_cast(h8, wreg[kb * 2 + 1]);
-      h8 xh[NT], xl[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        xh[t] = __builtin_bit_cast(h8, u4{in_hi[t][kb][0], in_hi[t][kb][1], in_hi[t][kb][2], in_hi[t][kb][3]});
-        xl[t] = __builtin_bit_cast(h8, u4{in_lo[t][kb][0], in_lo[t][kb][1], in_lo[t][kb][2], in_lo[t][kb][3]});
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc_m[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc_m[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc_c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[t], acc_c[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc_c[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, xh[t], acc_c[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f4 a = acc_m[t] + acc_c[t];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) out[t][jb * 4 + r] = a[r];
-    }
-    if (jb + 1 < NJB) {
-      ws.template commit<CF4>();
-    } else {
-      ws.template commit<NCF4>();
-    }
-  }
-}
+// The layer itself is H3Ring::chunk below (software-pipelined weight ring).
 
 // relu(z * unscale) of a whole layer (C layout, N neurons) -> packed hi/lo operands of the next layer:
 // output block jb = 2kb + e, reg r  ->  k-block kb, 32-bit register 2e + r/2.

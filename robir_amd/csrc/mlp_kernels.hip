@@ -49,7 +49,7 @@ __global__ void k_pack_layer(const float* __restrict__ W, const float* __restric
   }
 }
 
-// f16x3 packing (mlp_engine.h, dense_layer_h3): chunk jb = [bias*2^s (16 floats)] ++ [kb][hi|lo][lane][8 halves],
+// f16x3 packing (mlp_engine.h, H3Ring): chunk jb = [bias*2^s (16 floats)] ++ [kb][hi|lo][lane][8 halves],
 // half slot (lane, j) = W[16jb + (lane&15)][32kb + (j<4 ? 4g+j : 16+4g+j-4)] * 2^s, g = lane>>4.
 __global__ void k_pack_layer_h3(const float* __restrict__ W, const float* __restrict__ b, int n_out, int k_in,
                                 int n_pad, int k_pad, float scale, float* __restrict__ out) {
