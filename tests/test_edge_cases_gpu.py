@@ -1,0 +1,91 @@
+"""Edge cases on the GPU: empty inputs, all-miss chunks, ragged batches, degenerate rays (NaN propagation like the
+reference's IEEE 0*inf in intersect_box)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from robir_amd import renderer
+    return renderer.build_synthetic_model(dev)
+
+
+def test_empty_inputs(dev, model):
+    from robir_amd import ops, sg_render
+    z3 = torch.zeros(0, 3, device=dev)
+    assert model.implicit_network(z3).numel() == 0
+    assert model.implicit_network.gradient(z3).numel() == 0
+    assert model.visibility_network(z3, z3).shape == (0, 2)
+    assert model.implicit_network.batch_borrow_color(z3, z3).shape == (0, 3)
+    x, hit, t = model.ray_tracer.sdf_octree.cast_full(z3, z3)
+    assert x.shape == (0, 3) and hit.numel() == 0
+
+
+def test_all_miss_chunk_and_ragged_batch(dev, model):
+    """Rays looking away from the object: no hits -> every per-ray output keeps its prefill of 1.0; a batch whose size
+    is not a multiple of the chunk (2500 rays, chunk 1024) renders like its three chunks rendered separately."""
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(64, 64)
+    pose_away = pose.copy()
+    pose_away[:3, :3] = np.diag([1, 1, -1]).astype(np.float32) @ pose[:3, :3]      # look along +z, away from the origin
+    hdr = torch.full((1024, 1), 0.5, device=dev)
+    out = model.render_chunks(torch.from_numpy(uv[:1024]).to(dev), torch.from_numpy(pose_away).to(dev),
+                              torch.from_numpy(K).to(dev), hdr)
+    assert int(out["network_object_mask"].sum()) == 0
+    for k in ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "metallic", "vis_shadow"):
+        assert float(out[k].min()) == 1.0 and float(out[k].max()) == 1.0, k
+    # ragged: 2500 rays
+    uv_d = torch.from_numpy(uv[1024:3524]).to(dev)
+    pose_d, K_d = torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    hdr = torch.full((2500, 1), 0.5, device=dev)
+    big = model.render_chunks(uv_d, pose_d, K_d, hdr, trainstage="Illum", draws={})
+    for i, (a, b) in enumerate(((0, 1024), (1024, 2048), (2048, 2500))):
+        one = model.render_chunks(uv_d[a:b], pose_d, K_d, hdr[a:b], trainstage="Illum", draws={})
+        assert bool((big["network_object_mask"][a:b] == one["network_object_mask"]).all()), i
+        assert rel_err(big["points"][a:b].cpu(), one["points"].cpu()) <= 1e-6
+
+
+def test_axis_parallel_rays_propagate_nan_like_reference(dev, oracle_octree):
+    """d.x = 0 and o.x on a cell boundary gives 0*inf = NaN in the slab test; torch.minimum/maximum propagate it and
+    the reference reports such rays as misses with NaN distance.  The HIP tracer must do the same (golden chunk 1 of the
+    64x64 view contains the x = 32 pixel column)."""
+    from robir_amd.octree_tracing import OctreeSDF
+    from robir_oracle import octree as ooct
+    od = OctreeSDF.from_host_tables(oracle_octree, dev, -1)
+    o = torch.tensor([[0.0, 0.0, 0.9]]).expand(64, 3).contiguous()
+    d = torch.zeros(64, 3)
+    d[:, 1] = torch.linspace(-0.3, 0.3, 64)
+    d[:, 2] = -1.0
+    d = d / d.norm(dim=-1, keepdim=True)                # d.x == 0 exactly
+    t_ref, hit_ref = ooct.cast(oracle_octree, o, d, -1)
+    x, hit, t = od.cast_full(o.to(dev), d.to(dev))
+    assert bool((hit.cpu() == hit_ref).all())
+    assert bool((torch.isnan(t.cpu()) == torch.isnan(t_ref)).all())
+    assert rel_err(t.cpu(), t_ref) <= 1e-6
+
+
+def test_secondary_all_miss_and_octree_vis_model(dev, model):
+    from robir_amd.octree_tracing import OctreeVisModel, OctreeTracing
+    tr = OctreeTracing(max_iter=32)
+    tr.sdf_octree = type(model.ray_tracer.sdf_octree)(model.ray_tracer.sdf_octree.tables, 32)
+    vm = OctreeVisModel(tr)
+    p = torch.tensor([[0.0, 0.0, 0.6]], device=dev).expand(100, 3).contiguous()
+    d = torch.tensor([[0.0, 0.1, 1.0]], device=dev).expand(100, 3).contiguous()
+    d = d / d.norm(dim=-1, keepdim=True)
+    v = vm(p, d)                                        # pointing away: nothing hit -> [0, 1]
+    assert v.shape == (100, 2) and float(v[:, 0].max()) == 0.0 and float(v[:, 1].min()) == 1.0
+    # towards the object, off the cell-boundary planes (an exactly axis-parallel ray through x = y = 0 is the NaN case above)
+    p2 = torch.tensor([[0.013, 0.021, 0.6]], device=dev).expand(100, 3).contiguous()
+    d2 = -p2 / p2.norm(dim=-1, keepdim=True)
+    v2 = vm(p2, d2.contiguous())
+    assert float(v2[:, 0].min()) == 1.0 and float(v2[:, 1].max()) == 0.0
