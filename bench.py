@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--chunks-per-batch", type=int, default=125, help="1024-pixel chunks rendered per kernel pass")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3", "f16x3-nt2"],
+    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
     return ap.parse_args()

@@ -235,7 +235,7 @@ __device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float un
 // so neither the L2 latency of the weight stream, nor the LDS write/read round trip, nor the barrier sit between the
 // last MFMA of one chunk and the first MFMA of the next (PMC before: matrix pipe 37 % busy, 37 % parked in waits).
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, int NCHUNK>
+template <int NT, int NCHUNK, bool DMA = false>
 struct H3Ring {
   static constexpr int K = 256, KB = K / 32, CF4 = chunk_f4(K);
   static constexpr int NST = (CF4 + WG_THREADS - 1) / WG_THREADS;
@@ -257,6 +257,21 @@ struct H3Ring {
 #pragma unroll
     for (int i = 0; i < NST; ++i) stage[i] = src[elem(i)];
   }
+  // DMA variant: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, 1 KiB per wave
+  // instruction), no staging registers and no ds_write.  Completion is tracked with counted s_waitcnt vmcnt by hand.
+  static constexpr int NDMA = CF4 / WG_THREADS;          // full passes (4); the 4-float4 tail is copied by wave 0
+  __device__ __forceinline__ void dma_chunk(int chunk, int s) {
+    const f4* src = W + (long)chunk * CF4;
+    f4* dst = lds + s * CF4;
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * WG_THREADS + tid),
+                                       (__attribute__((address_space(3))) void*)(dst + i * WG_THREADS + wave * 64), 16, 0, 0);
+    if (tid < CF4 - NDMA * WG_THREADS)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + NDMA * WG_THREADS + tid),
+                                       (__attribute__((address_space(3))) void*)(dst + NDMA * WG_THREADS), 16, 0, 0);
+  }
   __device__ __forceinline__ void store_stage(int s) {
 #pragma unroll
     for (int i = 0; i < NST; ++i) lds[s * CF4 + elem(i)] = stage[i];
@@ -276,10 +291,17 @@ struct H3Ring {
     g = lane >> 4;
     c = 0;
     slot = 0;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    load_stage(1 % NCHUNK);
+    if constexpr (DMA) {
+      dma_chunk(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      dma_chunk(1 % NCHUNK, 1);
+    } else {
+      load_stage(0);
+      store_stage(0);
+      __syncthreads();
+      load_stage(1 % NCHUNK);
+    }
     bias = lds[g];
     read_w(0, 0, 2 * KB);
   }
@@ -319,8 +341,12 @@ struct H3Ring {
     for (int kb = 0; kb < KB / 2; ++kb) mfma_kb(kb);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2: stage chunk c+1 into its ring slot, start fetching chunk c+2
-    store_stage(nslot);
-    load_stage(c2);
+    if constexpr (DMA) {
+      dma_chunk(c2, nslot == 2 ? 0 : nslot + 1);   // slot of chunk c+2 == slot of chunk c-1: no wave still reads it
+    } else {
+      store_stage(nslot);
+      load_stage(c2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 3: third quarter
 #pragma unroll
@@ -328,7 +354,12 @@ struct H3Ring {
     __builtin_amdgcn_sched_barrier(0);
     // raw barrier: only the LDS writes must have landed; the global loads of chunk c+2 stay in flight across it
     // (__syncthreads() would add s_waitcnt vmcnt(0) and expose the L2 latency every chunk)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (DMA) {
+      // chunk c+1's DMA (issued one chunk ago) must have landed; chunk c+2's (NDMA, +1 in wave 0) may stay in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);

@@ -74,7 +74,7 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
 
 constexpr int DV_MAX_DIRS = 4096;
 
-template <bool H3, int CH, int NT>
+template <bool H3, int CH, int NT, bool DMA = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
   if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
 
   WStream<256> ws;
-  H3Ring<NT, 48> ring;
+  H3Ring<NT, 48, DMA> ring;
   constexpr long LF = (long)16 * chunk_f4(256);
   const float b0 = blast[0], b1 = blast[1];
   constexpr int RS = 64 * NT;   // samples per workgroup round
@@ -226,6 +226,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
       }
     }
   }
+  // drain the weight ring (the LDS-DMA variant still has chunks in flight that target this workgroup's LDS)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < L) {
     const float* w = wdir + dbase + (long)tid * nsamp;
@@ -255,15 +257,15 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                   int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
                   unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(precision >= 0 && precision <= 4, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
+  RB_REQUIRE(precision >= 0 && precision <= 5, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
     hipLaunchKernelGGL((k_dvis_fused<false, 1, 2>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
                        Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count);
   } else {
-#define RB_LAUNCH_H3(CH, NT)                                                                                          \
-  hipLaunchKernelGGL((k_dvis_fused<true, CH, NT>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
+#define RB_LAUNCH_H3(CH, NT, ...)                                                                                     \
+  hipLaunchKernelGGL((k_dvis_fused<true, CH, NT, ##__VA_ARGS__>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
                      n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
                      ldexpf(1.0f, -scale_log2), vis_out, eval_count)
     if (precision == 1) {
@@ -272,8 +274,10 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
       RB_LAUNCH_H3(1, 2);
     } else if (precision == 3) {
       RB_LAUNCH_H3(3, 2);
-    } else {
+    } else if (precision == 4) {
       RB_LAUNCH_H3(2, 1);       // one tile per wave, two workgroups per CU
+    } else {
+      RB_LAUNCH_H3(2, 1, true); // same, weights staged by LDS-DMA (global_load_lds)
     }
 #undef RB_LAUNCH_H3
   }

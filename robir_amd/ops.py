@@ -156,9 +156,11 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     normals = _f32(normals)
     h3 = precision.startswith("f16x3")
     assert h3 or precision == "fp32", precision
-    # "f16x3" = one 16-sample tile per wave, two workgroups per CU (measured fastest); "-nt2*" = two tiles per wave,
-    # one workgroup per CU, with 2 / 1 / 3 accumulator chains per tile
-    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-nt2-1chain": 2, "f16x3-nt2-3chain": 3, "f16x3": 4}[precision]
+    # "f16x3" = one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA (measured fastest);
+    # "f16x3-regstage" = same with global->VGPR->LDS staging; "-nt2*" = two tiles per wave, one workgroup per CU,
+    # with 2 / 1 / 3 accumulator chains per tile
+    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-nt2-1chain": 2, "f16x3-nt2-3chain": 3, "f16x3-regstage": 4,
+            "f16x3": 5}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
