@@ -195,6 +195,17 @@ int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv,
 int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,
                     float* pts, rb_stream_t stream);
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream);
+/* Element-wise heads of the hooks / networks:
+ * rb_material_decode: EnvmapMaterialNetwork outputs from the spec-AE's [n,5] (model/sg_envmap_material.py:205-211);
+ * rb_abs_scale: y = (take_abs ? |x| : x)*s (implicit_differentiable_renderer.py:220 abs; training/train_pbr.py:365 `* 2 pi`);
+ * rb_softmax2: torch.softmax(logits[n,2], -1)[..., which];
+ * rb_lin_diff_combine: diffuse*albedo/pi + specular on [n,3] (training/train_cesr.py:523-524). */
+int rb_material_decode(const float* brdf, const float* brdf_r, long n, float* albedo, float* rough, float* metal,
+                       float* albedo_r, float* rough_r, float* metal_r, rb_stream_t stream);
+int rb_abs_scale(const float* x, long n, float s, int take_abs, float* y, rb_stream_t stream);
+int rb_softmax2(const float* logits, long n, int which, float* p, rb_stream_t stream);
+int rb_lin_diff_combine(const float* diffuse, const float* albedo, const float* spec, long n, float* rgb,
+                        rb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Secondary rays / NeuS compositing -- IDRNetwork.trace_radiance (implicit_differentiable_renderer.py:566-650),

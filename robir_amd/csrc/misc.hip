@@ -164,6 +164,48 @@ __global__ void k_trace_integrate(const float* __restrict__ rad, const float* __
   for (int c = 0; c < 3; ++c) out[3 * i + c] = acc[c] / den;
 }
 
+// EnvmapMaterialNetwork head (sg_envmap_material.py:205-211): brdf / brdf_r [n,5] (sigmoid outputs of the spec AE) ->
+// albedo [n,3], roughness [n,1] = b3*0.9+0.09, metallic [n,1] = b4*0.99+0.01, and the random_xi_* twins
+// (random_xi_metallic is NOT rescaled in the reference).
+__global__ void k_material_decode(const float* __restrict__ brdf, const float* __restrict__ brdf_r, long n,
+                                  float* __restrict__ albedo, float* __restrict__ rough, float* __restrict__ metal,
+                                  float* __restrict__ albedo_r, float* __restrict__ rough_r, float* __restrict__ metal_r) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    albedo[3 * i + c] = brdf[5 * i + c];
+    albedo_r[3 * i + c] = brdf_r[5 * i + c];
+  }
+  rough[i] = brdf[5 * i + 3] * 0.9f + 0.09f;
+  metal[i] = brdf[5 * i + 4] * 0.99f + 0.01f;
+  rough_r[i] = brdf_r[5 * i + 3] * 0.9f + 0.09f;
+  metal_r[i] = brdf_r[5 * i + 4];
+}
+
+// y = (take_abs ? |x| : x) * s   (IndirctIllumNetwork: env_int = abs(...), implicit_differentiable_renderer.py:220; hooks: * 2 pi)
+__global__ void k_abs_scale(const float* __restrict__ x, long n, float s, int take_abs, float* __restrict__ y) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (take_abs ? fabsf(x[i]) : x[i]) * s;
+}
+
+// softmax over pairs of logits, component `which` (torch.softmax(x, -1)[..., which])
+__global__ void k_softmax2(const float* __restrict__ logits, long n, int which, float* __restrict__ p) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float l0 = logits[2 * i], l1 = logits[2 * i + 1];
+  const float mx = fmaxf(l0, l1);
+  const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+  p[i] = (which ? e1 : e0) / (e0 + e1);
+}
+
+// CESR recombination (training/train_cesr.py:523-524): rgb = diffuse * albedo / pi + specular, rows of 3
+__global__ void k_lin_diff_combine(const float* __restrict__ diffuse, const float* __restrict__ albedo,
+                                   const float* __restrict__ spec, long n3, float* __restrict__ rgb) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n3) rgb[i] = diffuse[i] * albedo[i] / (float)3.14159265358979323846 + spec[i];
+}
+
 }  // namespace rb
 
 using namespace rb;
@@ -228,6 +270,38 @@ int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char*
   RB_REQUIRE(rad && cosw && back && out, "null pointer");
   hipLaunchKernelGGL(k_trace_integrate, grid1d(n, 128), dim3(128), 0, (hipStream_t)stream, rad, cosw, back, n, nsamp, out);
   return check_launch("k_trace_integrate");
+}
+
+int rb_material_decode(const float* brdf, const float* brdf_r, long n, float* albedo, float* rough, float* metal,
+                       float* albedo_r, float* rough_r, float* metal_r, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(brdf && brdf_r && albedo && rough && metal && albedo_r && rough_r && metal_r, "null pointer");
+  hipLaunchKernelGGL(k_material_decode, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, brdf, brdf_r, n, albedo, rough,
+                     metal, albedo_r, rough_r, metal_r);
+  return check_launch("k_material_decode");
+}
+
+int rb_abs_scale(const float* x, long n, float s, int take_abs, float* y, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(x && y, "null pointer");
+  hipLaunchKernelGGL(k_abs_scale, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, x, n, s, take_abs, y);
+  return check_launch("k_abs_scale");
+}
+
+int rb_softmax2(const float* logits, long n, int which, float* p, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(logits && p && (which == 0 || which == 1), "bad arguments");
+  hipLaunchKernelGGL(k_softmax2, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, logits, n, which, p);
+  return check_launch("k_softmax2");
+}
+
+int rb_lin_diff_combine(const float* diffuse, const float* albedo, const float* spec, long n, float* rgb,
+                        rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(diffuse && albedo && spec && rgb, "null pointer");
+  hipLaunchKernelGGL(k_lin_diff_combine, grid1d(3 * n, 256), dim3(256), 0, (hipStream_t)stream, diffuse, albedo, spec,
+                     3 * n, rgb);
+  return check_launch("k_lin_diff_combine");
 }
 
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream) {

@@ -193,7 +193,7 @@ class IndirctIllumNetwork(nn.Module):
             noise = torch.randn(n, 64, device=dev)
         Xn = ops.axpy(X, noise.float().contiguous(), 0.02)
         _, second = self.integral_layer.run(X, X_noisy=Xn, need_first=False)
-        return sgs, second.abs()
+        return sgs, ops.abs_scale(second, 1.0)
 
 
 # ----------------------------------------------------------------------------------------- materials + light
@@ -250,16 +250,17 @@ class EnvmapMaterialNetwork(nn.Module):
         if train_norm:
             return {"sg_normal_map": normal_map, "random_xi_normal": random_xi_normal}
         lgtSGs = self.restrict_lobes_upper(self.lgtSGs) if self.upper_hemi else self.lgtSGs
+        alb, rough, metal, alb_r, rough_r, metal_r = ops.material_decode(brdf, brdf_r)
         return {
             "sg_lgtSGs": lgtSGs,
             "sg_specular_reflectance": self.specular_reflectance,
-            "sg_roughness": brdf[..., 3:4] * 0.9 + 0.09,
-            "sg_metallic": brdf[..., 4:5] * 0.99 + 0.01,
+            "sg_roughness": rough,
+            "sg_metallic": metal,
             "sg_normal_map": normal_map,
-            "sg_diffuse_albedo": brdf[..., :3],
-            "random_xi_roughness": brdf_r[..., 3:4] * 0.9 + 0.09,
-            "random_xi_metallic": brdf_r[..., 4:5],
-            "random_xi_diffuse_albedo": brdf_r[..., :3],
+            "sg_diffuse_albedo": alb,
+            "random_xi_roughness": rough_r,
+            "random_xi_metallic": metal_r,
+            "random_xi_diffuse_albedo": alb_r,
             "random_xi_normal": random_xi_normal,
         }
 

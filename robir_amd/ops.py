@@ -375,3 +375,35 @@ def cesr_net(X, M, kind, blob, n_label=1):
     Y = torch.empty(M, n_out, dtype=torch.float32, device=X.device)
     call("rb_cesr_net", ptr(_f32(X)), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), stream_ptr())
     return Y
+
+
+def material_decode(brdf, brdf_r):
+    brdf, brdf_r = _f32(brdf), _f32(brdf_r)
+    n, dev = brdf.shape[0], brdf.device
+    mk = lambda c: torch.empty(n, c, dtype=torch.float32, device=dev)
+    alb, rough, metal, alb_r, rough_r, metal_r = mk(3), mk(1), mk(1), mk(3), mk(1), mk(1)
+    call("rb_material_decode", ptr(brdf), ptr(brdf_r), c_long(n), ptr(alb), ptr(rough), ptr(metal), ptr(alb_r), ptr(rough_r),
+         ptr(metal_r), stream_ptr())
+    return alb, rough, metal, alb_r, rough_r, metal_r
+
+
+def abs_scale(x, s=1.0, take_abs=True):
+    x = _f32(x)
+    y = torch.empty_like(x)
+    call("rb_abs_scale", ptr(x), c_long(x.numel()), c_float(s), c_int(1 if take_abs else 0), ptr(y), stream_ptr())
+    return y
+
+
+def softmax2(logits, which=1):
+    logits = _f32(logits)
+    n = logits.shape[0]
+    p = torch.empty(n, dtype=torch.float32, device=logits.device)
+    call("rb_softmax2", ptr(logits), c_long(n), c_int(which), ptr(p), stream_ptr())
+    return p
+
+
+def lin_diff_combine(diffuse, albedo, spec):
+    diffuse, albedo, spec = _f32(diffuse), _f32(albedo), _f32(spec)
+    rgb = torch.empty_like(diffuse)
+    call("rb_lin_diff_combine", ptr(diffuse), ptr(albedo), ptr(spec), c_long(diffuse.shape[0]), ptr(rgb), stream_ptr())
+    return rgb

@@ -78,7 +78,7 @@ class IDRNetwork(nn.Module):
                                            noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
         shading_normal = normals if self.no_normal else mat["sg_normal_map"]
         ret = sg_render.render_with_all_sg(points=points, normal=shading_normal, viewdirs=vd, lgtSGs=mat["sg_lgtSGs"],
-                                           indir_integral=indir_integral * 2 * np.pi,
+                                           indir_integral=ops.abs_scale(indir_integral, 2 * np.pi, take_abs=False),
                                            specular_reflectance=mat["sg_specular_reflectance"].abs(),
                                            roughness=mat["sg_roughness"], diffuse_albedo=mat["sg_diffuse_albedo"],
                                            indir_lgtSGs=indir_lgtSGs, VisModel=self.visibility_network, fun_spec=False,
@@ -282,19 +282,19 @@ class CESRHook:
                                         noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
         Xp = ops.feat_pe10(points.float().contiguous())
         logits = self.shadow_net.eval_point_labels(Xp, 128)
-        diffuse_vis = torch.softmax(logits, -1)[..., 1]
+        diffuse_vis = ops.softmax2(logits, 1)
         normal_new = ops.normalize3(ops.cesr_net(Xp, Xp.shape[0], 0, self.normal_net.packed()), 1e-4, 1)
         albedo = mat["sg_diffuse_albedo"]
         ret = sg_render.render_with_all_sg(points=points, normal=normal_new if self.cur_iter > 1000 else mat["sg_normal_map"],
-                                           viewdirs=vd, lgtSGs=mat["sg_lgtSGs"], indir_integral=indir_integral * 2 * np.pi,
+                                           viewdirs=vd, lgtSGs=mat["sg_lgtSGs"], indir_integral=ops.abs_scale(indir_integral, 2 * np.pi, take_abs=False),
                                            specular_reflectance=mat["sg_specular_reflectance"].abs(),
                                            roughness=mat["sg_roughness"], diffuse_albedo=albedo,
                                            indir_lgtSGs=indir_lgtSGs, VisModel=m.visibility_network, fun_spec=False,
                                            lin_diff=True, testing=not self.is_training, metallic=None,
                                            diffuse_vis=diffuse_vis, prefit=self.prefit, argmax_vis=self.argmax_vis,
                                            draws=draws, chunk_id=chunk_id, n_chunks=n_chunks, stats=stats)
-        ret["sg_rgb"] = ret["sg_diffuse_rgb"] * albedo / np.pi + ret["sg_specular_rgb"]
-        ret["indir_rgb"] = ret["indir_diffuse_rgb"] * albedo / np.pi + ret["indir_specular_rgb"]
+        ret["sg_rgb"] = ops.lin_diff_combine(ret["sg_diffuse_rgb"], albedo, ret["sg_specular_rgb"])
+        ret["indir_rgb"] = ops.lin_diff_combine(ret["indir_diffuse_rgb"], albedo, ret["indir_specular_rgb"])
         supervise = ret["supervise"] + ((mat["sg_normal_map"] - normal_new) ** 2).mean()
         ret.update({"normals": normals, "diffuse_albedo": albedo, "roughness": mat["sg_roughness"],
                     "metallic": mat["sg_metallic"], "normal_map": normal_new, "gradient_error": supervise,
