@@ -326,13 +326,16 @@ struct H3Ring {
         a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
         b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
       }
-      constexpr int IA = CH >= 2 ? 1 : 0, IB = CH >= 3 ? 2 : IA;
+      // accumulator of each product: CH 1: all -> 0; 2: {0,1,1}; 3: {0,1,2}
+      constexpr int i0 = 0, ia = (CH >= 2 ? 1 : 0), ib = (CH >= 3 ? 2 : (CH >= 2 ? 1 : 0));
+      // issue order hi*lo, hi*hi, lo*hi: with two chains the two correction products (same accumulator) are never
+      // back to back, also when a wave owns a single tile
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t][0], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t][ia] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][ia], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][IA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][IA], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t][i0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t][i0], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][IB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t][IB], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t][ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t][ib], 0, 0, 0);
     };
     const int nslot = slot == 2 ? 0 : slot + 1;
     const int c2 = (c + 2) % NCHUNK;

@@ -277,7 +277,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
     } else if (precision == 4) {
       RB_LAUNCH_H3(2, 1);       // one tile per wave, two workgroups per CU
     } else {
-      RB_LAUNCH_H3(2, 1, true); // same, weights staged by LDS-DMA (global_load_lds)
+      RB_LAUNCH_H3(2, 1, true); // same, weights staged by LDS-DMA (global_load_lds); more accumulator chains spill here
     }
 #undef RB_LAUNCH_H3
   }

@@ -33,7 +33,7 @@ g = torch.Generator(device=dev).manual_seed(1)
 u = torch.rand(2, n_chunks, 128, 32, device=dev, generator=g)
 if prec == "variants":
     import itertools
-    names = ["f16x3", "f16x3-regstage", "f16x3-nt2", "fp32"]
+    names = ["f16x3", "f16x3-regstage", "f16x3-nt2"]
     times = {k: [] for k in names}
     for rep in range(4):
         for k in names:
