@@ -261,6 +261,28 @@ int rb_surface_points(const float* p, const float* dir, const float* tk, long m,
 int rb_surface_finish(const float* sdf, const float* grad, const float* xs, const float* p, const float* pred_n, long m,
                       int ns, float s, float* x_out, float* n_out, float* gerr, rb_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * IDR sphere tracer (the use_octree=False ray tracer) -- RayTracing.forward / sphere_tracing / ray_sampler / secant in
+ * eval mode (model/ray_tracing.py:26-297; get_sphere_intersection, utils/rend_util.py:141-163).  The host alternates
+ * these per-ray state updates with rb_sdf_mlp (mode 0) on pts[2N,3] (start points, then end points).
+ * state_f[6N] = acc_s, acc_e, cur_s, cur_e, nxt_s, nxt_e; state_b[4N] = un_s, un_e, bad_s, bad_e; ctrl int32[2]
+ * (zero before op 0).  cam_stride 0 = one camera centre cam[3], 3 = one origin per ray cam[N,3].
+ * op: 0 init (param = squared bounding-sphere radius) | 1 / 2 take sdf2[2N] for the unfinished / the
+ * line-search rows | 3 loop top (param = sdf threshold) | 4 step | 5 back-step (param = (1-line_search_step)/2^k) |
+ * 6 close iteration.  After the loop: hit = acc_s < acc_e, dist = acc_s, points = pts[:N]; rays with un_s set go
+ * through the sampler: rb_raytrace_samples (z[m,n], P[m*n,3]), rb_sdf_mlp, rb_raytrace_pick (first negative sample,
+ * minimal-SDF fallback for rays without surface, bracket[4m] = z_lo, z_hi, sdf_lo, sdf_hi), then n_rootfind_steps x
+ * (rb_raytrace_secant, rb_sdf_mlp on pmid).
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_raytrace_step(int op, const float* cam, int cam_stride, const float* dirs, long N, float param, const float* sdf2, float* state_f,
+                     unsigned char* state_b, float* pts, int* ctrl, rb_stream_t stream);
+int rb_raytrace_samples(const float* cam, int cam_stride, const float* dirs, const float* lo, const float* hi, const float* lin, long m,
+                        int n_steps, float* z, float* P, rb_stream_t stream);
+int rb_raytrace_pick(const float* sdf, const float* z, const float* P, const unsigned char* obj, long m, int n,
+                     float* out_pts, float* out_dist, unsigned char* out_hit, float* bracket, rb_stream_t stream);
+int rb_raytrace_secant(const float* cam, int cam_stride, const float* dirs, const unsigned char* on, const float* smid, long m, int phase,
+                       float* bracket, float* zp, float* pmid, rb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ _spec = importlib.util.spec_from_file_location("robir_synth", os.path.join(ROOT,
 synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 import robir_oracle as O  # noqa: E402
-from robir_oracle import nets as on, sg as osg, neus as oneus, octree as ooct, renderer as orend  # noqa: E402
+from robir_oracle import nets as on, sg as osg, neus as oneus, octree as ooct, renderer as orend, raytracing as ort  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
@@ -335,6 +335,26 @@ def main():
         save("forward_material_c1", weights=wsum, H=H, W=W, chunk=c, n_hit=n_hit, diffuse_vis_evals=nev,
              hdr_shift=hdr_in, **{"draw_" + k: v for k, v in dr.items()},
              **{"out_" + k: ref[k].detach() for k in ref if isinstance(ref[k], torch.Tensor)})
+
+        # ------------------------------------------------------------------ IDR sphere tracer (use_octree=False), chunk 1
+        from model.ray_tracing import RayTracing
+        rt_conf = ref_shim.hotdog_model_conf().get_config("ray_tracer")
+        rt = RayTracing(**{k: rt_conf[k] for k in rt_conf.keys()})
+        rt.eval()
+        sl = slice(1024, 2048)
+        # a bounding sphere that some rays miss, so every branch is exercised (r = 0.45 instead of the conf's 1.0)
+        for tag, radius in (("r1", 1.0), ("r045", 0.45)):
+            rt.object_bounding_sphere = radius
+            t0 = time.time()
+            rx, rh, rd_ = rt(sdf=sdf_fn, cam_loc=cl, object_mask=obj_mask[0, sl], ray_directions=rd[:, sl])
+            t_ref = time.time() - t0
+            ox, oh, od_ = ort.trace(lambda x: on.implicit_forward(sd, x)[:, 0], cl[0], rd[0, sl], obj_mask[0, sl], r=radius)
+            both = rh & oh
+            report("raytracing_" + tag, ref_s=t_ref, hits=int(rh.sum()), hit_mismatch=int((rh != oh).sum()),
+                   dist=relerr(od_[both], rd_.detach()[both]), pts=relerr(ox[both], rx.detach()[both]),
+                   miss_dist=relerr(od_[~rh & ~oh], rd_.detach()[~rh & ~oh]))
+            save("raytracing_" + tag, weights=wsum, radius=radius, cam=cl[0], dirs=rd[0, sl], points=rx.detach(), hit=rh,
+                 dist=rd_.detach())
 
         # ------------------------------------------------------------------ CESR hook (shadow_net / normal_net), chunk 1
         from training.train_cesr import ClusteredAlbedoTrainRunner

@@ -12,4 +12,4 @@ Pinning: the reference has no tests or golden vectors of its own (SURVEY.md sect
 oracle is pinned against outputs of the reference itself, recorded in this container by
 oracle/gen_golden.py into tests/golden/*.npz, and re-checked by tests/test_oracle_golden.py.
 """
-from . import encoding, nets, neus, octree, sg, renderer  # noqa: F401
+from . import encoding, nets, neus, octree, sg, renderer, raytracing  # noqa: F401

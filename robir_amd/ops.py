@@ -407,3 +407,54 @@ def lin_diff_combine(diffuse, albedo, spec):
     rgb = torch.empty_like(diffuse)
     call("rb_lin_diff_combine", ptr(diffuse), ptr(albedo), ptr(spec), c_long(diffuse.shape[0]), ptr(rgb), stream_ptr())
     return rgb
+
+
+# ---- IDR sphere tracer (use_octree=False) -----------------------------------------------------------------------------
+class RayTraceState:
+    """Device state of rb_raytrace_step for N rays (layout in include/robir_hip.h)."""
+
+    def __init__(self, cam, dirs):
+        self.cam, self.dirs = _f32(cam).reshape(-1, 3), _f32(dirs)
+        self.N = N = self.dirs.shape[0]
+        assert self.cam.shape[0] in (1, N)
+        self.cs = 0 if self.cam.shape[0] == 1 else 3
+        dev = dirs.device
+        self.f = torch.zeros(6, N, dtype=torch.float32, device=dev)
+        self.b = torch.zeros(4, N, dtype=torch.uint8, device=dev)
+        self.pts = torch.zeros(2 * N, 3, dtype=torch.float32, device=dev)
+        self.ctrl = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    def step(self, op, param=0.0, sdf2=None):
+        s = _f32(sdf2) if sdf2 is not None else None
+        call("rb_raytrace_step", c_int(op), ptr(self.cam), c_int(self.cs), ptr(self.dirs), c_long(self.N), c_float(param),
+             ptr(s), ptr(self.f), ptr(self.b), ptr(self.pts), ptr(self.ctrl), stream_ptr())
+
+
+def raytrace_samples(cam, dirs, lo, hi, lin):
+    cam, dirs, lo, hi, lin = _f32(cam).reshape(-1, 3), _f32(dirs), _f32(lo), _f32(hi), _f32(lin)
+    m, n = dirs.shape[0], lin.shape[0]
+    z = torch.empty(m, n, dtype=torch.float32, device=dirs.device)
+    P = torch.empty(m * n, 3, dtype=torch.float32, device=dirs.device)
+    call("rb_raytrace_samples", ptr(cam), c_int(0 if cam.shape[0] == 1 else 3), ptr(dirs), ptr(lo), ptr(hi), ptr(lin),
+         c_long(m), c_int(n), ptr(z), ptr(P), stream_ptr())
+    return z, P
+
+
+def raytrace_pick(sdf, z, P, obj):
+    m, n = z.shape
+    dev = z.device
+    obj = obj.to(torch.uint8).contiguous()
+    pts = torch.empty(m, 3, dtype=torch.float32, device=dev)
+    dist = torch.empty(m, dtype=torch.float32, device=dev)
+    hit = torch.empty(m, dtype=torch.uint8, device=dev)
+    bracket = torch.empty(4, m, dtype=torch.float32, device=dev)
+    call("rb_raytrace_pick", ptr(_f32(sdf)), ptr(z), ptr(P), ptr(obj), c_long(m), c_int(n), ptr(pts), ptr(dist), ptr(hit),
+         ptr(bracket), stream_ptr())
+    return pts, dist, hit, bracket
+
+
+def raytrace_secant(cam, dirs, on, smid, phase, bracket, zp, pmid):
+    cam = _f32(cam).reshape(-1, 3)
+    s = _f32(smid) if smid is not None else None
+    call("rb_raytrace_secant", ptr(cam), c_int(0 if cam.shape[0] == 1 else 3), ptr(dirs), ptr(on), ptr(s),
+         c_long(dirs.shape[0]), c_int(phase), ptr(bracket), ptr(zp), ptr(pmid), stream_ptr())

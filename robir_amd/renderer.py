@@ -23,6 +23,7 @@ import torch.nn as nn
 from . import ops, sg_render
 from .nets import (ImplicitNetworkMy, IndirctIllumNetwork, VisNetwork, EnvmapMaterialNetwork, GammaCorrect)
 from .octree_tracing import OctreeTracing
+from .ray_tracing import RayTracing
 
 TINY_NUMBER = 1e-6
 
@@ -40,9 +41,8 @@ class IDRNetwork(nn.Module):
         self.feature_vector_size = conf.get_int("feature_vector_size")
         rt = _cfg(conf, "ray_tracer")
         self.octree_ray_tracer = OctreeTracing(**rt, max_iter=32)
-        if not conf.get_bool("use_octree"):
-            raise NotImplementedError("use_octree=False (model/ray_tracing.py RayTracing) is a 'next' item (SURVEY 8f)")
-        self.ray_tracer = OctreeTracing(**rt)
+        self.use_octree = conf.get_bool("use_octree")
+        self.ray_tracer = OctreeTracing(**rt) if self.use_octree else RayTracing(**rt)
         self.object_bounding_sphere = conf.get_float("ray_tracer.object_bounding_sphere")
         self.implicit_network = ImplicitNetworkMy(self.feature_vector_size, **_cfg(conf, "implicit_network"))
         self.rendering_network = self.implicit_network.color
@@ -129,8 +129,12 @@ class IDRNetwork(nn.Module):
                 hit = torch.zeros(N, dtype=torch.bool, device=dev)
                 dist = torch.zeros(N, device=dev)
                 sel = object_mask.nonzero()[:, 0]
-                if sel.numel() > 0:
+                if sel.numel() > 0 and self.use_octree:
                     _, h, t = self.ray_tracer.sdf_octree.cast_full(origins[sel].contiguous(), dirs[sel].contiguous())
+                    hit[sel], dist[sel] = h, t
+                elif sel.numel() > 0:
+                    _, h, t = self.ray_tracer(sdf=self.implicit_network.sdf_only, cam_loc=origins[sel],
+                                              object_mask=object_mask[sel], ray_directions=dirs[sel][:, None, :])
                     hit[sel], dist[sel] = h, t
                 n_chunks = 1
                 points = ops.points_along(origins, dirs, dist)
@@ -143,7 +147,11 @@ class IDRNetwork(nn.Module):
         cam = pose[:3, 3].float().reshape(1, 3).contiguous()
         with torch.no_grad():
             dirs = ops.camera_rays(pose_h, K.detach().cpu().numpy(), uv.float().contiguous())
-            if chunk <= 1024:
+            if not self.use_octree:       # independent rays: the IDR tracer takes all chunks of the pass at once
+                _, hit, dist = self.ray_tracer(sdf=self.implicit_network.sdf_only, cam_loc=cam, object_mask=object_mask,
+                                               ray_directions=dirs[None])
+                n_chunks = (N + chunk - 1) // chunk
+            elif chunk <= 1024:
                 _, hit, dist = self.ray_tracer.sdf_octree.cast_chunks(cam, dirs, chunk=chunk)
                 n_chunks = (N + chunk - 1) // chunk
             else:
@@ -359,10 +367,10 @@ class DictConf:
         return self.d[k]
 
 
-def hotdog_conf():
+def hotdog_conf(use_octree=True):
     """model{} section of confs_sg/hotdog.conf:65-123 (truck.conf is identical in this section)."""
     return DictConf({
-        "gamma": 1.0, "hdr_mode": 0, "use_neus": True, "use_octree": True, "feature_vector_size": 256,
+        "gamma": 1.0, "hdr_mode": 0, "use_neus": True, "use_octree": use_octree, "feature_vector_size": 256,
         "implicit_network": {"d_in": 3, "d_out": 1, "dims": [512] * 8, "geometric_init": True, "bias": 0.6,
                              "skip_in": [4], "weight_norm": True, "multires": 6},
         "rendering_network": {"mode": "idr", "d_in": 9, "d_out": 3, "dims": [512] * 4, "weight_norm": True,
@@ -376,15 +384,19 @@ def hotdog_conf():
     })
 
 
-def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True):
+def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True, use_octree=True):
     """IDRNetwork with the synthetic weights of robir_amd.synth (the configuration tests and bench.py use)."""
     from . import synth
     sd = synth.synth_state_dict(seed, variance=variance, sharp_light=sharp_light)
-    model = IDRNetwork(hotdog_conf())
+    model = IDRNetwork(hotdog_conf(use_octree))
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not unexpected and not missing, (missing, unexpected)
     model = model.to(device).eval()
     if build_octrees:
-        model.ray_tracer.generate()
-        model.octree_ray_tracer.sdf_octree = type(model.ray_tracer.sdf_octree)(model.ray_tracer.sdf_octree.tables, 32)
+        if use_octree:
+            model.ray_tracer.generate()
+            tree = model.ray_tracer.sdf_octree
+            model.octree_ray_tracer.sdf_octree = type(tree)(tree.tables, 32)
+        else:                   # secondary rays (trace_radiance) always use the octree tracer, primary rays the IDR tracer
+            model.octree_ray_tracer.generate()
     return model
