@@ -29,7 +29,7 @@ class RayTracing(nn.Module):
 
     def bind(self, implicit_network):
         """Default SDF when forward() is called with sdf=None (mirrors OctreeTracing.bind)."""
-        self._bound = implicit_network
+        object.__setattr__(self, "_bound", implicit_network)       # not a submodule: no duplicate state-dict keys
 
     def generate(self, *a, **k):          # OctreeTracing API no-op so callers can treat both tracers alike
         return None

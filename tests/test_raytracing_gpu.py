@@ -88,17 +88,25 @@ def test_empty_and_all_miss(dev, implicit):
 
 
 def test_idr_network_with_ray_tracer(dev):
-    """IDRNetwork(use_octree=False): primary hits come from the IDR tracer and agree with the octree tracer's."""
+    """IDRNetwork(use_octree=False), chunk 1 of the 64x64 view: hits and surface points are the IDR tracer's
+    (golden raytracing_r1 is the reference's RayTracing on these rays), and a full Material forward runs on them."""
     from robir_amd import renderer, synth
-    m_rt = renderer.build_synthetic_model(dev, use_octree=False)
-    m_oc = renderer.build_synthetic_model(dev, use_octree=True)
+    from robir_amd.ray_tracing import RayTracing
+    m = renderer.build_synthetic_model(dev, use_octree=False)
+    assert isinstance(m.ray_tracer, RayTracing)
     uv, pose, K = synth.synth_camera(64, 64)
     sl = slice(1024, 2048)
     inp = {"uv": torch.from_numpy(uv[None, sl]).to(dev), "pose": torch.from_numpy(pose[None]).to(dev),
            "intrinsics": torch.from_numpy(K[None]).to(dev), "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev)}
-    a = m_rt(inp, trainstage="IDR")
-    b = m_oc(inp, trainstage="IDR")
-    ha, hb = a["network_object_mask"].cpu(), b["network_object_mask"].cpu()
-    assert float((ha != hb).float().mean()) <= 0.03           # silhouette pixels differ between the two tracers
-    both = ha & hb
-    assert bad_frac(a["points"].cpu()[both], b["points"].cpu()[both], 2e-3) <= 0.02
+    a = m(inp, trainstage="IDR")
+    g = load_golden("raytracing_r1")
+    hit, gh = a["network_object_mask"].cpu(), torch.from_numpy(g["hit"])
+    assert int((hit != gh).sum()) <= 1
+    both = (hit & gh).numpy()
+    assert bad_frac(a["points"].cpu()[both], g["points"][both], TOL) <= 0.005
+    n_hit = int(hit.sum())
+    dr = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(5, n_hit, chunk_id=1, nsamp_diffuse=8).items()}
+    inp["hdr_shift"] = torch.zeros(1024, 1, device=dev)
+    out = m(inp, trainstage="Material", train_spec=True, draws=dr)
+    assert out["sg_rgb"].shape == (1024, 3) and bool(torch.isfinite(out["sg_rgb"]).all())
+    assert float(out["sg_rgb"][hit.to(dev)].abs().mean()) > 0
