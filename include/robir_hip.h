@@ -124,6 +124,12 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
  *   minimum: the reference's batch-global sharpness.min()), dirs[n*nsamp,3], wts[n*nsamp], front[n*nsamp] (uint8).
  * rb_spec_vis_reduce: logits[n*nsamp,2] of the visibility MLP -> bvis[n]; inv: use softmax[...,0] (indirect pass).
  * ------------------------------------------------------------------------------------------------------------ */
+/* Second-generation kernel of the same stage (csrc/vis_diffuse_v2.hip): W49 = the three hidden layers and the 256->2 output
+ * layer (rows padded to 16) packed by rb_pack_layer_h3 back to back = 49 chunks; two sample tiles per wave, one workgroup
+ * per CU, output layer on the matrix pipe.  Same arguments and results (to fp32 rounding of the output layer). */
+int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                     const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                     float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 int rb_spec_vis_sample(const float* normal, const float* view, const float* rough, const int* chunk_id, long n,
                        int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
                        unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);

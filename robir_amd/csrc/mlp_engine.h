@@ -235,7 +235,7 @@ __device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float un
 // so neither the L2 latency of the weight stream, nor the LDS write/read round trip, nor the barrier sit between the
 // last MFMA of one chunk and the first MFMA of the next (PMC before: matrix pipe 37 % busy, 37 % parked in waits).
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, int NCHUNK, bool DMA = false>
+template <int NT, int NCHUNK, bool DMA = false, int ABL = 0>
 struct H3Ring {
   static constexpr int K = 256, KB = K / 32, CF4 = chunk_f4(K);
   static constexpr int NST = (CF4 + WG_THREADS - 1) / WG_THREADS;
@@ -260,17 +260,21 @@ struct H3Ring {
   // DMA variant: global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, 1 KiB per wave
   // instruction), no staging registers and no ds_write.  Completion is tracked with counted s_waitcnt vmcnt by hand.
   static constexpr int NDMA = CF4 / WG_THREADS;          // full passes (4); the 4-float4 tail is copied by wave 0
+  // The copy is issued from inline asm on purpose: hipcc's waitcnt pass cannot tell which LDS bytes an LDS-DMA it knows
+  // about will write, so it puts `s_waitcnt vmcnt(0)` in front of every later ds_read -- which drained the ring (the
+  // chunk c+2 copy issued a few MFMAs earlier) once per chunk and exposed the full L2 latency.  Ordering against the
+  // ds_reads of a slot is enforced by hand: counted vmcnt + s_barrier in chunk().
+  static __device__ __forceinline__ void dma16(const f4* gsrc, f4* ldst_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ldst_wave_base));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "memory");   // m0 is a reserved register: hipcc re-materialises it before each of its own uses
+  }
   __device__ __forceinline__ void dma_chunk(int chunk, int s) {
     const f4* src = W + (long)chunk * CF4;
     f4* dst = lds + s * CF4;
     const int wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * WG_THREADS + tid),
-                                       (__attribute__((address_space(3))) void*)(dst + i * WG_THREADS + wave * 64), 16, 0, 0);
-    if (tid < CF4 - NDMA * WG_THREADS)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + NDMA * WG_THREADS + tid),
-                                       (__attribute__((address_space(3))) void*)(dst + NDMA * WG_THREADS), 16, 0, 0);
+    for (int i = 0; i < NDMA; ++i) dma16(src + i * WG_THREADS + tid, dst + i * WG_THREADS + wave * 64);
+    if (tid < CF4 - NDMA * WG_THREADS) dma16(src + NDMA * WG_THREADS + tid, dst + NDMA * WG_THREADS);
   }
   __device__ __forceinline__ void store_stage(int s) {
 #pragma unroll
@@ -330,6 +334,7 @@ struct H3Ring {
       constexpr int i0 = 0, ia = (CH >= 2 ? 1 : 0), ib = (CH >= 3 ? 2 : (CH >= 2 ? 1 : 0));
       // issue order hi*lo, hi*hi, lo*hi: with two chains the two correction products (same accumulator) are never
       // back to back, also when a wave owns a single tile
+      if constexpr (ABL & 8) return;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t][ia] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][ia], 0, 0, 0);
 #pragma unroll
@@ -345,7 +350,7 @@ struct H3Ring {
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2: stage chunk c+1 into its ring slot, start fetching chunk c+2
     if constexpr (DMA) {
-      dma_chunk(c2, nslot == 2 ? 0 : nslot + 1);   // slot of chunk c+2 == slot of chunk c-1: no wave still reads it
+      if constexpr (!(ABL & 2)) dma_chunk(c2, nslot == 2 ? 0 : nslot + 1);   // slot of chunk c+2 == slot of chunk c-1: no wave still reads it
     } else {
       store_stage(nslot);
       load_stage(c2);
@@ -359,23 +364,23 @@ struct H3Ring {
     // (__syncthreads() would add s_waitcnt vmcnt(0) and expose the L2 latency every chunk)
     if constexpr (DMA) {
       // chunk c+1's DMA (issued one chunk ago) must have landed; chunk c+2's (NDMA, +1 in wave 0) may stay in flight
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 4: first half of chunk c+1's weights (their registers are free), bias of c+1
     const f4 nbias = lds[nslot * CF4 + g];
-    read_w(nslot, 0, KB);
+    if constexpr (!(ABL & 4)) read_w(nslot, 0, KB);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 5: last quarter
 #pragma unroll
     for (int kb = 3 * KB / 4; kb < KB; ++kb) mfma_kb(kb);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 6: second half of chunk c+1's weights; result
-    read_w(nslot, KB, KB);
+    if constexpr (!(ABL & 4)) read_w(nslot, KB, KB);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f4 r = acc[t][0];

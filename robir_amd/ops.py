@@ -154,17 +154,23 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
                precision="fp32"):
     """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain) or 'f16x3' (split-precision, ~2^-22 relative)."""
     normals = _f32(normals)
-    h3 = precision.startswith("f16x3")
+    h3 = precision.startswith("f16x3") or precision.startswith("abl")
     assert h3 or precision == "fp32", precision
     # "f16x3" = one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA (measured fastest);
     # "f16x3-regstage" = same with global->VGPR->LDS staging; "-nt2*" = two tiles per wave, one workgroup per CU,
     # with 2 / 1 / 3 accumulator chains per tile
     code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-nt2-1chain": 2, "f16x3-nt2-3chain": 3, "f16x3-regstage": 4,
-            "f16x3": 5}[precision]
+            "f16x3": 5, "f16x3-nt2-dma": 6, "f16x3-v2": 7, "abl-nobar": 10, "abl-nodma": 11, "abl-nords": 12, "abl-nomfma": 13,
+            "abl-onlymfma": 14, "abl-nobar-nodma": 15}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
         assert chunk_id.dtype == torch.int32
+    if precision == "f16x3-v2":
+        call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+             ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(split["h3_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
+        return out
     call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
          ptr(split["hidden_h3"] if h3 else split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L),
          c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(code), c_int(split["h3_scale_log2"] if h3 else 0),

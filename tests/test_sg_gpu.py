@@ -23,7 +23,7 @@ def vis_net(dev, synth_weights):
     return v.to(dev).eval()
 
 
-@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2"])
+@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2", "f16x3-v2"])
 def precision(request):
     from robir_amd import sg_render
     old = sg_render.VIS_PRECISION

@@ -33,7 +33,9 @@ g = torch.Generator(device=dev).manual_seed(1)
 u = torch.rand(2, n_chunks, 128, 32, device=dev, generator=g)
 if prec == "variants":
     import itertools
-    names = ["f16x3", "f16x3-regstage", "f16x3-nt2"]
+    names = ["f16x3", "f16x3-v2"]
+    if len(sys.argv) > 3:
+        names = sys.argv[3].split(",")
     times = {k: [] for k in names}
     for rep in range(4):
         for k in names:
@@ -51,6 +53,14 @@ if prec == "variants":
             times[k].append(s.elapsed_time(e))
     for k in names:
         print(k, " ".join(f"{t:.2f}" for t in times[k]), "ms  (min %.2f)" % min(times[k]))
+    if os.environ.get("RB_V2_ABL") == "16":
+        import ctypes
+        from robir_amd import _lib
+        buf = (ctypes.c_ulonglong * 8)()
+        _lib.lib().rb_dvis_v2_debug(buf)
+        tot = sum(buf[:6]) or 1
+        print("v2 phases (wave-0 clocks, share):", ", ".join(f"{n}={100 * buf[i] / tot:.1f}%" for i, n in
+              enumerate(["prologue", "ring-start", "gather", "layers", "head", "final"])), "total", tot)
     sys.exit(0)
 sg_render.VIS_PRECISION = prec
 stats = {}
