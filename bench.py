@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--chunks-per-batch", type=int, default=125, help="1024-pixel chunks rendered per kernel pass")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--vis-precision", default="f16x3", choices=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2"],
+    ap.add_argument("--vis-precision", default="f16x3-v2", choices=["fp32", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
     return ap.parse_args()
@@ -216,7 +216,7 @@ def main():
         # peak of the pipe the dominant kernel runs on, per ALGORITHMIC flop: exact mode = dense f32-input MFMA;
         # f16x3 = dense f16 MFMA (2.5 PFLOP/s) / 3 products per algorithmic multiply-add
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": "k_dvis_fused (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
+        roofline = {"bound": "mfma", "kernel": ("k_dvis_v2" if precision == "f16x3-v2" else "k_dvis_fused") + " (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak,
                     # HBM bytes per launch: 31 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
                     # correction) + WRITE_SIZE on this kernel (profiles/r01_dvis_f16x3_pmc.md), scaled to this launch's pair

@@ -235,7 +235,7 @@ __device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float un
 // so neither the L2 latency of the weight stream, nor the LDS write/read round trip, nor the barrier sit between the
 // last MFMA of one chunk and the first MFMA of the next (PMC before: matrix pipe 37 % busy, 37 % parked in waits).
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, int NCHUNK, bool DMA = false, int ABL = 0>
+template <int NT, int NCHUNK, bool DMA = false>
 struct H3Ring {
   static constexpr int K = 256, KB = K / 32, CF4 = chunk_f4(K);
   static constexpr int NST = (CF4 + WG_THREADS - 1) / WG_THREADS;
@@ -334,7 +334,6 @@ struct H3Ring {
       constexpr int i0 = 0, ia = (CH >= 2 ? 1 : 0), ib = (CH >= 3 ? 2 : (CH >= 2 ? 1 : 0));
       // issue order hi*lo, hi*hi, lo*hi: with two chains the two correction products (same accumulator) are never
       // back to back, also when a wave owns a single tile
-      if constexpr (ABL & 8) return;
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t][ia] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][ia], 0, 0, 0);
 #pragma unroll
@@ -350,7 +349,7 @@ struct H3Ring {
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2: stage chunk c+1 into its ring slot, start fetching chunk c+2
     if constexpr (DMA) {
-      if constexpr (!(ABL & 2)) dma_chunk(c2, nslot == 2 ? 0 : nslot + 1);   // slot of chunk c+2 == slot of chunk c-1: no wave still reads it
+      dma_chunk(c2, nslot == 2 ? 0 : nslot + 1);   // slot of chunk c+2 == slot of chunk c-1: no wave still reads it
     } else {
       store_stage(nslot);
       load_stage(c2);
@@ -364,23 +363,23 @@ struct H3Ring {
     // (__syncthreads() would add s_waitcnt vmcnt(0) and expose the L2 latency every chunk)
     if constexpr (DMA) {
       // chunk c+1's DMA (issued one chunk ago) must have landed; chunk c+2's (NDMA, +1 in wave 0) may stay in flight
-      if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 4: first half of chunk c+1's weights (their registers are free), bias of c+1
     const f4 nbias = lds[nslot * CF4 + g];
-    if constexpr (!(ABL & 4)) read_w(nslot, 0, KB);
+    read_w(nslot, 0, KB);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 5: last quarter
 #pragma unroll
     for (int kb = 3 * KB / 4; kb < KB; ++kb) mfma_kb(kb);
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 6: second half of chunk c+1's weights; result
-    if constexpr (!(ABL & 4)) read_w(nslot, KB, KB);
+    read_w(nslot, KB, KB);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f4 r = acc[t][0];

@@ -74,7 +74,7 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
 
 constexpr int DV_MAX_DIRS = 4096;
 
-template <bool H3, int CH, int NT, bool DMA = false, int ABL = 0>
+template <bool H3, int CH, int NT, bool DMA = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
   if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
 
   WStream<256> ws;
-  H3Ring<NT, 48, DMA, ABL> ring;
+  H3Ring<NT, 48, DMA> ring;
   constexpr long LF = (long)16 * chunk_f4(256);
   const float b0 = blast[0], b1 = blast[1];
   constexpr int RS = 64 * NT;   // samples per workgroup round
@@ -257,7 +257,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                   int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
                   unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(precision >= 0 && precision <= 16, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
+  RB_REQUIRE(precision >= 0 && precision <= 6, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
@@ -276,12 +276,6 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
       RB_LAUNCH_H3(3, 2);
     } else if (precision == 4) {
       RB_LAUNCH_H3(2, 1);       // one tile per wave, two workgroups per CU
-    } else if (precision == 10) { RB_LAUNCH_H3(2, 1, true, 1);
-    } else if (precision == 11) { RB_LAUNCH_H3(2, 1, true, 2);
-    } else if (precision == 12) { RB_LAUNCH_H3(2, 1, true, 4);
-    } else if (precision == 13) { RB_LAUNCH_H3(2, 1, true, 8);
-    } else if (precision == 14) { RB_LAUNCH_H3(2, 1, true, 7);
-    } else if (precision == 15) { RB_LAUNCH_H3(2, 1, true, 3);
     } else if (precision == 6) {
       RB_LAUNCH_H3(2, 2, true); // two tiles per wave, one workgroup per CU, LDS-DMA
     } else {

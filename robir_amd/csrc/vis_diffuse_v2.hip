@@ -35,7 +35,7 @@ __device__ __forceinline__ void v2_dma16(const f4* gbase_uniform, unsigned lane_
 
 __device__ unsigned long long rb_v2_dbg[8];
 #define V2_T(i)                                                   \
-  if constexpr (ABL & 16) {                                       \
+  if constexpr (TIMED) {                                          \
     const long long now_ = clock64();                             \
     tacc[i] += now_ - tlast;                                      \
     tlast = now_;                                                 \
@@ -57,7 +57,7 @@ struct V2Acc {
   f4 a[2][2];
 };
 
-template <int ABL>
+template <bool TIMED>
 __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tlast = (ABL & 16) ? clock64() : 0;
+  long long tlast = TIMED ? clock64() : 0;
   const long p = blockIdx.x;
   const int LS = L * nsamp;
   const long dbase = (cid ? (long)cid[p] : 0L) * LS;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
       const int j = jjn[t] < 0 ? 0 : jjn[t];
       const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) raw[t][kb] = (ABL & 4) ? f4{(float)j, 1.f, 2.f, 3.f} : brow[kb * 4];
+      for (int kb = 0; kb < 16; ++kb) raw[t][kb] = brow[kb * 4];
     }
   };
   if (rounds > 0) fetch_rows(0);
@@ -217,14 +217,12 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
         // chunk jb+1 has landed in its slot once at most the copy of chunk jb+2 (4 instructions) is still in flight;
         // past the barrier every wave has also finished with chunk jb-1, whose slot the copy of chunk jb+3 reuses
         // (the 32 row loads issued at the top of layer 1 are younger than the copies the first two chunks wait for)
-        if constexpr (!(ABL & 2)) {
-          if (jb < 2 && l == 1) {
-            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          }
+        if (jb < 2 && l == 1) {
+          asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
-        if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int nx3 = jb + V2_DIST;
         const f4* dsrc = nx3 < 16 ? Wl + (long)nx3 * V2_CF4 : Wn + (long)(nx3 - 16) * V2_CF4;
@@ -237,16 +235,10 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
           mfma_kb(kb, acc, wreg);
-          if constexpr (ABL & 64) {      // timing ablation: no fragment reads (opaque touch keeps the MFMAs alive)
-            asm volatile("" : "+v"(wreg[2 * kb]), "+v"(wreg[2 * kb + 1]));
-          } else {
-            wreg[2 * kb] = ring_u[ns * V2_WF4 + (2 * kb) * 64];
-            wreg[2 * kb + 1] = ring_u[ns * V2_WF4 + (2 * kb + 1) * 64];
-          }
-          if constexpr (!(ABL & 128))
-            if (jb > 0 && (kb & 1)) epilogue_piece(prev, jb - 1, kb >> 1);
-          if constexpr (!(ABL & 2))
-            if (!(kb & 1)) v2_dma16(dsrc + (kb >> 1) * 256, lane_off, ddst + (unsigned)(kb >> 1) * 4096u);
+          wreg[2 * kb] = ring_u[ns * V2_WF4 + (2 * kb) * 64];
+          wreg[2 * kb + 1] = ring_u[ns * V2_WF4 + (2 * kb + 1) * 64];
+          if (jb > 0 && (kb & 1)) epilogue_piece(prev, jb - 1, kb >> 1);
+          if (!(kb & 1)) v2_dma16(dsrc + (kb >> 1) * 256, lane_off, ddst + (unsigned)(kb >> 1) * 4096u);
           __builtin_amdgcn_sched_barrier(0);
         }
         prev = acc;
@@ -309,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     vis_out[p * L + tid] = acc / wsum[(cid ? cid[p] : 0) * L + tid];
   }
   V2_T(5)
-  if constexpr (ABL & 16) {
+  if constexpr (TIMED) {
     if (tid == 0)
       for (int i = 0; i < 6; ++i) atomicAdd(&rb_v2_dbg[i], (unsigned long long)tacc[i]);
   }
@@ -323,31 +315,21 @@ extern "C" int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long 
                                 const float* dirs, const float* wdir, const float* wsum, const float* W49, int L, int nsamp,
                                 int argmax_vis, int scale_log2, float* vis_out, unsigned long long* eval_count,
                                 rb_stream_t stream) {
-  const char* ab = getenv("RB_V2_ABL");
-  const int abl = ab ? atoi(ab) : 0;
-  if (n <= 0) return 0;
-  RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
-  RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= V2_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
-#define RB_V2(AB)                                                                                                          \
-  hipLaunchKernelGGL(k_dvis_v2<AB>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, \
+  // RB_V2_TIMED=1: per-phase shader-clock totals (rb_dvis_v2_debug), a profiling aid -- costs ~10 % in the kernel
+  const char* tm = getenv("RB_V2_TIMED");
+#define RB_V2(T)                                                                                                          \
+  hipLaunchKernelGGL(k_dvis_v2<T>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, \
                      wdir, wsum, (const f4*)W49, L, nsamp, argmax_vis, ldexpf(1.0f, -scale_log2), vis_out, eval_count)
-  switch (abl) {
-    case 1: RB_V2(1); break;
-    case 2: RB_V2(2); break;
-    case 3: RB_V2(3); break;
-    case 4: RB_V2(4); break;
-    case 7: RB_V2(7); break;
-    case 16: RB_V2(16); break;
-    case 64: RB_V2(64); break;
-    case 128: RB_V2(128); break;
-    case 195: RB_V2(195); break;
-    case 194: RB_V2(194); break;
-    default: RB_V2(0);
+  if (tm && tm[0] == '1') {
+    RB_V2(true);
+  } else {
+    RB_V2(false);
   }
+#undef RB_V2
   return check_launch("k_dvis_v2");
 }
 
-// debug: per-phase shader-clock totals of wave 0 (RB_V2_ABL=16): prologue, ring start, gather, layers, head, final
+// debug: per-phase shader-clock totals of wave 0 (RB_V2_TIMED=1): prologue, ring start, gather, layers, head, final
 extern "C" int rb_dvis_v2_debug(unsigned long long* out8) {
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rb_v2_dbg), sizeof(z)) != hipSuccess) return 1;

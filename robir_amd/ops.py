@@ -154,14 +154,15 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
                precision="fp32"):
     """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain) or 'f16x3' (split-precision, ~2^-22 relative)."""
     normals = _f32(normals)
-    h3 = precision.startswith("f16x3") or precision.startswith("abl")
+    h3 = precision.startswith("f16x3")
     assert h3 or precision == "fp32", precision
-    # "f16x3" = one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA (measured fastest);
+    # "f16x3-v2" (default of sg_render) = second-generation kernel: two tiles per wave, one workgroup per CU, head on
+    # the matrix pipe (csrc/vis_diffuse_v2.hip);
+    # "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA;
     # "f16x3-regstage" = same with global->VGPR->LDS staging; "-nt2*" = two tiles per wave, one workgroup per CU,
     # with 2 / 1 / 3 accumulator chains per tile
     code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-nt2-1chain": 2, "f16x3-nt2-3chain": 3, "f16x3-regstage": 4,
-            "f16x3": 5, "f16x3-nt2-dma": 6, "f16x3-v2": 7, "abl-nobar": 10, "abl-nodma": 11, "abl-nords": 12, "abl-nomfma": 13,
-            "abl-onlymfma": 14, "abl-nobar-nodma": 15}[precision]
+            "f16x3": 5, "f16x3-nt2-dma": 6, "f16x3-v2": 7,}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:

@@ -21,10 +21,11 @@ from .nets import VisNetwork
 
 TINY_NUMBER = 1e-6
 # Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
-# chain); "f16x3" (default) = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative error,
-# measured parity identical to "fp32": tests/test_sg_gpu.py runs both); "f16x3-nt2*" = register-blocking variants.
+# chain); "f16x3-v2" (default) / "f16x3" = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22
+# relative error, measured parity identical to "fp32": tests/test_sg_gpu.py runs all of them) in the second- / first-
+# generation kernel; "f16x3-nt2*", "f16x3-regstage" = register-blocking / staging variants of the first generation.
 import os as _os
-VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3")
+VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3-v2")
 
 
 # ----------------------------------------------------------------------------------------- small public helpers

@@ -53,7 +53,7 @@ if prec == "variants":
             times[k].append(s.elapsed_time(e))
     for k in names:
         print(k, " ".join(f"{t:.2f}" for t in times[k]), "ms  (min %.2f)" % min(times[k]))
-    if os.environ.get("RB_V2_ABL") == "16":
+    if os.environ.get("RB_V2_TIMED") == "1":
         import ctypes
         from robir_amd import _lib
         buf = (ctypes.c_ulonglong * 8)()
