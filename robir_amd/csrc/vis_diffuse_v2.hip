@@ -53,8 +53,9 @@ __device__ __forceinline__ void v2_split_pair(float v0, float v1, unsigned& hi, 
   lo = l;
 }
 
+constexpr int V2_CH = 1;   // accumulator chains per tile: 1 = all three products into one accumulator
 struct V2Acc {
-  f4 a[2][2];
+  f4 a[2][V2_CH];
 };
 
 template <bool TIMED>
@@ -144,19 +145,25 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     }
     // same product order as H3Ring::chunk (hi*lo, hi*hi, lo*hi; corrections share an accumulator)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc.a[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc.a[t][1], 0, 0, 0);
+    for (int t = 0; t < 2; ++t)
+      acc.a[t][V2_CH - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc.a[t][V2_CH - 1], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc.a[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc.a[t][0], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc.a[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc.a[t][1], 0, 0, 0);
+    for (int t = 0; t < 2; ++t)
+      acc.a[t][V2_CH - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc.a[t][V2_CH - 1], 0, 0, 0);
   };
   // relu(z * unscale) of output block jb -> packed operands of the next layer: k-block jb/2, registers 2*(jb&1)+{0,1}.
   // piece = (tile, register pair): four pieces per chunk, spread over the next chunk's k-blocks
   auto epilogue_piece = [&](const V2Acc& acc, int jb, int piece) {
     const int t = piece >> 1, q = piece & 1;
-    const float r0 = acc.a[t][0][2 * q] + acc.a[t][1][2 * q], r1 = acc.a[t][0][2 * q + 1] + acc.a[t][1][2 * q + 1];
-    v2_split_pair(fmaxf(r0 * w_unscale, 0.f), fmaxf(r1 * w_unscale, 0.f), yh[t][jb >> 1][(jb & 1) * 2 + q],
-                  yl[t][jb >> 1][(jb & 1) * 2 + q]);
+    float r0 = acc.a[t][0][2 * q], r1 = acc.a[t][0][2 * q + 1];
+    if constexpr (V2_CH == 2) {
+      r0 += acc.a[t][1][2 * q];
+      r1 += acc.a[t][1][2 * q + 1];
+    }
+    const float v0 = fmaxf(r0 * w_unscale, 0.f), v1 = fmaxf(r1 * w_unscale, 0.f);
+    v2_split_pair(v0, v1, yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
   };
   auto epilogue = [&](const V2Acc& acc, int jb) {
 #pragma unroll
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           acc.a[t][0] = bias;
-          acc.a[t][1] = f4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (V2_CH == 2) acc.a[t][1] = f4{0.f, 0.f, 0.f, 0.f};
         }
         // chunk jb+1 has landed in its slot once at most the copy of chunk jb+2 (4 instructions) is still in flight;
         // past the barrier every wave has also finished with chunk jb-1, whose slot the copy of chunk jb+3 reuses
@@ -267,14 +274,15 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         acc.a[t][0] = bias;
-        acc.a[t][1] = f4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (V2_CH == 2) acc.a[t][1] = f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) mfma_kb(kb, acc, hreg);
       bias = bias_tab[g];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const f4 r = acc.a[t][0] + acc.a[t][1];
+        f4 r = acc.a[t][0];
+        if constexpr (V2_CH == 2) r = r + acc.a[t][1];
         const float l0 = r[0] * w_unscale, l1 = r[1] * w_unscale;
         if (g == 0 && jj[t] >= 0) {
           float v;

@@ -170,7 +170,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     if precision == "f16x3-v2":
         call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
-             c_int(split["h3_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
+             c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
     call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
          ptr(split["hidden_h3"] if h3 else split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L),

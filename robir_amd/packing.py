@@ -100,7 +100,7 @@ def pack_vis_split(sd, device):
     # 49 chunks: hidden stack + the output layer as one more 16-row chunk (rb_dvis_fused_v2)
     hid_h3_head = pack_layers_h3(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
     return dict(point=wp, dir=wd, hidden=hid, hidden_h3=hid_h3, hidden_h3_head=hid_h3_head, h3_scale_log2=H3_SCALE_LOG2,
-                w_last=w_last, b_last=b_last)
+                h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last)
 
 
 def pack_sdf(sd, device, full=True):
