@@ -70,7 +70,10 @@ int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_strea
  * X from rb_feat_pe10 (jvp rows for modes 2,3).  Wp packed [64->256, 256->256 x2, 256->208, 272->256, 256->256 x3,
  * 256->272] (modes 1,3) or [... , 256->16] (modes 0,2).
  * mode 0: out0[M] = sdf*out_scale          mode 1: out0[M,257] = (sdf,feat)*out_scale
- * mode 2: + grad[M,3] = d sdf/d(x*scale) * grad_scale (forward-mode), out0[M]      mode 3: same with out0[M,257] */
+ * mode 2: + grad[M,3] = d sdf/d(x*scale) * grad_scale (forward-mode), out0[M]      mode 3: same with out0[M,257]
+ * Softplus(beta=100) is evaluated with the hardware exp/log/rcp (a few ulp); modes 4 and 6 are modes 0 and 2 with the
+ * library expf/log1pf instead -- the octree build uses them because its split / hit thresholds must fall exactly where
+ * the reference's do. */
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).

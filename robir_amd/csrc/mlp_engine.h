@@ -32,6 +32,33 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2, ACT_SOFTPLUS100 = 3 };
 
 __host__ __device__ constexpr int chunk_f4(int K) { return K > 0 ? 4 + K * 4 : 0; }  // float4s per chunk
 
+// torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta, and its derivative
+// sigmoid(beta*x) (1 above the threshold, like torch's softplus_backward).  The SDF kernels spend more time here than in
+// their MFMAs when this goes through the library expf/log1pf, so it is built from the hardware transcendentals
+// (v_exp/v_log/v_rcp, 1 ulp each) with the one step that needs care done exactly:
+//   u = fl(1 + e), c = e - (u - 1) (the rounding error of u, exact), log1p(e) = log(u) + c/u.
+// Error: a few ulp of the result (tests/test_mlp_gpu.py compares with the oracle), i.e. fp32-rounding level.
+// PRECISE = library expf/log1pf and true divisions, bit-compatible with the first implementation: used where the value
+// feeds a threshold decision that must reproduce the reference's (octree build), not in the shading passes.
+template <bool PRECISE = false>
+__device__ __forceinline__ float softplus100(float z, float* dsig) {
+  const float bz = 100.0f * z;
+  if constexpr (PRECISE) {
+    const float ex = expf(bz);
+    if (dsig) *dsig = bz > 20.0f ? 1.0f : ex / (ex + 1.0f);
+    return bz > 20.0f ? z : log1pf(ex) / 100.0f;
+  }
+  // exp(min(bz, 20)); the select (not fminf) keeps a NaN input a NaN, like the reference (rays that graze a cell face)
+  const float e = __builtin_amdgcn_exp2f((bz > 20.0f ? 20.0f : bz) * 1.44269504088896340736f);
+  const float u = 1.0f + e;
+  const float r = __builtin_amdgcn_rcpf(u);
+  const float c = e - (u - 1.0f);
+  const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;                  // ln(u); v_log_f32 is log2
+  const float sp = (lg + c * r) * 0.01f;
+  if (dsig) *dsig = bz > 20.0f ? 1.0f : e * r;
+  return bz > 20.0f ? z : sp;
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fn(float z) {
   if constexpr (ACT == ACT_RELU) {
@@ -39,20 +66,10 @@ __device__ __forceinline__ float act_fn(float z) {
   } else if constexpr (ACT == ACT_LEAKY02) {
     return z > 0.0f ? z : 0.2f * z;
   } else if constexpr (ACT == ACT_SOFTPLUS100) {
-    // torch.nn.Softplus(beta=100, threshold=20): x if beta*x > 20 else log1p(exp(beta*x))/beta
-    float bz = 100.0f * z;
-    return bz > 20.0f ? z : log1pf(expf(bz)) / 100.0f;
+    return softplus100<false>(z, nullptr);
   } else {
     return z;
   }
-}
-
-// d softplus100 / dz = sigmoid(100 z)   (1 above the threshold, like torch's softplus_backward)
-__device__ __forceinline__ float softplus100_grad(float z) {
-  float bz = 100.0f * z;
-  if (bz > 20.0f) return 1.0f;
-  float e = expf(bz);
-  return e / (e + 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restric
 // MODE 0: sdf only -> out0[M]          MODE 1: sdf+feat -> out0[M,257]
 // MODE 2: forward-mode jvp, sdf only: X[4M,64] (value row + 3 tangent rows per point); out0[M], grad[M,3]
 // MODE 3: forward-mode jvp, full:     X[4M,64]; out0[M,257], grad[M,3]
-template <int NREG, int HREG, bool JVP>
+template <int NREG, int HREG, bool JVP, bool PRECISE = false>
 __device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (&h)[2][HREG], int lane, float scale) {
   if constexpr (JVP) {
     const bool is_val = (lane & 3) == 0;
@@ -307,19 +307,21 @@ __device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < NREG; ++i) {
-        float zv = __shfl(z[t][i], src);
-        float v = is_val ? act_fn<ACT_SOFTPLUS100>(zv) : z[t][i] * softplus100_grad(zv);
+        const float zv = __shfl(z[t][i], src);
+        float sig;
+        const float sp = softplus100<PRECISE>(zv, &sig);   // value row: softplus; tangent rows: z' * sigmoid(100 z)
+        const float v = is_val ? sp : z[t][i] * sig;
         h[t][i] = v * scale;
       }
   } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < NREG; ++i) h[t][i] = act_fn<ACT_SOFTPLUS100>(z[t][i]) * scale;
+      for (int i = 0; i < NREG; ++i) h[t][i] = softplus100<PRECISE>(z[t][i], nullptr) * scale;
   }
 }
 
-template <int MODE>
+template <int MODE, bool PRECISE = false>
 __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
                                                      float out_scale, float grad_scale, float* __restrict__ out0,
                                                      float* __restrict__ grad) {
@@ -345,18 +347,18 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
   load_features<64>(X, row0 + 16, MR, lane, x0[1]);
   ws.prime<chunk_f4(64)>(w0);
   dense_layer<64, 256, 2, 256>(ws, w0, w1, x0, z, lane, bias_on);
-  softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+  softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
 #pragma unroll 1
   for (int l = 0; l < 2; ++l) {
     dense_layer<256, 256, 2, 256>(ws, w1 + l * LF, w1 + (l + 1) * LF, ha, z, lane, bias_on);
-    softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+    softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
   }
   {
     float hs[2][68];
     {
       float z3[2][52];
       dense_layer<256, 208, 2, 272>(ws, w3, w4, ha, z3, lane, bias_on);
-      softplus_into<52, 68, JVP>(z3, hs, lane, inv_sqrt2);   // neurons 193..207 are padding: zero weights downstream
+      softplus_into<52, 68, JVP, PRECISE>(z3, hs, lane, inv_sqrt2);   // neurons 193..207 are padding: zero weights downstream
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -364,11 +366,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
       for (int i = 0; i < 16; ++i) hs[t][52 + i] = x0[t][i] * inv_sqrt2;
     dense_layer<272, 256, 2, 256>(ws, w4, w5, hs, z, lane, bias_on);
   }
-  softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+  softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
 #pragma unroll 1
   for (int l = 0; l < 3; ++l) {
     dense_layer<256, 256, 2, 256>(ws, w5 + l * LF, w5 + (l + 1) * LF, ha, z, lane, bias_on);
-    softplus_into<64, 64, JVP>(z, ha, lane, 1.0f);
+    softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
   }
   float zo[2][NL / 4];
   dense_layer<256, NL, 2, 0>(ws, w8, nullptr, ha, zo, lane, bias_on);
@@ -748,9 +750,9 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
                float* grad, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && out0, "null pointer");
-  RB_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0..3");
-  RB_REQUIRE(mode < 2 || grad, "jvp modes need a gradient output");
-  const long MR = mode >= 2 ? 4 * M : M;
+  RB_REQUIRE((mode >= 0 && mode <= 3) || mode == 4 || mode == 6, "mode must be 0..3, or 4 / 6 (= 0 / 2 with library-grade activations)");
+  RB_REQUIRE((mode & 3) < 2 || grad, "jvp modes need a gradient output");
+  const long MR = (mode & 3) >= 2 ? 4 * M : M;
   dim3 grid = grid1d(MR, 128), block(256);
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
@@ -758,7 +760,9 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
     case 0: hipLaunchKernelGGL(k_sdf_mlp<0>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
     case 1: hipLaunchKernelGGL(k_sdf_mlp<1>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
     case 2: hipLaunchKernelGGL(k_sdf_mlp<2>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    default: hipLaunchKernelGGL(k_sdf_mlp<3>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    case 3: hipLaunchKernelGGL(k_sdf_mlp<3>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    case 4: hipLaunchKernelGGL((k_sdf_mlp<0, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    default: hipLaunchKernelGGL((k_sdf_mlp<2, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
   }
   return check_launch("k_sdf_mlp");
 }

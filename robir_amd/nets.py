@@ -326,12 +326,14 @@ class SDFNetwork(nn.Module):
         return self._packed.get("w512", self, lambda sd: packing.pack_softplus512(
             {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
 
-    def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False):
-        """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx."""
+    def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False, precise=False):
+        """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
+        precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
         assert self.kind == "neus"
         x = x.float().contiguous()
         M = x.shape[0]
-        mode = (1 if full else 0) + (2 if grad else 0)
+        assert not (precise and full)
+        mode = (1 if full else 0) + (2 if grad else 0) + (4 if precise else 0)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
         return ops.sdf_mlp(X, M, self.packed(full), mode, out_scale, out_scale * in_scale)
 

@@ -45,7 +45,7 @@ class OctreeSDF:
         call("rb_octree_base_grid", rm, rs, rr, ptr(node), ptr(centre), stream_ptr())
 
         def sdf_at(c):
-            outs = [sdf_network.eval_points(c[i:i + eval_chunk], in_scale, out_scale, full=False)[0]
+            outs = [sdf_network.eval_points(c[i:i + eval_chunk], in_scale, out_scale, full=False, precise=True)[0]
                     for i in range(0, c.shape[0], eval_chunk)]
             return torch.cat(outs) if len(outs) > 1 else outs[0]
 
@@ -74,7 +74,7 @@ class OctreeSDF:
         nrm = torch.empty(total, 3, dtype=torch.float32, device=dev)
         for i in range(0, total, eval_chunk):
             c = centre[i:i + eval_chunk]
-            sdf, grad = sdf_network.eval_points(c, in_scale, out_scale, full=False, grad=True)
+            sdf, grad = sdf_network.eval_points(c, in_scale, out_scale, full=False, grad=True, precise=True)
             call("rb_octree_store_cells", ptr(node), ptr(nrm), ctypes.c_long(i), ctypes.c_long(c.shape[0]), ptr(sdf),
                  ptr(grad), stream_ptr())
         torch.cuda.current_stream().synchronize()

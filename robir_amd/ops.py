@@ -70,7 +70,7 @@ def linear_64_256(X, blob):
 def sdf_mlp(X, M, blob, mode, out_scale=1.0, grad_scale=1.0):
     full = mode in (1, 3)
     out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=X.device)
-    grad = torch.empty(M, 3, dtype=torch.float32, device=X.device) if mode >= 2 else None
+    grad = torch.empty(M, 3, dtype=torch.float32, device=X.device) if (mode & 3) >= 2 else None
     call("rb_sdf_mlp", ptr(X), c_long(M), ptr(blob), c_int(mode), c_float(out_scale), c_float(grad_scale), ptr(out0),
          ptr(grad), stream_ptr())
     return out0, grad
