@@ -133,6 +133,10 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
 int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* Profiling aid: with RB_V2_TIMED=1 in the environment rb_dvis_fused_v2 runs an instrumented build that accumulates
+ * shader-clock totals of wave 0 per phase (prologue, ring start, row gather, hidden layers, head, final reduction);
+ * this call copies the six totals to out8[0..5] and clears them.  Returns non-zero on a HIP error. */
+int rb_dvis_v2_debug(unsigned long long* out8);
 int rb_spec_vis_sample(const float* normal, const float* view, const float* rough, const int* chunk_id, long n,
                        int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
                        unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);
