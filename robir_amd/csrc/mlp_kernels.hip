@@ -202,22 +202,22 @@ __global__ void k_feat_ipe(const float* __restrict__ x, long M, float var, const
 __global__ void k_feat_color(const float* __restrict__ x, float x_scale, const float* __restrict__ view,
                              const float* __restrict__ normal, const float* __restrict__ feat, long feat_stride,
                              float feat_scale, long M, float* __restrict__ X) {
-  long i = blockIdx.x;
-  if (i >= M) return;
-  float* row = X + i * 304;
-  const int t = threadIdx.x;  // 256 threads: one feature each
-  row[t] = feat[i * feat_stride + t] * feat_scale;
-  if (t == 0) {
-    float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
-    row[256] = x[3 * i] * x_scale;
-    row[257] = x[3 * i + 1] * x_scale;
-    row[258] = x[3 * i + 2] * x_scale;
-    write_pe<4>(v, row + 259);
-    row[286] = normal[3 * i];
-    row[287] = normal[3 * i + 1];
-    row[288] = normal[3 * i + 2];
+  const int t = threadIdx.x;  // 256 threads: one feature each; rows by grid stride (M * 256 may exceed 2^32 work-items)
+  for (long i = blockIdx.x; i < M; i += gridDim.x) {
+    float* row = X + i * 304;
+    row[t] = feat[i * feat_stride + t] * feat_scale;
+    if (t == 0) {
+      float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
+      row[256] = x[3 * i] * x_scale;
+      row[257] = x[3 * i + 1] * x_scale;
+      row[258] = x[3 * i + 2] * x_scale;
+      write_pe<4>(v, row + 259);
+      row[286] = normal[3 * i];
+      row[287] = normal[3 * i + 1];
+      row[288] = normal[3 * i + 2];
 #pragma unroll
-    for (int k = 289; k < 304; ++k) row[k] = 0.f;
+      for (int k = 289; k < 304; ++k) row[k] = 0.f;
+    }
   }
 }
 
@@ -727,7 +727,7 @@ int rb_feat_color(const float* x, float x_scale, const float* view, const float*
                   long feat_stride, float feat_scale, long M, float* X, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && view && normal && feat && X, "null pointer");
-  hipLaunchKernelGGL(k_feat_color, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, x_scale, view, normal, feat,
+  hipLaunchKernelGGL(k_feat_color, dim3((unsigned)(M < RB_MAX_BLOCKS ? M : RB_MAX_BLOCKS)), dim3(256), 0, (hipStream_t)stream, x, x_scale, view, normal, feat,
                      feat_stride, feat_scale, M, X);
   return check_launch("k_feat_color");
 }

@@ -511,6 +511,7 @@ int rb_octree_cast_batched(const float* node, const float* nrm, long B, const fl
   RB_REQUIRE(batch >= 1 && batch <= 1024, "a lock-step batch of the batched kernel holds 1..1024 rays");
   Oct T = make_oct(node, nrm, B, root_min, root_size, res);
   const long nb = (R_total + batch - 1) / batch;
+  RB_REQUIRE(nb <= RB_MAX_BLOCKS, "too many lock-step batches for one launch");
   hipLaunchKernelGGL(k_cast_batched, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, T, origins, per_ray_origin,
                      dirs, R_total, batch, max_iter, step, clamp_dt, x_out, hit_out, t_out, sched, sched_cap);
   return check_launch("k_cast_batched");

@@ -259,6 +259,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
   if (n <= 0) return 0;
   RB_REQUIRE(precision >= 0 && precision <= 6, "precision: 0 = fp32 MFMA, 1 = f16x3 split (2 / 3: accumulator-chain variants)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
+  RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
     hipLaunchKernelGGL((k_dvis_fused<false, 1, 2>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,

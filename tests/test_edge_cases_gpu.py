@@ -89,3 +89,20 @@ def test_secondary_all_miss_and_octree_vis_model(dev, model):
     d2 = -p2 / p2.norm(dim=-1, keepdim=True)
     v2 = vm(p2, d2.contiguous())
     assert float(v2[:, 0].min()) == 1.0 and float(v2[:, 1].max()) == 0.0
+
+
+def test_oversized_launch_fails_loudly(dev):
+    """A dispatch holds its grid size in work-items as a 32-bit number; a request beyond that must come back as an error,
+    not as a grid whose tail never runs (that is how a 20 M-point colour batch went wrong before the guard)."""
+    import ctypes
+    from robir_amd import _lib
+    x = torch.zeros(16, 3, device=dev)
+    shift = torch.full((1, 1), 0.5, device=dev)
+    y = torch.zeros(16, 3, device=dev)
+    with pytest.raises(_lib.RobirHipError):
+        _lib.call("rb_tonemap", _lib.ptr(x), ctypes.c_long(1 << 40), _lib.ptr(shift), ctypes.c_int(0), ctypes.c_int(0),
+                  _lib.ptr(y), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    # the library is usable afterwards
+    from robir_amd import ops
+    assert ops.tonemap(x + 0.25, shift, 0).shape == (16, 3)
