@@ -175,3 +175,44 @@ def test_config1_sdf_forward_64x64x64(dev, synth_weights):
     assert full.shape == (64 * 64 * 64, 257) and bool(torch.isfinite(full).all())
     part = torch.cat([net(pts[i:i + 1024]) for i in range(0, 8192, 1024)])
     assert torch.equal(part, full[:8192])
+
+
+def test_config5_cesr_chunks_of_1600x1200(dev):
+    """truck-sized view (1600x1200 = 1875 chunks) with the CESR hook (shadow_net over 128 one-hot lobe labels per hit,
+    normal_net, 8-sample light visibility): 6 chunks across the image through forward(), the reference's call shape --
+    determinism with shared draws, fill value on missed rays, value ranges."""
+    from robir_amd import nets, renderer, synth
+    c = synth.synth_cesr_nets(0)
+    shadow = nets.SDFNetwork(63 + 128, 2, 512, 8, [4], 0)
+    normal = nets.SDFNetwork(63, 3, 512, 8, [4], 0)
+    shadow.load_state_dict({k: torch.from_numpy(v) for k, v in c["shadow_net"].items()})
+    normal.load_state_dict({k: torch.from_numpy(v) for k, v in c["normal_net"].items()})
+    m = renderer.build_synthetic_model(dev)
+    m.get_sg_render = renderer.CESRHook(m, shadow.to(dev).eval(), normal.to(dev).eval(), is_training=False, cur_iter=100000,
+                                        prefit="explore")
+    uv, pose, K = synth.synth_camera(1200, 1600)
+    assert uv.shape[0] == 1600 * 1200
+    pose_d, K_d = torch.from_numpy(pose).to(dev)[None], torch.from_numpy(K).to(dev)[None]
+    n_hit_total = 0
+    for cidx in (0, 700, 930, 937, 940, 1874):
+        sl = slice(cidx * 1024, (cidx + 1) * 1024)
+        inp = {"uv": torch.from_numpy(uv[sl]).to(dev)[None], "pose": pose_d, "intrinsics": K_d,
+               "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+               "hdr_shift": torch.full((1024, 1), 0.5, device=dev)}
+        o0 = m(inp, trainstage="IDR")
+        n_hit = int(o0["network_object_mask"].sum())
+        n_hit_total += n_hit
+        dr = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(3, n_hit, chunk_id=cidx, nsamp_diffuse=8).items()}
+        a = m(inp, trainstage="Material", lin_diff=True, train_spec=True, draws=dr)
+        b = m(inp, trainstage="Material", lin_diff=True, train_spec=True, draws=dr)
+        hit = a["network_object_mask"]
+        assert torch.equal(hit, o0["network_object_mask"])
+        for k in ("sg_rgb", "indir_rgb", "vis_shadow", "normal_map", "diffuse_albedo", "roughness"):
+            ok = ~torch.isnan(a["points"][:, 0])
+            assert _same(a[k], b[k]), k
+            assert bool(torch.isfinite(a[k][ok]).all()), k
+            assert bool((a[k][~hit & ok] == 1.0).all()), k
+        if n_hit:
+            assert float(a["vis_shadow"][hit].min()) >= 0.0 and float(a["vis_shadow"][hit].max()) <= 1.0 + 1e-6
+            assert float((a["normal_map"][hit].norm(dim=-1) - 1.0).abs().max()) < 1e-4
+    assert n_hit_total > 1500          # the central chunks are on the object, the corner chunks are all-miss
