@@ -108,11 +108,11 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
  *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
  *   precision 0: hidden layers on the f32-input MFMA (exact fp32 fma chain), Whid from rb_pack_layer;
- *   precision 1..5: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
- *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2.  5 = fastest
- *                (1 tile per wave, 2 workgroups per CU, LDS-DMA weight ring); 4 = same with register staging;
- *                1,2,3 = 2 tiles per wave with 2 / 1 / 3 accumulator chains.  All give identical results up to fp32
- *                summation order.
+ *   precision 1, 4, 5: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
+ *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2.  5 = 1 tile per wave,
+ *                2 workgroups per CU, LDS-DMA weight ring; 4 = same with register staging; 1 = 2 tiles per wave, one
+ *                workgroup per CU.  All give identical results up to fp32 summation order.  The production path is
+ *                rb_dvis_fused_v2 below.
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream);

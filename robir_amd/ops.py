@@ -159,10 +159,8 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     # "f16x3-v2" (default of sg_render) = second-generation kernel: two tiles per wave, one workgroup per CU, head on
     # the matrix pipe (csrc/vis_diffuse_v2.hip);
     # "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA;
-    # "f16x3-regstage" = same with global->VGPR->LDS staging; "-nt2*" = two tiles per wave, one workgroup per CU,
-    # with 2 / 1 / 3 accumulator chains per tile
-    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-nt2-1chain": 2, "f16x3-nt2-3chain": 3, "f16x3-regstage": 4,
-            "f16x3": 5, "f16x3-nt2-dma": 6, "f16x3-v2": 7,}[precision]
+    # "f16x3-regstage" = same with global->VGPR->LDS staging; "f16x3-nt2" = two tiles per wave, one workgroup per CU
+    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
