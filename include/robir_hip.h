@@ -38,8 +38,8 @@ const char* rb_last_error(void);
 long rb_packed_layer_floats(int n_pad, int k_pad);
 /* split-precision packing: weights (and bias) scaled by 2^scale_log2, stored as hi/lo half pairs; k_pad % 32 == 0;
  * same size as the fp32 packing. */
-int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, int scale_log2,
-                     float* out, rb_stream_t stream);
+int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* perm,
+                     int scale_log2, float* out, rb_stream_t stream);
 int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
                   float w_scale, float* out, rb_stream_t stream);
 
@@ -64,6 +64,8 @@ int rb_feat_color(const float* x, float x_scale, const float* view, const float*
 /* VisNetwork.forward (implicit_differentiable_renderer.py:250-258): X[M,128] -> logits[M,2].
  * Wp: packed [128->256, 256->256 x3, 256->16]. */
 int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream);
+/* Same with split-precision (f16x3) layers: Wp = the five layers packed by rb_pack_layer_h3 with scale 2^scale_log2. */
+int rb_vis_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* logits, rb_stream_t stream);
 /* One linear layer X[M,64] -> Y[M,256] (packed 64->256); used to factor the visibility net's first layer. */
 int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream);
 /* SDFNetwork.forward / .gradient (model/neus_model.py:385-438), ImplicitNetworkMy.forward/.gradient (:788-818).
@@ -74,11 +76,17 @@ int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_strea
  * Softplus(beta=100) is evaluated with the hardware exp/log/rcp (a few ulp); modes 4 and 6 are modes 0 and 2 with the
  * library expf/log1pf instead -- the octree build uses them because its split / hit thresholds must fall exactly where
  * the reference's do. */
+/* Split-precision (f16x3) form of modes 0..3: Wp = the nine layers packed by rb_pack_layer_h3 with k_pad 64, 256, 256, 256,
+ * 288 (skip layer: [208 | 64 | 16 zero slots]), 256 x4 and one scale 2^scale_log2. */
+int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
+                  float* out0, float* grad, rb_stream_t stream);
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);
+/* Split-precision (f16x3) form: Wp = the five layers packed by rb_pack_layer_h3 (first layer k_pad 320, same permutation). */
+int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
 /* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
  * Wp packed [64->512, 512->512 x3, 512->144]. */
 int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream);

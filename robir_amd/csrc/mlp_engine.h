@@ -240,6 +240,109 @@ __device__ __forceinline__ void relu_split(const float (&z)[NT][N / 4], float un
       }
 }
 
+// hi/lo split of two fp32 values in 3 VALU ops: packed round-toward-zero hi halves, then lo = f16(v - float(hi)) with the
+// mixed-precision fma (f16 source read straight from the packed register, result written to one half of `lo`)
+__device__ __forceinline__ void split_pair_mix(float v0, float v1, unsigned& hi, unsigned& lo) {
+  const h2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  const unsigned hu = __builtin_bit_cast(unsigned, h);
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hu), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hu), "v"(v1));
+  hi = hu;
+  lo = l;
+}
+
+// fp32 activations of a layer (C layout, KV = 4 * NF valid values per lane-row, zero-padded up to K) -> packed hi/lo
+// operands of the next split-precision layer: k-block kb <- output blocks 2kb, 2kb+1 (register pairs 2e + r/2).
+// `scale` (a power of two, may differ per lane) lifts the values into the range where both halves are normal f16 numbers:
+// an (hi, lo) pair has an absolute resolution of 2^-25, i.e. full fp32-like relative precision only for |v| >~ 0.1.
+template <int K, int NF, int NT>
+__device__ __forceinline__ void split_operands(const float (&h)[NT][NF], unsigned (&hi)[NT][K / 32][4],
+                                               unsigned (&lo)[NT][K / 32][4], float scale = 1.0f) {
+  static_assert(K % 32 == 0 && NF * 4 <= K, "K must be a multiple of 32 that covers the activations");
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int kb = 0; kb < K / 32; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
+        const float v0 = i < NF ? h[t][i < NF ? i : 0] : 0.f, v1 = i + 1 < NF ? h[t][i + 1 < NF ? i + 1 : 0] : 0.f;
+        split_pair_mix(v0 * scale, v1 * scale, hi[t][kb][q], lo[t][kb][q]);
+      }
+}
+
+// act(z * unscale) of a whole layer -> packed operands of the next one (3-op split)
+template <int N, int NT, int ACT>
+__device__ __forceinline__ void act_split(const float (&z)[NT][N / 4], float unscale, unsigned (&hi)[NT][N / 32][4],
+                                          unsigned (&lo)[NT][N / 32][4], float scale = 1.0f) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int kb = 0; kb < N / 32; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
+        split_pair_mix(act_fn<ACT>(z[t][i] * unscale) * scale, act_fn<ACT>(z[t][i + 1] * unscale) * scale, hi[t][kb][q],
+                       lo[t][kb][q]);
+      }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-precision counterpart of dense_layer: same weight stream (an f16x3 chunk has the byte size of the fp32 chunk of
+// the same K), operands as packed hi/lo halves, one fp32 accumulator per tile (two tiles alternate, so consecutive
+// MFMAs never share an accumulator).  out = 2^s * (W.x + b): the caller un-scales (rb_pack_layer_h3 scale).
+// ---------------------------------------------------------------------------------------------------------
+template <int K, int N, int NT, int NEXTK, class WS>
+__device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl, const f4* __restrict__ wnext,
+                                               const unsigned (&xh)[NT][K / 32][4], const unsigned (&xl)[NT][K / 32][4],
+                                               float (&out)[NT][N / 4], int lane, float bias_mul) {
+  // bias_mul: 0 for rows without bias (tangent columns), otherwise the scale the operands of this lane carry
+  static_assert(K % 32 == 0 && N % 16 == 0 && NT == 2, "split-precision layers: K % 32 == 0, two tiles per wave");
+  constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
+  const int g = lane >> 4;
+#pragma unroll
+  for (int jb = 0; jb < NJB; ++jb) {
+    if (jb + 1 < NJB) {
+      ws.template prefetch<CF4>(wl + (jb + 1) * CF4);
+    } else {
+      if constexpr (NCF4 > 0) ws.template prefetch<NCF4>(wnext);
+    }
+    const f4* cw = ws.chunk();
+    const f4 bias = cw[g] * bias_mul;
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = bias;
+    const u4* cu = reinterpret_cast<const u4*>(cw + 4) + lane;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const h8 wh = __builtin_bit_cast(h8, cu[(2 * kb) * 64]);
+      const h8 wlo = __builtin_bit_cast(h8, cu[(2 * kb + 1) * 64]);
+      h8 a[NT], b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
+        b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][jb * 4 + r] = acc[t][r];
+    if (jb + 1 < NJB) {
+      ws.template commit<CF4>();
+    } else {
+      ws.template commit<NCF4>();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Software-pipelined weight ring for the split-precision hidden stack (fused light-visibility kernel).
 // A chunk = 16 output neurons x K=256 (bias + hi/lo half fragments, chunk_f4(256) float4s).  The chunk stream of the

@@ -51,6 +51,16 @@ def _dev(module):
 
 
 # ----------------------------------------------------------------------------------------- visibility
+def mlp_precision():
+    """Arithmetic of the stand-alone MLP kernels: 'f16x3' (default; split-precision f16 MFMA, fp32 accumulate, ~2^-22
+    relative error) or 'fp32' (exact f32-input MFMA).  Environment: ROBIR_MLP_PRECISION."""
+    import os
+    p = os.environ.get("ROBIR_MLP_PRECISION", "f16x3")
+    if p not in ("f16x3", "fp32"):
+        raise ValueError("ROBIR_MLP_PRECISION must be f16x3 or fp32")
+    return p
+
+
 class VisNetwork(nn.Module):
     """implicit_differentiable_renderer.py:225-258."""
 
@@ -73,13 +83,22 @@ class VisNetwork(nn.Module):
     def packed_full(self):
         return self._packed.get("full", self, lambda sd: packing.pack_vis(self._rename(sd), _dev(self)))
 
+    def packed_full_h3(self):
+        return self._packed.get("full_h3", self, lambda sd: packing.pack_vis_h3(self._rename(sd), _dev(self)))
+
     def packed_split(self):
         return self._packed.get("split", self, lambda sd: packing.pack_vis_split(self._rename(sd), _dev(self)))
+
+    def logits_from_features(self, X):
+        """X [M,128] = [PE10(p) | PE10(d)] (ops.feat_vis) -> logits [M,2]; arithmetic per robir_amd.MLP_PRECISION."""
+        if mlp_precision() == "fp32":
+            return ops.vis_mlp(X, self.packed_full())
+        return ops.vis_mlp_h3(X, self.packed_full_h3(), packing.H3_SCALE_LOG2)
 
     def forward(self, points, view_dirs):
         if points.shape[0] == 0:
             return torch.zeros(0, 2, device=points.device)
-        return ops.vis_mlp(ops.feat_vis(points.float().contiguous(), view_dirs.float().contiguous()), self.packed_full())
+        return self.logits_from_features(ops.feat_vis(points.float().contiguous(), view_dirs.float().contiguous()))
 
 
 # ----------------------------------------------------------------------------------------- sparse auto-encoder
@@ -326,6 +345,11 @@ class SDFNetwork(nn.Module):
         return self._packed.get("w512", self, lambda sd: packing.pack_softplus512(
             {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
 
+    def packed_h3(self, full=True):
+        assert self.kind == "neus"
+        return self._packed.get("full_h3" if full else "sdf_h3", self,
+                                lambda sd: packing.pack_sdf_h3(self._sd(sd), _dev(self), full=full))
+
     def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False, precise=False):
         """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
         precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
@@ -335,6 +359,8 @@ class SDFNetwork(nn.Module):
         assert not (precise and full)
         mode = (1 if full else 0) + (2 if grad else 0) + (4 if precise else 0)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
+        if not precise and mlp_precision() == "f16x3":
+            return ops.sdf_mlp_h3(X, M, self.packed_h3(full), mode, packing.H3_SCALE_LOG2, out_scale, out_scale * in_scale)
         return ops.sdf_mlp(X, M, self.packed(full), mode, out_scale, out_scale * in_scale)
 
     def eval_point_labels(self, Xp, n_label=128):
@@ -384,9 +410,15 @@ class RenderingNetwork(nn.Module):
         return self._packed.get("c", self, lambda sd: packing.pack_color(
             {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
 
+    def packed_h3(self):
+        return self._packed.get("c_h3", self, lambda sd: packing.pack_color_h3(
+            {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
+
     def forward(self, points, normals, view_dirs, feature_vectors, x_scale=1.0, feat_scale=1.0):
         X = ops.feat_color(points.float().contiguous(), view_dirs.float().contiguous(), normals.float().contiguous(),
                            feature_vectors, x_scale=x_scale, feat_scale=feat_scale)
+        if mlp_precision() == "f16x3":
+            return ops.color_mlp_h3(X, self.packed_h3(), packing.H3_SCALE_LOG2)
         return ops.color_mlp(X, self.packed())
 
 

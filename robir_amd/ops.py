@@ -60,6 +60,13 @@ def vis_mlp(X, blob):
     return Y
 
 
+def vis_mlp_h3(X, blob, scale_log2):
+    M = X.shape[0]
+    Y = torch.empty(M, 2, dtype=torch.float32, device=X.device)
+    call("rb_vis_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(scale_log2), ptr(Y), stream_ptr())
+    return Y
+
+
 def linear_64_256(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 256, dtype=torch.float32, device=X.device)
@@ -76,11 +83,27 @@ def sdf_mlp(X, M, blob, mode, out_scale=1.0, grad_scale=1.0):
     return out0, grad
 
 
+def sdf_mlp_h3(X, M, blob, mode, scale_log2, out_scale=1.0, grad_scale=1.0):
+    full = mode in (1, 3)
+    out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=X.device)
+    grad = torch.empty(M, 3, dtype=torch.float32, device=X.device) if mode >= 2 else None
+    call("rb_sdf_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(mode), c_int(scale_log2), c_float(out_scale),
+         c_float(grad_scale), ptr(out0), ptr(grad), stream_ptr())
+    return out0, grad
+
+
 def color_mlp(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 3, dtype=torch.float32, device=X.device)
     call("rb_color_mlp", ptr(X), c_long(M), ptr(blob), ptr(Y), stream_ptr())
     return Y
+
+
+def color_mlp_h3(X, blob, scale_log2):
+    M = X.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=X.device)
+    call("rb_color_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(scale_log2), ptr(rgb), stream_ptr())
+    return rgb
 
 
 def illum_mlp(X, blob):

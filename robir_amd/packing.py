@@ -62,9 +62,13 @@ def pack_layers_h3(layers, device, scale_log2=H3_SCALE_LOG2):
     for l, sz in zip(layers, sizes):
         W = l["W"].to(device=device, dtype=torch.float32).contiguous()
         b = l["b"].to(device=device, dtype=torch.float32).contiguous() if l.get("b") is not None else None
-        keep += [W, b]
+        perm = None
+        if l.get("perm") is not None:
+            perm = torch.tensor(l["perm"], dtype=torch.int32, device=device)
+            assert perm.numel() == l["k_pad"]
+        keep += [W, b, perm]
         _lib.call("rb_pack_layer_h3", _lib.ptr(W), _lib.ptr(b), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
-                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), ctypes.c_int(scale_log2),
+                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), _lib.ptr(perm), ctypes.c_int(scale_log2),
                   ctypes.c_void_p(blob[off:off + sz].data_ptr()), _lib.stream_ptr())
         off += sz
     torch.cuda.current_stream().synchronize()
@@ -83,6 +87,15 @@ def pack_vis(sd, device):
         W, b = _t(sd, VIS + "%d.weight" % (2 * i)), _t(sd, VIS + "%d.bias" % (2 * i))
         ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad16(W.shape[1])))
     return pack_layers(ls, device)
+
+
+def pack_vis_h3(sd, device):
+    """Same five layers in split-precision form (rb_vis_mlp_h3)."""
+    ls = []
+    for i in range(5):
+        W, b = _t(sd, VIS + "%d.weight" % (2 * i)), _t(sd, VIS + "%d.bias" % (2 * i))
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=(W.shape[1] + 31) // 32 * 32))
+    return pack_layers_h3(ls, device)
 
 
 def pack_vis_split(sd, device):
@@ -120,6 +133,27 @@ def pack_sdf(sd, device, full=True):
     return pack_layers(ls, device)
 
 
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def pack_sdf_h3(sd, device, full=True):
+    """pack_sdf in split-precision form (rb_sdf_mlp_h3): K padded to multiples of 32, the skip layer to 288 slots."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
+    ls = []
+    for l in range(9):
+        W = _fold_wn(sdt, SDF + "lin%d." % l)
+        b = sdt[SDF + "lin%d.bias" % l].float()
+        n_pad, k_pad, perm = _pad16(W.shape[0]), _pad32(W.shape[1]), None
+        if l == 4:   # input = cat[act(lin3) (193), PE (63)] -> packed order [208 slots | 64 slots | 16 zero slots]
+            k_pad = 288
+            perm = [k if k < 193 else -1 for k in range(208)] + [193 + j if j < 63 else -1 for j in range(64)] + [-1] * 16
+        if l == 8 and not full:
+            W, b, n_pad = W[:1].contiguous(), b[:1].contiguous(), 16
+        ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
+    return pack_layers_h3(ls, device)
+
+
 def pack_color(sd, device):
     """[304->256 (cols permuted to [feat|x|PE4(view)|normal]), 256->256 x3, 256->16]  (neus_model.py:511-531)."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}
@@ -132,6 +166,20 @@ def pack_color(sd, device):
             perm = [33 + k for k in range(256)] + list(range(33)) + [-1] * 15
         ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=304 if l == 0 else _pad16(W.shape[1]), perm=perm))
     return pack_layers(ls, device)
+
+
+def pack_color_h3(sd, device):
+    """pack_color in split-precision form (rb_color_mlp_h3): first layer padded to 320 slots."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}
+    ls = []
+    for l in range(5):
+        W = _fold_wn(sdt, COL + "lin%d." % l)
+        b = sdt[COL + "lin%d.bias" % l].float()
+        perm = None
+        if l == 0:
+            perm = [33 + k for k in range(256)] + list(range(33)) + [-1] * 31
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=320 if l == 0 else _pad32(W.shape[1]), perm=perm))
+    return pack_layers_h3(ls, device)
 
 
 def pack_illum(sd, device):

@@ -136,7 +136,7 @@ def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p,
     n, nsamp = u_t.shape
     dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
     if isinstance(VisModel, VisNetwork):
-        logits = ops.vis_mlp(ops.feat_vis(points.float().contiguous(), dirs, rep=nsamp), VisModel.packed_full())
+        logits = VisModel.logits_from_features(ops.feat_vis(points.float().contiguous(), dirs, rep=nsamp))
     else:
         logits = VisModel(points.unsqueeze(1).expand(-1, nsamp, 3).reshape(-1, 3), dirs).float().contiguous()
     return ops.spec_vis_reduce(logits, front, wts, n, nsamp, inv, argmax_vis, testing)

@@ -60,6 +60,12 @@ def test_vis_mlp(dev, pts_dirs, synth_weights, oracle_sd):
     g = load_golden("nets")
     out = ops.vis_mlp(ops.feat_vis(torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)), blob).cpu()
     assert rel_err(out, g["vis_logits"]) <= TOL          # against the reference's own output
+    # split-precision (f16x3) form of the same kernel: same tolerance, and ~1e-6 from the exact-fp32 MFMA path
+    blob3 = packing.pack_vis_h3(synth_weights, dev)
+    X = ops.feat_vis(torch.from_numpy(g["pts"]).to(dev), torch.from_numpy(g["dirs"]).to(dev))
+    out3 = ops.vis_mlp_h3(X, blob3, packing.H3_SCALE_LOG2).cpu()
+    assert rel_err(out3, g["vis_logits"]) <= TOL
+    assert rel_err(out3, out) <= 1e-5
 
 
 def test_linear_split_layer(dev, pts_dirs, synth_weights):
@@ -93,6 +99,25 @@ def test_sdf_mlp(dev, pts_dirs, synth_weights, oracle_sd, mode):
         assert rel_err(grad.cpu(), nets.implicit_gradient(oracle_sd, pts)) <= TOL
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_sdf_mlp_split_precision(dev, pts_dirs, synth_weights, oracle_sd, mode):
+    """f16x3 form of the SDF kernels: same tolerance against the oracle, and fp32-rounding-level distance from the exact path."""
+    from robir_amd import ops, packing
+    from robir_oracle import nets
+    pts, _ = pts_dirs
+    full = mode in (1, 3)
+    X = ops.feat_pe10(pts.to(dev), scale=2.0, jvp=mode >= 2)
+    out0, grad = ops.sdf_mlp_h3(X, pts.shape[0], packing.pack_sdf_h3(synth_weights, dev, full=full), mode,
+                                packing.H3_SCALE_LOG2, out_scale=0.5, grad_scale=1.0)
+    ex0, exg = ops.sdf_mlp(X, pts.shape[0], packing.pack_sdf(synth_weights, dev, full=full), mode, out_scale=0.5, grad_scale=1.0)
+    ref = nets.implicit_forward(oracle_sd, pts)
+    assert rel_err(out0.cpu(), ref if full else ref[:, 0]) <= TOL
+    assert rel_err(out0.cpu(), ex0.cpu()) <= 1e-5
+    if mode >= 2:
+        assert rel_err(grad.cpu(), nets.implicit_gradient(oracle_sd, pts)) <= TOL
+        assert rel_err(grad.cpu(), exg.cpu()) <= 1e-5
+
+
 def test_sdf_golden(dev, synth_weights):
     from robir_amd import ops, packing
     g = load_golden("nets")
@@ -112,6 +137,8 @@ def test_color_mlp(dev, synth_weights):
     X = ops.feat_color(pts, dirs, nrm, feat[:, 1:], x_scale=2.0, feat_scale=2.0)
     rgb = ops.color_mlp(X, packing.pack_color(synth_weights, dev)).cpu()
     assert rel_err(rgb, g["color"]) <= TOL
+    rgb3 = ops.color_mlp_h3(X, packing.pack_color_h3(synth_weights, dev), packing.H3_SCALE_LOG2).cpu()
+    assert rel_err(rgb3, g["color"]) <= TOL and rel_err(rgb3, rgb) <= 1e-5
 
 
 def test_illum_and_autoencoders(dev, synth_weights):

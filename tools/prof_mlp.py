@@ -38,3 +38,9 @@ timeit("sdf full (257 outputs)", lambda: imp(x))
 timeit("sdf gradient (jvp)", lambda: imp.gradient(x))
 timeit("indirect illum net", lambda: model.indirect_illum_network(x, hdr))
 timeit("material net", lambda: model.envmap_material_network(x, train_spec=True))
+d = torch.nn.functional.normalize(torch.rand(n * 16, 3, device=dev, generator=g) - 0.5, dim=-1)
+X = __import__("robir_amd").ops.feat_vis(x, d, rep=16)
+from robir_amd import ops, packing  # noqa: E402
+vn = model.visibility_network
+timeit("vis MLP fp32 (16 dirs/pt)", lambda: ops.vis_mlp(X, vn.packed_full()))
+timeit("vis MLP f16x3 (16 dirs/pt)", lambda: ops.vis_mlp_h3(X, vn.packed_full_h3(), packing.H3_SCALE_LOG2))
