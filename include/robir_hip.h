@@ -89,6 +89,9 @@ int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_
 int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
 /* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
  * Wp packed [64->512, 512->512 x3, 512->144]. */
+/* Split-precision (f16x3) form of rb_illum_mlp (encoder = 0, raw[M,144]) and rb_ae_encode (encoder = 1, raw_latent[M,32]):
+ * Wp = the five layers packed by rb_pack_layer_h3 with one scale. */
+int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, rb_stream_t stream);
 int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream);
 /* raw[M,24,6] -> lgt_sgs[M,24,7] (implicit_differentiable_renderer.py:208-218). */
 int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);

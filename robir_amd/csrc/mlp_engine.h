@@ -297,9 +297,12 @@ template <int K, int N, int NT, int NEXTK, class WS>
 __device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl, const f4* __restrict__ wnext,
                                                const unsigned (&xh)[NT][K / 32][4], const unsigned (&xl)[NT][K / 32][4],
                                                float (&out)[NT][N / 4], int lane, float bias_mul) {
-  // bias_mul: 0 for rows without bias (tangent columns), otherwise the scale the operands of this lane carry
-  static_assert(K % 32 == 0 && N % 16 == 0 && NT == 2, "split-precision layers: K % 32 == 0, two tiles per wave");
+  // bias_mul: 0 for rows without bias (tangent columns), otherwise the scale the operands of this lane carry.
+  // Accumulators: two tiles alternate on one chain each; a single tile uses one chain per product (hi*lo, hi*hi, lo*hi)
+  // so that consecutive MFMAs never wait on each other.
+  static_assert(K % 32 == 0 && N % 16 == 0 && (NT == 1 || NT == 2), "split-precision layers: K % 32 == 0, 1 or 2 tiles");
   constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
+  constexpr int CH = NT == 1 ? 3 : 1;
   const int g = lane >> 4;
 #pragma unroll
   for (int jb = 0; jb < NJB; ++jb) {
@@ -310,9 +313,13 @@ __device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl
     }
     const f4* cw = ws.chunk();
     const f4 bias = cw[g] * bias_mul;
-    f4 acc[NT];
+    f4 acc[NT][CH];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = bias;
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = bias;
+#pragma unroll
+      for (int c = 1; c < CH; ++c) acc[t][c] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     const u4* cu = reinterpret_cast<const u4*>(cw + 4) + lane;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -325,16 +332,21 @@ __device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl
         b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t)
+        acc[t][CH == 3 ? 1 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc[t][CH == 3 ? 1 : 0], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc[t][0], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t)
+        acc[t][CH == 3 ? 2 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc[t][CH == 3 ? 2 : 0], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      f4 r = acc[t][0];
+      if constexpr (CH == 3) r = r + (acc[t][1] + acc[t][2]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[t][jb * 4 + r] = acc[t][r];
+      for (int q = 0; q < 4; ++q) out[t][jb * 4 + q] = r[q];
+    }
     if (jb + 1 < NJB) {
       ws.template commit<CF4>();
     } else {

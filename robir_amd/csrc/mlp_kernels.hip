@@ -700,6 +700,52 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp(const float* __restrict__ X
   }
 }
 
+// Split-precision (f16x3) form of the 512-wide nets: Wp from rb_pack_layer_h3 (64->512, 512->512 x3, 512->NO; output rows
+// padded to 16), operands lifted by 2^4 before the hi/lo split.
+template <bool ENC>
+__global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
+                                                         float us, float* __restrict__ Y) {
+  constexpr int NO = ENC ? 32 : 144;
+  constexpr int ACT = ENC ? ACT_LEAKY02 : ACT_RELU;
+  constexpr float AS = 16.0f;
+  __shared__ f4 lds[2 * chunk_f4(512)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WStream<512> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<512, 512>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<64, 512>();
+  const f4* w4 = w1 + 3 * LF;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const float zs = us * (1.0f / AS);
+  float z[1][128];
+  unsigned xh[1][16][4], xl[1][16][4];
+  {
+    float in0[1][16];
+    load_features<64>(X, row, M, lane, in0[0]);
+    unsigned ih[1][2][4], il[1][2][4];
+    split_operands<64, 16, 1>(in0, ih, il, AS);
+    ws.prime<chunk_f4(64)>(w0);
+    dense_layer_h3<64, 512, 1, 512>(ws, w0, w1, ih, il, z, lane, AS);
+  }
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    act_split<512, 1, ACT>(z, zs, xh, xl, AS);
+    dense_layer_h3<512, 512, 1, 512>(ws, w1 + l * LF, w1 + (l + 1) * LF, xh, xl, z, lane, AS);
+  }
+  act_split<512, 1, ACT>(z, zs, xh, xl, AS);
+  float o[1][NO / 4];
+  dense_layer_h3<512, NO, 1, 0>(ws, w4, nullptr, xh, xl, o, lane, AS);
+  if (row < M) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int jb = 0; jb < NO / 16; ++jb) {
+      f4* dst = reinterpret_cast<f4*>(Y + row * NO + jb * 16) + g;
+      *dst = f4{o[0][jb * 4] * zs, o[0][jb * 4 + 1] * zs, o[0][jb * 4 + 2] * zs, o[0][jb * 4 + 3] * zs};
+    }
+  }
+}
+
 // ---- SparseAE decoder (sg_envmap_material.py:61-68): 32 -> 128 -> 128 LeakyReLU(0.2) -> n_out(16)
 __global__ __launch_bounds__(256, 1) void k_ae_decode(const float* __restrict__ L, long M, const f4* __restrict__ Wp,
                                                        int n_out, int sigmoid_out, float* __restrict__ Y) {
@@ -1019,6 +1065,18 @@ int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_
   RB_REQUIRE(X && Wp && raw, "null pointer");
   hipLaunchKernelGGL(k_wide_mlp<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, raw);
   return check_launch("k_wide_mlp<illum>");
+}
+
+int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && Y, "null pointer");
+  const float us = ldexpf(1.0f, -scale_log2);
+  if (encoder) {
+    hipLaunchKernelGGL(k_wide_mlp_h3<true>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y);
+  } else {
+    hipLaunchKernelGGL(k_wide_mlp_h3<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y);
+  }
+  return check_launch("k_wide_mlp_h3");
 }
 
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream) {

@@ -133,6 +133,13 @@ class SparseAE(nn.Module):
         return self._packed.get("ae", self, lambda sd: packing.pack_sparse_ae(
             {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
 
+    def _encode(self, X):
+        if mlp_precision() == "f16x3":
+            blob = self._packed.get("enc_h3", self, lambda sd: packing.pack_sparse_ae_encoder_h3(
+                {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
+            return ops.wide_mlp_h3(X, blob, True, packing.H3_SCALE_LOG2)
+        return ops.ae_encode(X, self._blobs()[0])
+
     def _latent_act_code(self):
         name = getattr(self.lc_act, "__name__", "")
         if name == "softplus":
@@ -156,12 +163,12 @@ class SparseAE(nn.Module):
         if sig_out and getattr(self.out_act, "__name__", "") != "sigmoid":
             raise NotImplementedError("out_act must be torch.sigmoid or None")
         if self.smooth_on_latent:
-            lat, lat2 = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code(), noise, 0.01)
+            lat, lat2 = ops.ae_latent(self._encode(X), self._var(dev), self._latent_act_code(), noise, 0.01)
         else:
-            lat2, _ = ops.ae_latent(ops.ae_encode(X_noisy, enc), self._var(dev), self._latent_act_code())
+            lat2, _ = ops.ae_latent(self._encode(X_noisy), self._var(dev), self._latent_act_code())
             if not need_first:
                 return None, ops.ae_decode(lat2, dec, self.out_dim, sig_out)
-            lat, _ = ops.ae_latent(ops.ae_encode(X, enc), self._var(dev), self._latent_act_code())
+            lat, _ = ops.ae_latent(self._encode(X), self._var(dev), self._latent_act_code())
         return ops.ae_decode(lat, dec, self.out_dim, sig_out), ops.ae_decode(lat2, dec, self.out_dim, sig_out)
 
     def forward(self, values, noise=None):
@@ -207,7 +214,12 @@ class IndirctIllumNetwork(nn.Module):
         blob = self._packed.get("lobe", self.lobe_layer, lambda sd: packing.pack_illum(
             {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
         X = ops.feat_pe10(points.float().contiguous(), extra=hdr_shift.float().contiguous())
-        sgs = ops.illum_decode(ops.illum_mlp(X, blob))
+        if mlp_precision() == "f16x3":
+            blob3 = self._packed.get("lobe_h3", self.lobe_layer, lambda sd: packing.pack_illum_h3(
+                {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
+            sgs = ops.illum_decode(ops.wide_mlp_h3(X, blob3, False, packing.H3_SCALE_LOG2))
+        else:
+            sgs = ops.illum_decode(ops.illum_mlp(X, blob))
         if noise is None:
             noise = torch.randn(n, 64, device=dev)
         Xn = ops.axpy(X, noise.float().contiguous(), 0.02)

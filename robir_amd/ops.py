@@ -113,6 +113,14 @@ def illum_mlp(X, blob):
     return raw
 
 
+def wide_mlp_h3(X, blob, encoder, scale_log2):
+    """Split-precision 512-wide nets: encoder=False -> raw SG outputs [M,144]; encoder=True -> raw latent [M,32]."""
+    M = X.shape[0]
+    Y = torch.empty(M, 32 if encoder else 144, dtype=torch.float32, device=X.device)
+    call("rb_wide_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(1 if encoder else 0), c_int(scale_log2), ptr(Y), stream_ptr())
+    return Y
+
+
 def illum_decode(raw):
     M = raw.shape[0]
     sgs = torch.empty(M, 24, 7, dtype=torch.float32, device=raw.device)

@@ -190,6 +190,24 @@ def pack_illum(sd, device):
     return pack_layers(ls, device)
 
 
+def pack_illum_h3(sd, device):
+    ls = []
+    for i in range(5):
+        W, b = _t(sd, ILL + "lobe_layer.%d.weight" % (2 * i)), _t(sd, ILL + "lobe_layer.%d.bias" % (2 * i))
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad32(W.shape[1])))
+    return pack_layers_h3(ls, device)
+
+
+def pack_sparse_ae_encoder_h3(sd, prefix, device):
+    """Encoder [64->512, 512->512 x3, 512->32] in split-precision form (rb_wide_mlp_h3); the small decoder stays fp32."""
+    enc = []
+    for i in range(5):
+        W = _t(sd, prefix + ".brdf_encoder_layer.%d.weight" % (2 * i))
+        b = _t(sd, prefix + ".brdf_encoder_layer.%d.bias" % (2 * i))
+        enc.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=_pad32(W.shape[1])))
+    return pack_layers_h3(enc, device)
+
+
 def pack_sparse_ae(sd, prefix, device):
     """-> (encoder blob [64->512, 512->512 x3, 512->32], decoder blob [32->128, 128->128, 128->16])."""
     enc, dec = [], []

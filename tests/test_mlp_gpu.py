@@ -172,3 +172,25 @@ def test_illum_and_autoencoders(dev, synth_weights):
     nm2 = ops.ae_decode(lat, dec, 3, False).cpu()
     nm2 = nm2 / torch.clamp(nm2.norm(dim=-1, keepdim=True), 1e-4)
     assert rel_err(nm2, g["mat_random_xi_normal"]) <= TOL
+
+
+def test_wide_nets_split_precision(dev, synth_weights):
+    """f16x3 forms of the 512-wide nets (indirect-illumination lobe net, SparseAE encoders): golden tolerance and
+    fp32-rounding-level distance from the exact kernels."""
+    from robir_amd import ops, packing
+    g = load_golden("nets")
+    pts = torch.from_numpy(g["pts"]).to(dev)
+    hdr = torch.from_numpy(g["hdr"]).to(dev)
+    X = ops.feat_pe10(pts, extra=hdr)
+    raw = ops.illum_mlp(X, packing.pack_illum(synth_weights, dev))
+    raw3 = ops.wide_mlp_h3(X, packing.pack_illum_h3(synth_weights, dev), False, packing.H3_SCALE_LOG2)
+    assert rel_err(raw3.cpu(), raw.cpu()) <= 1e-5
+    assert rel_err(ops.illum_decode(raw3).cpu(), g["illum_sgs"]) <= TOL
+    for prefix, feats in (("envmap_material_network.spec_brdf_encoder_layer", ops.feat_pe10(pts)),
+                          ("envmap_material_network.normal_decoder_layer", ops.feat_ipe(pts, 1e-5)),
+                          ("indirect_illum_network.integral_layer", X)):
+        enc, _ = packing.pack_sparse_ae(synth_weights, prefix, dev)
+        enc3 = packing.pack_sparse_ae_encoder_h3(synth_weights, prefix, dev)
+        a = ops.ae_encode(feats, enc).cpu()
+        b = ops.wide_mlp_h3(feats, enc3, True, packing.H3_SCALE_LOG2).cpu()
+        assert rel_err(b, a) <= 1e-5, prefix
