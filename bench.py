@@ -167,6 +167,8 @@ def main():
     if "ROBIR_VIS_PRECISION" not in os.environ:
         sg_render.VIS_PRECISION = args.vis_precision
     precision = sg_render.VIS_PRECISION
+    if precision == "fp32":        # exact f32-input MFMA everywhere, not only in the visibility kernel
+        os.environ.setdefault("ROBIR_MLP_PRECISION", "fp32")
     t0 = time.time()
     model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
     torch.cuda.synchronize()
@@ -233,7 +235,7 @@ def main():
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if precision == "fp32" else "f32 (visibility hidden layers: 3x f16 hi/lo-split MFMA, fp32 accumulate)",
+            "dtype": "f32" if precision == "fp32" else "f32 (MLP layers as 3x f16 hi/lo-split MFMA products, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "hotdog-like synthetic 800x800 full PBR forward (BASELINE.json configs[3]): "
                                    "625 lock-step chunks of 1024 px per view, one view per GPU",

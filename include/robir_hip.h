@@ -101,6 +101,9 @@ int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
  *         the one-hot block is synthesised in registers -> Y[M,2].
  * Wp packed [K0P->512, 512->512 x2, 512->N3P, 528->512 (cols [lin3 | input]), 512->512 x3, 512->16]. */
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
+/* Split-precision (f16x3) form: Wp = the nine layers packed by rb_pack_layer_h3 (skip layer k_pad 544). */
+int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,
+                   rb_stream_t stream);
 /* SparseAE (model/sg_envmap_material.py:40-99): encoder X[M,64] -> raw latent[M,32]
  * (packed [64->512, 512->512 x3, 512->32]); latent = act(raw*(1-var)) [+ lat2 = latent + noise*noise_scale];
  * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus. */

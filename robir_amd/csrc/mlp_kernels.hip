@@ -865,6 +865,91 @@ __global__ __launch_bounds__(256, 1) void k_softplus512(const float* __restrict_
   }
 }
 
+// Split-precision (f16x3) form: Wp from rb_pack_layer_h3 (k_pad: K0P, 512, 512, 512, 544 = [N3P | K0P | 16 zero slots],
+// 512 x4), operands lifted by 2^6 before the hi/lo split (softplus outputs are small), `us` = 2^-s.
+template <int K0P, int N3P, bool ONEHOT>
+__global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restrict__ X, long M, int n_label,
+                                                            const f4* __restrict__ Wp, float us, int n_out,
+                                                            float* __restrict__ Y) {
+  constexpr int K4 = N3P + K0P, K4P = 544;
+  static_assert(K4 == 528 && K0P % 32 == 0, "both CESR nets give a 528-wide skip layer");
+  constexpr float AS = 64.0f;
+  __shared__ f4 lds[2 * chunk_f4(K4P)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  WStream<K4P> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<512, 512>();
+  const f4* w0 = Wp;
+  const f4* w1 = w0 + layer_f4<K0P, 512>();
+  const f4* w3 = w1 + 2 * LF;
+  const f4* w4 = w3 + layer_f4<512, N3P>();
+  const f4* w5 = w4 + layer_f4<K4P, 512>();
+  const f4* w8 = w5 + 3 * LF;
+  const long row = ((long)blockIdx.x * 4 + wave) * 16 + (lane & 15);
+  const float inv_sqrt2 = 0.70710678118654752440f, zs = us * (1.0f / AS);
+  float x0[1][K0P / 4], z[1][128];
+  unsigned xh[1][16][4], xl[1][16][4];
+  if constexpr (ONEHOT) {
+    const bool ok = row < M;
+    const long pt = ok ? row / n_label : 0;
+    const int label = ok ? (int)(row % n_label) : -1;
+    const f4* p = reinterpret_cast<const f4*>(X + pt * 64) + g;
+#pragma unroll
+    for (int kb = 0; kb < K0P / 16; ++kb) {
+      f4 v = (kb < 4 && ok) ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = kb * 16 + 4 * g + r;
+        float e = v[r];
+        if (k == 63) e = 0.f;                       // column 63 of Xp is padding; the one-hot block starts here
+        if (k >= 63 && k - 63 == label) e = 1.f;
+        x0[0][kb * 4 + r] = e;
+      }
+    }
+  } else {
+    load_features<K0P>(X, row, M, lane, x0[0]);
+  }
+  {
+    unsigned ih[1][K0P / 32][4], il[1][K0P / 32][4];
+    split_operands<K0P, K0P / 4, 1>(x0, ih, il, AS);
+    ws.template prime<chunk_f4(K0P)>(w0);
+    dense_layer_h3<K0P, 512, 1, 512>(ws, w0, w1, ih, il, z, lane, AS);
+  }
+#pragma unroll 1
+  for (int l = 0; l < 2; ++l) {
+    act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+    dense_layer_h3<512, 512, 1, 512>(ws, w1 + l * LF, w1 + (l + 1) * LF, xh, xl, z, lane, AS);
+  }
+  act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+  {
+    float hs[1][K4 / 4];
+    {
+      float z3[1][N3P / 4];
+      dense_layer_h3<512, N3P, 1, K4P>(ws, w3, w4, xh, xl, z3, lane, AS);
+#pragma unroll
+      for (int i = 0; i < N3P / 4; ++i) hs[0][i] = act_fn<ACT_SOFTPLUS100>(z3[0][i] * zs) * inv_sqrt2;
+    }
+#pragma unroll
+    for (int i = 0; i < K0P / 4; ++i) hs[0][N3P / 4 + i] = x0[0][i] * inv_sqrt2;
+    unsigned sh[1][K4P / 32][4], sl[1][K4P / 32][4];
+    split_operands<K4P, K4 / 4, 1>(hs, sh, sl, AS);
+    dense_layer_h3<K4P, 512, 1, 512>(ws, w4, w5, sh, sl, z, lane, AS);
+  }
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {
+    act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+    dense_layer_h3<512, 512, 1, 512>(ws, w5 + l * LF, w5 + (l + 1) * LF, xh, xl, z, lane, AS);
+  }
+  act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+  float o[1][4];
+  dense_layer_h3<512, 16, 1, 0>(ws, w8, nullptr, xh, xl, o, lane, AS);
+  if (row < M && g == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < n_out) Y[row * n_out + r] = o[0][r] * zs;
+  }
+}
+
 // ---- small element-wise pieces of the auto-encoders / indirect-illumination head
 // latent = act(raw * (1 - var));  act: 0 sigmoid, 1 softplus(beta=1, threshold 20)   (sg_envmap_material.py:74-99)
 // writes lat[M,32]; if lat2 != null also lat2 = lat + noise*noise_scale (smooth_on_latent branch)
@@ -1095,6 +1180,26 @@ int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, 
     default: return rb::fail("rb_cesr_net", "kind: 0 normal_net, 1 shadow_net (dense rows), 2 shadow_net (point x one-hot label)");
   }
   return check_launch("k_softplus512");
+}
+
+int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,
+                   rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && Y, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid1d(M, 64), block(256);
+  const f4* W = (const f4*)Wp;
+  const float us = ldexpf(1.0f, -scale_log2);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((k_softplus512_h3<64, 464, false>), grid, block, 0, s, X, M, 1, W, us, 3, Y); break;
+    case 1: hipLaunchKernelGGL((k_softplus512_h3<192, 336, false>), grid, block, 0, s, X, M, 1, W, us, 2, Y); break;
+    case 2:
+      RB_REQUIRE(n_label >= 1 && n_label <= 128, "n_label must be 1..128");
+      hipLaunchKernelGGL((k_softplus512_h3<192, 336, true>), grid, block, 0, s, X, M, n_label, W, us, 2, Y);
+      break;
+    default: return rb::fail("rb_cesr_net_h3", "kind: 0 normal_net, 1 shadow_net (dense rows), 2 shadow_net (point x one-hot label)");
+  }
+  return check_launch("k_softplus512_h3");
 }
 
 int rb_ae_encode(const float* X, long M, const float* Wp, float* raw_latent, rb_stream_t stream) {

@@ -375,10 +375,19 @@ class SDFNetwork(nn.Module):
             return ops.sdf_mlp_h3(X, M, self.packed_h3(full), mode, packing.H3_SCALE_LOG2, out_scale, out_scale * in_scale)
         return ops.sdf_mlp(X, M, self.packed(full), mode, out_scale, out_scale * in_scale)
 
+    def packed_w512_h3(self):
+        return self._packed.get("w512_h3", self, lambda sd: packing.pack_softplus512_h3(
+            {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
+
+    def _cesr(self, X, M, kind, n_label=1):
+        if mlp_precision() == "f16x3":
+            return ops.cesr_net_h3(X, M, kind, self.packed_w512_h3(), packing.H3_SCALE_LOG2, n_label)
+        return ops.cesr_net(X, M, kind, self.packed(), n_label)
+
     def eval_point_labels(self, Xp, n_label=128):
         """shadow_net on every (point, one-hot label) pair: Xp [n,64] PE10 features -> logits [n*n_label, 2]."""
         assert self.kind == "shadow"
-        return ops.cesr_net(Xp, Xp.shape[0] * n_label, 2, self.packed(), n_label)
+        return self._cesr(Xp, Xp.shape[0] * n_label, 2, n_label)
 
     def forward(self, inputs, var=0.0001, chunk=1024):
         if inputs.numel() == 0:
@@ -392,7 +401,7 @@ class SDFNetwork(nn.Module):
         kp = 64 if self.kind == "normal" else 192
         X = torch.zeros(M, kp, device=flat.device)
         X[:, :self.d_in] = flat
-        return ops.cesr_net(X, M, 0 if self.kind == "normal" else 1, self.packed()).reshape(shape)
+        return self._cesr(X, M, 0 if self.kind == "normal" else 1).reshape(shape)
 
     def sdf(self, x):
         assert self.kind == "neus"

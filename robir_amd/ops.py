@@ -413,6 +413,14 @@ def cesr_net(X, M, kind, blob, n_label=1):
     return Y
 
 
+def cesr_net_h3(X, M, kind, blob, scale_log2, n_label=1):
+    n_out = 3 if kind == 0 else 2
+    Y = torch.empty(M, n_out, dtype=torch.float32, device=X.device)
+    call("rb_cesr_net_h3", ptr(_f32(X)), c_long(M), c_int(kind), c_int(n_label), ptr(blob), c_int(scale_log2), ptr(Y),
+         stream_ptr())
+    return Y
+
+
 def material_decode(brdf, brdf_r):
     brdf, brdf_r = _f32(brdf), _f32(brdf_r)
     n, dev = brdf.shape[0], brdf.device
