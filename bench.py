@@ -170,7 +170,9 @@ def main():
     if precision == "fp32":        # exact f32-input MFMA everywhere, not only in the visibility kernel
         os.environ.setdefault("ROBIR_MLP_PRECISION", "fp32")
     t0 = time.time()
-    model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the octree build prints like the reference; stdout carries only the JSON line
+        model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
     torch.cuda.synchronize()
     build_s = time.time() - t0
 
