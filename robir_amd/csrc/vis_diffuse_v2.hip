@@ -324,7 +324,7 @@ extern "C" int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long 
                                 int argmax_vis, int scale_log2, float* vis_out, unsigned long long* eval_count,
                                 rb_stream_t stream) {
   // RB_V2_TIMED=1: per-phase shader-clock totals (rb_dvis_v2_debug), a profiling aid -- costs ~10 % in the kernel
-  const char* tm = getenv("RB_V2_TIMED");
+  static const char* const tm = getenv("RB_V2_TIMED");   // read once
 #define RB_V2(T)                                                                                                          \
   hipLaunchKernelGGL(k_dvis_v2<T>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, \
                      wdir, wsum, (const f4*)W49, L, nsamp, argmax_vis, ldexpf(1.0f, -scale_log2), vis_out, eval_count)
