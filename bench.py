@@ -223,10 +223,11 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else PEAK_FP32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "kernel": ("k_dvis_v2" if precision == "f16x3-v2" else "k_dvis_fused") + " (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak,
-                    # HBM bytes per launch: 31 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
-                    # correction) + WRITE_SIZE on this kernel (profiles/r01_dvis_f16x3_pmc.md), scaled to this launch's pair
-                    # count: 0.3 % of the HBM roofline -- the bound is the matrix pipe
-                    "traffic": 31.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                    # HBM bytes per launch: 30 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
+                    # correction) + WRITE_SIZE on this kernel at 16 and at 128 chunks per launch (28-31 B/pair,
+                    # profiles/r01_dvis_f16x3_pmc.md), scaled to this launch's pair count: ~0.4 % of the HBM roofline --
+                    # the bound is the matrix pipe
+                    "traffic": 30.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
                     "precision": precision,
                     "peak_note": ("dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)" if h3
                                   else "dense f32-input MFMA"),
