@@ -280,10 +280,13 @@ int rb_neus_upsample(const float* o, const float* d, const float* z, const float
 int rb_neus_merge(const float* z_old, const float* sdf_old, int n, const float* z_new, const float* sdf_new, int m,
                   long R, float* z_out, float* sdf_out, rb_stream_t stream);
 int rb_neus_mid_z(const float* z, long R, int n, float sample_dist, float* zmid, rb_stream_t stream);
+/* z / rays_d / sample_dist / cos_anneal: NULL z = stage-2 alpha from the neighbouring mid-point SDFs (model/sdf_render.py:
+ * 206-218); z[R,n] (section starts) + rays_d[R,3] = stage-1 alpha, SDF extrapolated half a section along the ray with the
+ * annealed cosine (neus/volume_render/sdf_render.py:172-190) -- for rendering directly from stage-1 checkpoints. */
 int rb_neus_finish(const float* sdf, long sdf_stride, const float* color, const float* grad, const float* pts,
                    const float* zmid, const float* near, const float* far, long R, int n, float inv_s, float radius,
-                   int white, float* rgb, float* dist, float* acc, float* normal, float* weights, float* gerr,
-                   rb_stream_t stream);
+                   int white, const float* z, const float* rays_d, float sample_dist, float cos_anneal, float* rgb,
+                   float* dist, float* acc, float* normal, float* weights, float* gerr, rb_stream_t stream);
 int rb_surface_points(const float* p, const float* dir, const float* tk, long m, int ns, float* xs, rb_stream_t stream);
 int rb_surface_finish(const float* sdf, const float* grad, const float* xs, const float* p, const float* pred_n, long m,
                       int ns, float s, float* x_out, float* n_out, float* gerr, rb_stream_t stream);

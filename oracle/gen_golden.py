@@ -481,6 +481,28 @@ def main():
                  **{"out_" + k: ref_rn[k].detach() for k in rk})
         impl.neus_model.deviation_network.variance.data.fill_(0.3)
 
+        # stage-1 renderer (neus/volume_render/sdf_render.py: cos-annealed alpha), same model, same rays
+        for name in ("absl", "absl.flags", "absl.app", "absl.logging"):
+            ref_shim._mod(name)
+        sys.path.insert(0, os.path.join(ref_shim.REF_ROOT, "neus"))
+        from volume_render.sdf_render import render_neus as render_neus_stage1
+        R = 48
+        ro = (cl.expand(R, 3) * 2.0).contiguous()
+        rdd = rd[0, 1024 + 16 * 64: 1024 + 16 * 64 + R].contiguous()
+        near, far = torch.full((R, 1), 0.8), torch.full((R, 1), 2.8)
+        rays = Rays(ro, rdd, rdd, None, None, near, far)
+        for tag, ratio in (("c03", 0.3), ("c10", 1.0)):
+            ref_rn = render_neus_stage1(rays, impl.neus_model, ratio, n_samples=64, n_importance=64, n_outside=0,
+                                        up_sample_steps=4, is_eval=True)
+            mine_rn = oneus.render_neus(sd, ro, rdd, near, far, cos_anneal_ratio=ratio)
+            rep = {k: relerr(mine_rn[k], ref_rn[k].detach()) for k in ("rgb", "dist", "acc", "weights")}
+            rep["grad_error"] = relerr(mine_rn["grad_error"], ref_rn["sim_or_grad"].detach())
+            report("render_neus_stage1_" + tag, **rep)
+            save("render_neus_stage1_" + tag, weights=wsum, ratio=ratio, rays_o=ro, rays_d=rdd, near=near, far=far,
+                 out_rgb=ref_rn["rgb"].detach(), out_dist=ref_rn["dist"].detach(), out_acc=ref_rn["acc"].detach(),
+                 out_weights=ref_rn["weights"].detach(), out_grad_error=ref_rn["sim_or_grad"].detach(),
+                 out_means=ref_rn["means"].detach())
+
     REPORT["_meta"] = {"torch": torch.__version__, "threads": torch.get_num_threads(), "weights": wsum,
                        "seconds": time.time() - t_start}
     with open(os.path.join(HERE, "PINNING.json"), "w") as f:

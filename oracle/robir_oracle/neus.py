@@ -86,9 +86,11 @@ def importance_z(rays_o, rays_d, z, sdf, n_new, s, radius):
 
 
 def render_neus(sd, rays_o, rays_d, near, far, n_samples=64, n_importance=64, up_sample_steps=4,
-                white_bkgd=True):
+                white_bkgd=True, cos_anneal_ratio=None):
     """render_neus with n_outside=0, is_eval=True (sdf_render.py:263-374) in NeuS space.
-    rays_o/d [R,3]; near/far [R,1].  -> dict(rgb, dist, acc, grad, weights, grad_error, z_vals)."""
+    rays_o/d [R,3]; near/far [R,1].  -> dict(rgb, dist, acc, grad, weights, grad_error, z_vals).
+    cos_anneal_ratio not None: the stage-1 render_core (neus/volume_render/sdf_render.py:172-190), whose alpha comes from
+    the SDF extrapolated half a section along the ray with the annealed cosine instead of from the neighbouring samples."""
     R = rays_o.shape[0]
     sample_dist = 2.0 / n_samples
     radius = 2.0                                                        # NeuSModel.radius() (neus_model.py:743)
@@ -113,7 +115,15 @@ def render_neus(sd, rays_o, rays_d, near, far, n_samples=64, n_importance=64, up
     out = nets.sdf_raw(sd, pts)
     grads = nets.sdf_raw_gradient(sd, pts)
     col = nets.color_raw(sd, pts, grads, dirs, out[:, 1:]).reshape(R, n, 3)
-    alpha = alpha_from_sdf(out[:, :1].reshape(R, n), nets.inv_s(sd)).clip(0.0, 1.0)
+    if cos_anneal_ratio is None:
+        alpha = alpha_from_sdf(out[:, :1].reshape(R, n), nets.inv_s(sd)).clip(0.0, 1.0)
+    else:
+        true_cos = (dirs * grads).sum(-1, keepdim=True)
+        iter_cos = -(torch.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + torch.relu(-true_cos) * cos_anneal_ratio)
+        s0 = out[:, :1]
+        nxt, prv = s0 + iter_cos * dz.reshape(-1, 1) * 0.5, s0 - iter_cos * dz.reshape(-1, 1) * 0.5
+        c0, c1 = torch.sigmoid(prv * nets.inv_s(sd)), torch.sigmoid(nxt * nets.inv_s(sd))
+        alpha = ((c0 - c1 + 1e-5) / (c0 + 1e-5)).reshape(R, n).clip(0.0, 1.0)
     pnorm = torch.linalg.norm(pts, dim=-1).reshape(R, n)
     alpha = alpha * (pnorm < radius).float()
     w = transmittance_weights(alpha)

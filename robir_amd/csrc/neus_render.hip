@@ -136,7 +136,8 @@ __global__ void k_neus_finish(const float* __restrict__ sdf, long sdf_stride, co
                               const float* __restrict__ grad, const float* __restrict__ pts,
                               const float* __restrict__ zmid, const float* __restrict__ near,
                               const float* __restrict__ far, long R, int n, float inv_s, float radius, int white,
-                              float* __restrict__ rgb, float* __restrict__ dist, float* __restrict__ acc_out,
+                              const float* __restrict__ z, const float* __restrict__ rays_d, float sample_dist,
+                              float cos_anneal, float* __restrict__ rgb, float* __restrict__ dist, float* __restrict__ acc_out,
                               float* __restrict__ normal, float* __restrict__ weights, float* __restrict__ gerr) {
   const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
   float e_num = 0.f, e_den = 0.f;
@@ -144,8 +145,18 @@ __global__ void k_neus_finish(const float* __restrict__ sdf, long sdf_stride, co
     float T = 1.f, acc = 0.f, col[3] = {0.f, 0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f}, dsum = 0.f;
     for (int k = 0; k < n; ++k) {
       const long j = r * n + k;
-      const float s0 = sdf[j * sdf_stride];
-      const float s1 = sdf[(k + 1 < n ? j + 1 : j) * sdf_stride];
+      float s0 = sdf[j * sdf_stride];
+      float s1 = sdf[(k + 1 < n ? j + 1 : j) * sdf_stride];
+      if (z) {
+        // stage-1 render_core (neus/volume_render/sdf_render.py:172-190): the SDF of this sample extrapolated half a
+        // section back / forth with the annealed cosine between ray and gradient
+        const float dz = k + 1 < n ? z[j + 1] - z[j] : sample_dist;
+        const float tc = (rays_d[3 * r] * grad[3 * j] + rays_d[3 * r + 1] * grad[3 * j + 1]) + rays_d[3 * r + 2] * grad[3 * j + 2];
+        const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.f) * (1.0f - cos_anneal) + fmaxf(-tc, 0.f) * cos_anneal);
+        const float h = ic * dz * 0.5f;
+        s1 = s0 + h;
+        s0 = s0 - h;
+      }
       const float c0 = sigmoidf_(s0 * inv_s), c1 = sigmoidf_(s1 * inv_s);
       float a = ((c0 - c1) + 1e-5f) / (c0 + 1e-5f);
       a = fminf(fmaxf(a, 0.f), 1.f);
@@ -302,13 +313,15 @@ int rb_neus_mid_z(const float* z, long R, int n, float sample_dist, float* zmid,
 
 int rb_neus_finish(const float* sdf, long sdf_stride, const float* color, const float* grad, const float* pts,
                    const float* zmid, const float* near, const float* far, long R, int n, float inv_s, float radius,
-                   int white, float* rgb, float* dist, float* acc, float* normal, float* weights, float* gerr,
-                   rb_stream_t stream) {
+                   int white, const float* z, const float* rays_d, float sample_dist, float cos_anneal, float* rgb,
+                   float* dist, float* acc, float* normal, float* weights, float* gerr, rb_stream_t stream) {
   if (R <= 0) return 0;
   RB_REQUIRE(sdf && color && grad && pts && zmid && near && far && rgb && dist && acc && normal && weights,
              "null pointer");
+  RB_REQUIRE(!z || rays_d, "the stage-1 alpha needs the ray directions");
   hipLaunchKernelGGL(k_neus_finish, grid1d(R, 128), dim3(128), 0, (hipStream_t)stream, sdf, sdf_stride, color, grad, pts,
-                     zmid, near, far, R, n, inv_s, radius, white, rgb, dist, acc, normal, weights, gerr);
+                     zmid, near, far, R, n, inv_s, radius, white, z, rays_d, sample_dist, cos_anneal, rgb, dist, acc,
+                     normal, weights, gerr);
   return check_launch("k_neus_finish");
 }
 

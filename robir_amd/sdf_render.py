@@ -22,7 +22,10 @@ def _f(t):
 
 
 def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
-                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False):
+                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, stage1_alpha=False):
+    """model/sdf_render.py:263-374 (stage 2; `cos_anneal_ratio` is ignored there).  stage1_alpha=True renders with the
+    stage-1 render_core instead (neus/volume_render/sdf_render.py:172-190: alpha from the cos-annealed half-section
+    extrapolation of the SDF), i.e. what NeuS stage-1 checkpoints were trained against; see render_neus_stage1."""
     if n_outside != 0 or lindisp or not (is_eval or perturb == 0):
         raise NotImplementedError("HIP render_neus: n_outside=0, lindisp=False, is_eval=True (deterministic sampling)")
     o, d = _f(rays.origins), _f(rays.directions)
@@ -70,10 +73,23 @@ def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64
     rgb, dist, acc = torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
     nrm, w = torch.empty(R, 3, device=dev), torch.empty(R, n, device=dev)
     gerr = torch.zeros(2, device=dev)
+    z = z.contiguous()
     call("rb_neus_finish", ptr(out), c_long(257), ptr(col), ptr(grad), ptr(pts), ptr(zmid), ptr(near), ptr(far), c_long(R),
-         c_int(n), c_float(model.inv_s()), c_float(radius), c_int(1 if white_bkgd else 0), ptr(rgb), ptr(dist), ptr(acc),
-         ptr(nrm), ptr(w), ptr(gerr), S())
-    return {"rgb": rgb, "dist": dist, "acc": acc, "grad_error": gerr[0] / (gerr[1] + 1e-5), "grad": nrm, "weights": w}
+         c_int(n), c_float(model.inv_s()), c_float(radius), c_int(1 if white_bkgd else 0),
+         ptr(z if stage1_alpha else None), ptr(d if stage1_alpha else None), c_float(sample_dist),
+         c_float(float(cos_anneal_ratio)), ptr(rgb), ptr(dist), ptr(acc), ptr(nrm), ptr(w), ptr(gerr), S())
+    ge = gerr[0] / (gerr[1] + 1e-5)
+    if stage1_alpha:        # the stage-1 function's own result dict (neus/volume_render/sdf_render.py:358-365)
+        return {"rgb": rgb, "dist": dist, "acc": acc, "sim_or_grad": ge, "weights": w, "means": zmid}
+    return {"rgb": rgb, "dist": dist, "acc": acc, "grad_error": ge, "grad": nrm, "weights": w}
+
+
+def render_neus_stage1(rays, model, cos_anneal_ratio, n_samples=64, n_importance=64, n_outside=32, up_sample_steps=4,
+                       white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False):
+    """neus/volume_render/sdf_render.py:238-365 (stage-1 `render_neus`; n_outside must be passed as 0 like every stage-2
+    caller does -- the NeRF++ background is out of scope)."""
+    return render_neus(rays, model, cos_anneal_ratio, n_samples, n_importance, n_outside, up_sample_steps, white_bkgd,
+                       lindisp, perturb, is_eval, stage1_alpha=True)
 
 
 def get_neus_surface(implicit_network, points, view_dirs, pred_normals, n_samp=32, dist=0.05):

@@ -39,6 +39,23 @@ def test_render_neus_golden(dev, synth_weights, tag):
     assert bad_frac(out["weights"].cpu(), g["out_weights"], 5e-3) <= 0.01
 
 
+@pytest.mark.parametrize("tag", ["c03", "c10"])
+def test_render_neus_stage1_golden(dev, synth_weights, tag):
+    """Stage-1 renderer (cos-annealed alpha) against the reference's neus/volume_render/sdf_render.py output."""
+    from robir_amd import sdf_render
+    g = load_golden("render_neus_stage1_" + tag)
+    model = _neus(dev, synth_weights, 0.3)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if v.dtype.kind == "f" and v.ndim > 0}
+    rays = sdf_render.Rays(t["rays_o"], t["rays_d"], t["rays_d"], None, None, t["near"], t["far"])
+    out = sdf_render.render_neus_stage1(rays, model, float(g["ratio"]), n_samples=64, n_importance=64, n_outside=0,
+                                        up_sample_steps=4, is_eval=True)
+    for k, tol in (("rgb", 1e-4), ("dist", 1e-4), ("acc", 2e-4)):
+        assert rel_err(out[k].cpu(), g["out_" + k]) <= tol, (k, rel_err(out[k].cpu(), g["out_" + k]))
+    assert rel_err(out["sim_or_grad"].cpu(), g["out_grad_error"]) <= 1e-4
+    assert rel_err(out["means"].cpu(), g["out_means"]) <= 1e-4
+    assert bad_frac(out["weights"].cpu(), g["out_weights"], 5e-3) <= 0.02     # same bound as the oracle (test_oracle_golden.py)
+
+
 def test_render_neus_vs_oracle_more_rays(dev, synth_weights, oracle_sd):
     """400 rays of a 64x64 view (hits, grazing rays and misses) against the oracle."""
     from robir_amd import sdf_render, synth

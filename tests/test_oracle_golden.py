@@ -155,6 +155,21 @@ def test_render_neus(synth_weights, tag):
     assert bad_frac(out["weights"], g["out_weights"], 5e-3) <= 0.01      # per-sample weights: inv_s-amplified noise
 
 
+@pytest.mark.parametrize("tag", ["c03", "c10"])
+def test_render_neus_stage1(synth_weights, tag):
+    """Stage-1 render_core (cos-annealed alpha), neus/volume_render/sdf_render.py, against the reference's own output."""
+    from robir_oracle import neus, nets
+    g = load_golden("render_neus_stage1_" + tag)
+    sd = nets.as_torch(synth_weights)
+    out = neus.render_neus(sd, torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"]), torch.from_numpy(g["near"]),
+                           torch.from_numpy(g["far"]), cos_anneal_ratio=float(g["ratio"]))
+    for k in ("rgb", "dist", "acc"):
+        assert rel_err(out[k], g["out_" + k]) <= TOL, k
+    assert rel_err(out["grad_error"], g["out_grad_error"]) <= TOL
+    # per-sample weights: the SDF *and* gradient noise is amplified by inv_s * section length in this alpha
+    assert bad_frac(out["weights"], g["out_weights"], 5e-3) <= 0.02
+
+
 def test_cesr_nets_and_forward(oracle_sd, oracle_octree):
     """CESR hook (shadow_net on 128 one-hot labels per point, normal_net, linear-diffuse shading) vs the reference."""
     from robir_amd import synth
