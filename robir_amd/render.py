@@ -39,7 +39,8 @@ def render_view(model, uv, pose, K, chunks_per_pass=125, chunk=1024, hdr_shift=N
     shift = model.gamma.hdr_shift.as_input().detach() if hdr_shift is None else torch.tensor([[hdr_shift]], device=dev)
     hdr = shift.expand(N, 1).contiguous()
     per = chunks_per_pass * chunk
-    keys = ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "vis_shadow", "normal_map", "network_object_mask", "bg_rgb")
+    keys = ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "vis_shadow", "normal_map", "normals",
+            "network_object_mask", "bg_rgb")
     acc = {k: [] for k in keys}
     for s in range(0, N, per):
         o = model.render_chunks(uv_d[s:s + per], pose_d, K_d, hdr[s:s + per], chunk=chunk)
@@ -53,6 +54,35 @@ def render_view(model, uv, pose, K, chunks_per_pass=125, chunk=1024, hdr_shift=N
     return out
 
 
+def save_relight_images(out, H, W, images_dir, name, light_type="origin"):
+    """The image set scripts/relight.py:60-113 writes per view: `sg_rgb_bg_<name>.png` (sg_rgb [+ indir_rgb for the
+    original light], x^(1/2.2), envmap background behind the object), and for the original light `roughness_`, `albedo_`
+    (x^(1/2.2)) and `normal_` ((n+1)/2).  Needs PIL."""
+    import os
+    from PIL import Image
+
+    def img(x, tonemap):
+        x = x.detach().float().cpu().numpy().reshape(H, W, -1)
+        if x.shape[-1] == 1:
+            x = np.repeat(x, 3, -1)
+        if tonemap:
+            x = np.power(np.clip(x, 0.0, None), 1.0 / 2.2)
+        return np.clip(x, 0.0, 1.0)
+
+    os.makedirs(images_dir, exist_ok=True)
+    hit = out["network_object_mask"].detach().cpu().numpy().reshape(H, W)
+    rgb = out["sg_rgb"] + out["indir_rgb"] if light_type == "origin" else out["sg_rgb"]
+    rgb, bg = img(rgb, True), img(out["bg_rgb"], True)
+    rgb[~hit] = bg[~hit]
+    files = {"sg_rgb_bg": rgb}
+    if light_type == "origin":
+        files.update(roughness=img(out["roughness"], False), albedo=img(out["diffuse_albedo"], True),
+                     normal=img((out["normals"] + 1.0) / 2.0, False))
+    for k, v in files.items():
+        Image.fromarray((v * 255).astype(np.uint8)).save(os.path.join(images_dir, "%s_%s.png" % (k, name)))
+    return sorted(files)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", action="store_true")
@@ -63,6 +93,7 @@ def main():
     ap.add_argument("--index", type=int, default=0)
     ap.add_argument("--light", help="directory holding sg_128.npy (and optionally <dir>.exr)")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--png-dir", help="also write the PNG set of scripts/relight.py into this directory")
     a = ap.parse_args()
     from . import renderer, synth
     dev = torch.device("cuda:0")
@@ -84,6 +115,9 @@ def main():
     out = render_view(model, uv, pose, K)
     np.savez_compressed(a.out, **{k: v.detach().cpu().numpy().reshape(H, W, -1) for k, v in out.items()})
     print("wrote", a.out, "hit fraction %.3f" % float(out["network_object_mask"].float().mean()))
+    if a.png_dir:
+        names = save_relight_images(out, H, W, a.png_dir, str(a.index), "relit" if a.light else "origin")
+        print("wrote", ", ".join("%s_%d.png" % (n, a.index) for n in names), "to", a.png_dir)
 
 
 if __name__ == "__main__":

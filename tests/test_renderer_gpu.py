@@ -183,6 +183,15 @@ def test_norm_hook_and_render_view(dev, model):
     uv, pose, K = synth.synth_camera(96, 96)
     out = render.render_view(model, uv, pose, K, chunks_per_pass=4)
     assert out["pred_rgb"].shape == (96 * 96, 3) and bool(torch.isfinite(out["pred_rgb"][out["network_object_mask"]]).all())
+    # the PNG set of scripts/relight.py (original light: composite, roughness, albedo, normal)
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        names = render.save_relight_images(out, 96, 96, d, "0")
+        assert names == ["albedo", "normal", "roughness", "sg_rgb_bg"]
+        from PIL import Image
+        im = np.asarray(Image.open(os.path.join(d, "sg_rgb_bg_0.png")))
+        assert im.shape == (96, 96, 3) and im.dtype == np.uint8 and int(im.max()) > 0
     old = model.get_sg_render
     try:
         model.get_sg_render = renderer.NormHook(model)
