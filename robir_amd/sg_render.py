@@ -58,6 +58,22 @@ def render_envmap(envmap, viewdirs):
 
 
 # ----------------------------------------------------------------------------------------- visibility
+_SCALARS = {}
+
+
+def _host_scalar(t):
+    """First element of a (parameter) tensor as a Python float.  Reading it is a device->host copy, i.e. a full stream
+    synchronisation, twice per forward(); the value only changes when the parameter does, so it is cached per
+    (storage, version)."""
+    key = (t.data_ptr(), t._version)
+    v = _SCALARS.get(key)
+    if v is None:
+        if len(_SCALARS) > 64:
+            _SCALARS.clear()
+        v = _SCALARS[key] = float(t.detach().reshape(-1)[0])
+    return v
+
+
 def _rand(shape, device):
     return torch.rand(*shape, device=device)
 
@@ -183,7 +199,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     nrm = normal.float().contiguous()
     vd = viewdirs.float().contiguous()
     rough = roughness.float().contiguous().reshape(-1)
-    f0 = float(specular_reflectance.detach().reshape(-1)[0])
+    f0 = _host_scalar(specular_reflectance)
     shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
     lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
     light_vis = None
