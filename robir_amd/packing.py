@@ -62,6 +62,10 @@ def pack_layers_h3(layers, device, scale_log2=H3_SCALE_LOG2):
     for l, sz in zip(layers, sizes):
         W = l["W"].to(device=device, dtype=torch.float32).contiguous()
         b = l["b"].to(device=device, dtype=torch.float32).contiguous() if l.get("b") is not None else None
+        wmax = float(W.abs().max()) * 2.0 ** scale_log2
+        if not wmax < 65504.0:       # the hi half would overflow to inf: fail here, not as NaNs in the image
+            raise ValueError("split-precision packing: |w| * 2^%d = %.3g exceeds the f16 range; run this network with "
+                             "ROBIR_MLP_PRECISION=fp32 / ROBIR_VIS_PRECISION=fp32" % (scale_log2, wmax))
         perm = None
         if l.get("perm") is not None:
             perm = torch.tensor(l["perm"], dtype=torch.int32, device=device)

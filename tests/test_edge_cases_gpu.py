@@ -106,3 +106,14 @@ def test_oversized_launch_fails_loudly(dev):
     # the library is usable afterwards
     from robir_amd import ops
     assert ops.tonemap(x + 0.25, shift, 0).shape == (16, 3)
+
+
+def test_split_precision_packing_rejects_out_of_range_weights(dev):
+    """|w| * 2^8 must fit the f16 hi half; such a checkpoint has to use the exact-fp32 kernels."""
+    from robir_amd import packing
+    W = torch.zeros(16, 32)
+    W[3, 5] = 300.0
+    with pytest.raises(ValueError):
+        packing.pack_layers_h3([dict(W=W, b=None, n_pad=16, k_pad=32)], dev)
+    W[3, 5] = 200.0
+    assert packing.pack_layers_h3([dict(W=W, b=None, n_pad=16, k_pad=32)], dev).numel() > 0
