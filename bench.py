@@ -45,6 +45,8 @@ def parse():
                     help="1024-pixel chunks rendered per kernel pass (625 = the whole 800x800 view; 2.7 GB of tables)")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact", action="store_true",
+                    help="skip the exact-fp32 cross-check step that follows the timed region (rank 0, N = 1)")
     ap.add_argument("--vis-precision", default="f16x3-v2", choices=["fp32", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
@@ -247,6 +249,34 @@ def main():
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "parallelism": f"ray-shard x{world} (views)"},
             "roofline": roofline,
         }
+        if world == 1 and precision != "fp32" and not args.no_exact:
+            # Outside the timed region: the same view with every MLP on the exact f32-input MFMA and the same random
+            # draws -- the conservative rate, and how far the split-precision image is from it.
+            torch.manual_seed(20260928)
+            split_img = step()
+            sg_render.VIS_PRECISION = "fp32"
+            os.environ["ROBIR_MLP_PRECISION"] = "fp32"
+            torch.manual_seed(20260928)
+            step()                                      # packs the fp32 weight blobs
+            torch.cuda.synchronize()
+            torch.manual_seed(20260928)
+            t1 = time.perf_counter()
+            exact_img = step()
+            torch.cuda.synchronize()
+            t_exact = time.perf_counter() - t1
+            ok = torch.isfinite(exact_img).all(-1) & torch.isfinite(split_img).all(-1)
+            a, b = split_img[ok], exact_img[ok]
+            rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
+            line["exact_fp32"] = {"value": H * W / t_exact, "unit": "rays/s", "ms_per_step": t_exact * 1e3,
+                                  "max_rel_diff_of_split_precision_image": float(rel.max()),
+                                  "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
+                                  "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum()),
+                                  "note": "same view and draws, every MLP on v_mfma_f32_16x16x4_f32; diff = |a-b|/(|b|+mean|b|) "
+                                          "over the 17 output channels of all rays; the outliers are rays where a sampled "
+                                          "direction sits on the n.d > 1e-6 cull (a 1e-6 change of the normal flips one "
+                                          "visibility sample), the same effect as between two exact runs on different hardware"}
+            sg_render.VIS_PRECISION = precision
+            os.environ["ROBIR_MLP_PRECISION"] = "f16x3"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline_chunks, uv, pose, K)
         print(json.dumps(line), flush=True)
