@@ -66,3 +66,16 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.RobirHipError):
         _lib.lib()
+
+
+def test_mlp_precision_switch(monkeypatch):
+    """ROBIR_MLP_PRECISION selects the arithmetic of the stand-alone MLP kernels; anything else is an error, not a guess."""
+    from robir_amd import nets
+    monkeypatch.delenv("ROBIR_MLP_PRECISION", raising=False)
+    assert nets.mlp_precision() == "f16x3"
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", "fp32")
+    assert nets.mlp_precision() == "fp32"
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", "bf16")
+    import pytest
+    with pytest.raises(ValueError):
+        nets.mlp_precision()
