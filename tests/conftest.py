@@ -70,3 +70,22 @@ def oracle_octree(oracle_sd):
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     return octree.build(lambda x: nets.implicit_forward(oracle_sd, x)[:, 0],
                         lambda x: nets.implicit_gradient(oracle_sd, x), [-1.0] * 3, [1.0] * 3)
+
+
+def oracle_tables_from_device(Td):
+    """The oracle's OctreeTables from a device-built octree (same cells: lets oracle and kernels trace identical geometry
+    for weight sets that have no CPU-built fixture)."""
+    import torch
+    from robir_oracle import octree as ooct
+    node = Td.node.cpu()
+    T = ooct.OctreeTables()
+    T.root_min, T.root_size = torch.from_numpy(Td.root_min.copy()), torch.from_numpy(Td.root_size.copy())
+    T.box_min, T.box_size, T.sdf_val = node[:, 0:3].contiguous(), node[:, 4:7].contiguous(), node[:, 7].contiguous()
+    fc = node[:, 3].contiguous().view(torch.int32).long()
+    T.is_split = fc >= 0
+    T.child = torch.where(T.is_split[:, None], fc[:, None] + torch.arange(8)[None, :], torch.full((1, 8), -1))
+    res = [int(v) for v in Td.res]
+    T.base_index = torch.arange(res[0] * res[1] * res[2]).reshape(*res)
+    T.sdf_nrm, T.centre = Td.nrm.cpu(), T.box_min + T.box_size * 0.5
+    T.hit, T.min_step = T.sdf_val <= 1e-4, Td.min_step
+    return T

@@ -85,6 +85,42 @@ def test_forward_material_vs_oracle_same_tables(dev, model_oracle_tables, oracle
             assert tuple(out[name].shape) == tuple(g[k].shape), (name, out[name].shape, g[k].shape)
 
 
+def test_forward_material_second_weight_set(dev):
+    """A second synthetic checkpoint (other seed, sharper NeuS variance, light SGs shaped like the shipped fits: |lambda|
+    up to ~500) through the whole Material forward against the oracle on the same octree cells."""
+    from conftest import oracle_tables_from_device
+    from robir_amd import renderer, synth
+    from robir_oracle import nets as on, octree as ooct, renderer as orend
+    m = renderer.build_synthetic_model(dev, seed=3, variance=0.6, sharp_light=True)
+    sd = on.as_torch(synth.synth_state_dict(3, variance=0.6, sharp_light=True))
+    T = oracle_tables_from_device(m.ray_tracer.sdf_octree.tables)
+    uv_d, pose_d, K_d, uv, pose, K, sl = _inputs(dev, 2)
+    uv_t, pose_t, K_t = torch.from_numpy(uv[sl])[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None]
+    dirs, cam = orend.camera_rays(uv_t, pose_t, K_t)
+    _, hit, _ = ooct.trace(T, cam, dirs, -1)
+    n_hit = int(hit.sum())
+    assert n_hit > 300
+    drt = {k: torch.from_numpy(v) for k, v in synth.pbr_draws(11, n_hit, chunk_id=2).items()}
+    hdr = torch.full((1024, 1), 0.35)
+    ref = orend.forward(sd, T, uv_t, pose_t, K_t, torch.ones(1, 1024, dtype=torch.bool), hdr, drt, "Material", testing=True)
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr.to(dev)}
+    out = m(inp, trainstage="Material", train_spec=True, draws={k: v.to(dev) for k, v in drt.items()})
+    assert bool((out["network_object_mask"].cpu() == ref["network_object_mask"]).all())
+    assert rel_err(out["points"].cpu(), ref["points"]) <= 1e-6
+    # With these sharp lights the specular term is ill-conditioned in fp32 (tests/test_sg_gpu.py::
+    # test_specular_term_conditioning: the reference's formula differs by percent between fp32 and fp64), so 1e-6 input
+    # differences show up at the 1e-3 level there -- identically with the exact-fp32 kernels.  Everything else keeps the
+    # chained bound.
+    loose = ("sg_specular_rgb", "sg_rgb", "indir_specular_rgb")
+    for k in FIELDS:
+        frac, worst = bad_frac(out[k].cpu(), ref[k], 2e-4), rel_err(out[k].cpu(), ref[k])
+        if k in loose:
+            assert frac <= 0.1 and worst <= 5e-3, (k, frac, worst)
+        else:
+            assert frac <= 0.005 and worst <= 1e-3, (k, frac, worst)
+
+
 def test_forward_material_vs_reference_golden(dev, model):
     """End to end with the device-built octree against the reference's own output (looser: PE amplifies the ~1e-6
     hit-position noise of two independently built octrees 512-fold -- DESIGN.md 'Parity tolerances')."""

@@ -112,3 +112,42 @@ def test_fused_visibility_is_deterministic(dev, vis_net):
         assert torch.equal(outs["f16x3"], outs["f16x3-regstage"])
     finally:
         sg_render.VIS_PRECISION = old
+
+
+def test_specular_term_conditioning(dev):
+    """Sharp light SGs (|lambda| up to ~500, like the shipped envmap fits) with low roughness make the reference's own
+    specular formula ill-conditioned in fp32: evaluated in fp64 and fp32 it differs by percent on some rays
+    (lambda_trick / hemisphere_int cancel large exponentials).  A 1e-4 bound against an fp32 oracle is meaningless
+    there; what can be asked is that the kernel is as close to the fp64 evaluation as the fp32 oracle is."""
+    from robir_amd import sg_render, synth
+    from robir_oracle import sg as osg
+    g = torch.Generator().manual_seed(0)
+    n = 600
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128, sharp=True)).float()
+    pts = torch.randn(n, 3, generator=g) * 0.2
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    view = torch.nn.functional.normalize(nrm + 0.8 * torch.randn(n, 3, generator=g), dim=-1)
+    rough = torch.rand(n, 1, generator=g) * 0.9 + 0.09
+    alb = torch.rand(n, 3, generator=g)
+    f0 = torch.full((1, 1), 0.05)
+    dr = {"dvis_theta": torch.rand(128, 32, generator=g), "dvis_phi": torch.rand(128, 32, generator=g),
+          "svis_theta_dir": torch.rand(n, 8, generator=g), "svis_phi_dir": torch.rand(n, 8, generator=g)}
+
+    def oracle(dt):
+        c = lambda t: t.to(dt)
+        return osg.render_with_all_sg(c(pts), c(nrm), c(view), c(lgt), c(f0), c(rough), c(alb), {k: c(v) for k, v in dr.items()},
+                                      vis_fn=lambda p, d: torch.zeros(p.shape[0], 2, dtype=dt), testing=True)
+
+    o32, o64 = oracle(torch.float32), oracle(torch.float64)
+    vis = lambda p, d: torch.zeros(p.shape[0], 2, device=p.device)
+    d = lambda t: t.to(dev)
+    out = sg_render.render_with_all_sg(d(pts), d(nrm), d(view), d(lgt), d(f0), d(rough), d(alb), VisModel=vis, testing=True,
+                                       draws={k: d(v) for k, v in dr.items()})
+    for k in ("sg_specular_rgb", "sg_rgb"):
+        e_oracle = rel_err(o32[k].double(), o64[k])
+        e_kernel = rel_err(out[k].cpu().double(), o64[k])
+        assert e_oracle > 1e-3, "this test is meant to sit in the ill-conditioned regime"
+        assert e_kernel <= 2.0 * e_oracle, (k, e_kernel, e_oracle)
+        print(f"{k}: fp32 oracle vs fp64 {e_oracle:.2e}, kernel vs fp64 {e_kernel:.2e}")
+    # the well-conditioned diffuse term keeps the strict bound
+    assert rel_err(out["sg_diffuse_rgb"].cpu(), o32["sg_diffuse_rgb"]) <= TOL
