@@ -194,6 +194,34 @@ def test_illum_and_trace_radiance_vs_golden(dev, model_oracle_tables):
     assert bool((out["indir_mask"].cpu().numpy() == g["out_indir_mask"]).mean() > 0.999)
 
 
+def test_trace_radiance_second_weight_set(dev):
+    """Vis-stage path (secondary rays, borrow_color through the 4-column SDF kernel, visibility MLP) with another
+    checkpoint, against the oracle fed with the kernels' own Illum forward (same octree cells)."""
+    from conftest import oracle_tables_from_device
+    from robir_amd import renderer, synth
+    from robir_oracle import nets as on, renderer as orend
+    m = renderer.build_synthetic_model(dev, seed=3, variance=0.6, sharp_light=True)
+    sd = on.as_torch(synth.synth_state_dict(3, variance=0.6, sharp_light=True))
+    T = oracle_tables_from_device(m.ray_tracer.sdf_octree.tables)
+    uv_d, pose_d, K_d, *_ = _inputs(dev, 2)
+    hdr = torch.full((1024, 1), 0.35, device=dev)
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr}
+    ill = m(inp, trainstage="Illum")
+    n = int(ill["network_object_mask"].sum())
+    g = torch.Generator().manual_seed(5)
+    u1, u2 = torch.rand(n * 8, generator=g), torch.rand(n * 8, generator=g)
+    fwd = {"points": ill["points"], "hdr_shift": hdr, "network_object_mask": ill["network_object_mask"], "normals": ill["normals"]}
+    out = m.trace_radiance(fwd, nsamp=8, draws=(u1, u2))
+    ref = orend.trace_radiance(sd, T, {k: v.cpu() for k, v in fwd.items()}, 8, u1, u2)
+    assert rel_err(out["sample_dirs"].cpu(), ref["sample_dirs"]) <= 1e-5
+    assert int((out["gt_vis"].cpu() != ref["gt_vis"]).sum()) <= 4
+    assert rel_err(out["pred_vis"].cpu(), ref["pred_vis"]) <= 1e-4
+    assert bad_frac(out["trace_radiance"].cpu(), ref["trace_radiance"], 1e-3) <= 0.004
+    assert bad_frac(out["gt_integral"].cpu(), ref["gt_integral"], 1e-3) <= 0.01
+    assert float((out["indir_mask"].cpu() == ref["indir_mask"]).float().mean()) > 0.999
+
+
 def test_points_dirs_form_equals_uv_form(dev, model):
     """forward({'points','dirs'}) (implicit_differentiable_renderer.py:306-322) on the camera's own rays == uv form."""
     from robir_amd import synth, ops
