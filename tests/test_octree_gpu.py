@@ -119,3 +119,33 @@ def test_camera_rays(dev):
     d = ops.camera_rays(pose, K, torch.from_numpy(uv).to(dev)).cpu()
     ref, cam = renderer.camera_rays(torch.from_numpy(uv)[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
     assert rel_err(d, ref[0]) <= 1e-6
+
+
+def test_build_second_sdf_and_mesh_box(dev):
+    """Another SDF (other seed) and the mesh-bounding-box form of generate() (octree_tracing.py:33-39: root = a box
+    tighter than [-1,1]^3): the device-built node structure must again equal the oracle's exactly."""
+    from robir_amd import nets, synth
+    from robir_amd.octree_tracing import OctreeSDF
+    from robir_oracle import nets as on, octree as ooct
+    import os
+    w = synth.synth_state_dict(3, variance=0.6)
+    m = nets.NeuSModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(w).items()})
+    m = m.to(dev).eval()
+    sd = on.as_torch(w)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    box = ([-0.42, -0.40, -0.45], [0.41, 0.43, 0.40])
+    O = ooct.build(lambda x: on.implicit_forward(sd, x)[:, 0], lambda x: on.implicit_gradient(sd, x), box[0], box[1])
+    T = OctreeSDF.build(m.sdf_network, [box[0], box[1]]).tables
+    node = T.node.cpu()
+    # A cell splits when |sdf(centre)| is below a size-dependent threshold; the device and the CPU evaluate the SDF with
+    # different summation orders (~1e-7), so a cell sitting on the threshold may split on one side only.  Such a flip
+    # renumbers every later node, hence the comparison by cell set: the two trees must agree except for at most a few
+    # threshold cells (and their 8 children).
+    def cells(bmin, bsize):
+        a = torch.cat([bmin, bsize], 1).contiguous().numpy()
+        return set(map(bytes, a.view(np.uint8).reshape(a.shape[0], -1)))
+    dev_cells, ora_cells = cells(node[:, 0:3], node[:, 4:7]), cells(O.box_min, O.box_size)
+    only = len(dev_cells ^ ora_cells)
+    print("nodes", T.B, O.box_min.shape[0], "cells in one tree only:", only)
+    assert only <= 4 * 9 and abs(T.B - O.box_min.shape[0]) <= 4 * 8
