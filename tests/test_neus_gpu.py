@@ -87,3 +87,27 @@ def test_borrow_color_and_surface_golden(dev, synth_weights):
     assert rel_err(x.cpu(), g["ns_x"]) <= 1e-4
     assert rel_err(n.cpu(), g["ns_n"]) <= 1e-4
     assert rel_err(ge.cpu(), g["ns_gerr"]) <= 1e-4
+
+
+def test_render_neus_second_weight_set(dev):
+    """render_neus with another checkpoint (other seed, variance 0.6 -> inv_s ~ 403, a trained-like sharpness) and a
+    different ray bundle against the oracle."""
+    from robir_amd import nets, sdf_render, synth
+    from robir_oracle import neus as oneus, nets as on, renderer as orend
+    w = synth.synth_state_dict(3, variance=0.6)
+    m = nets.NeuSModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(w).items()})
+    m = m.to(dev).eval()
+    sd = on.as_torch(w)
+    uv, pose, K = synth.synth_camera(48, 48)
+    dirs, cam = orend.camera_rays(torch.from_numpy(uv)[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
+    sel = torch.arange(900, 1140)
+    R = sel.numel()
+    ro = (cam.expand(R, 3) * 2.0).contiguous()
+    rd = dirs[0, sel].contiguous()
+    near, far = torch.full((R, 1), 0.9), torch.full((R, 1), 2.7)
+    ref = oneus.render_neus(sd, ro, rd, near, far)
+    rays = sdf_render.Rays(ro.to(dev), rd.to(dev), rd.to(dev), None, None, near.to(dev), far.to(dev))
+    out = sdf_render.render_neus(rays, m, 1.0, is_eval=True)
+    for k, tol in (("rgb", 2e-4), ("dist", 2e-4), ("acc", 4e-4), ("grad", 4e-4)):
+        assert bad_frac(out[k].cpu(), ref[k], tol) <= 0.01, (k, rel_err(out[k].cpu(), ref[k]))
