@@ -323,6 +323,10 @@ extern "C" int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long 
                                 const float* dirs, const float* wdir, const float* wsum, const float* W49, int L, int nsamp,
                                 int argmax_vis, int scale_log2, float* vis_out, unsigned long long* eval_count,
                                 rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
+  RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
+  RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= V2_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   // RB_V2_TIMED=1: per-phase shader-clock totals (rb_dvis_v2_debug), a profiling aid -- costs ~10 % in the kernel
   static const char* const tm = getenv("RB_V2_TIMED");   // read once
 #define RB_V2(T)                                                                                                          \

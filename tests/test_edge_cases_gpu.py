@@ -117,3 +117,22 @@ def test_split_precision_packing_rejects_out_of_range_weights(dev):
         packing.pack_layers_h3([dict(W=W, b=None, n_pad=16, k_pad=32)], dev)
     W[3, 5] = 200.0
     assert packing.pack_layers_h3([dict(W=W, b=None, n_pad=16, k_pad=32)], dev).numel() > 0
+
+
+def test_visibility_kernel_size_limits(dev):
+    """The fused light-visibility kernels keep a point's directions in LDS: L * nsamp <= 4096 (128 lobes x 32 samples is
+    the reference's maximum, sg_render.py:389); beyond that the call must fail, not truncate."""
+    from robir_amd import _lib, ops, renderer, sg_render
+    m = renderer.build_synthetic_model(dev, build_octrees=False)
+    lgt = m.envmap_material_network.lgtSGs.detach()
+    n = 5
+    g = torch.Generator(device=dev).manual_seed(0)
+    pts = (torch.rand(n, 3, device=dev, generator=g) - 0.5) * 0.4
+    nrm = torch.nn.functional.normalize(torch.rand(n, 3, device=dev, generator=g) - 0.5, dim=-1)
+    for ns in (8, 32):                                           # CESR (8) and PBR (32) sample counts
+        u = torch.rand(2, 128, ns, device=dev, generator=g)
+        v = sg_render._diffuse_vis_core(pts, nrm, m.visibility_network, lgt, u[0], u[1], 1.0, False, None, 1, None)
+        assert v.shape == (n, 128) and float(v.min()) >= 0.0 and float(v.max()) <= 1.0 + 1e-6
+    u = torch.rand(2, 128, 33, device=dev, generator=g)          # 128 * 33 > 4096
+    with pytest.raises(_lib.RobirHipError):
+        sg_render._diffuse_vis_core(pts, nrm, m.visibility_network, lgt, u[0], u[1], 1.0, False, None, 1, None)
