@@ -343,6 +343,7 @@ extern "C" int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long 
 
 // debug: per-phase shader-clock totals of wave 0 (RB_V2_TIMED=1): prologue, ring start, gather, layers, head, final
 extern "C" int rb_dvis_v2_debug(unsigned long long* out8) {
+  RB_REQUIRE(out8, "null pointer");
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rb_v2_dbg), sizeof(z)) != hipSuccess) return 1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(rb_v2_dbg), z, sizeof(z)) != hipSuccess) return 1;
