@@ -136,3 +136,28 @@ def test_visibility_kernel_size_limits(dev):
     u = torch.rand(2, 128, 33, device=dev, generator=g)          # 128 * 33 > 4096
     with pytest.raises(_lib.RobirHipError):
         sg_render._diffuse_vis_core(pts, nrm, m.visibility_network, lgt, u[0], u[1], 1.0, False, None, 1, None)
+
+
+def test_split_precision_kernels_ragged_row_counts(dev, synth_weights):
+    """Row counts that are not multiples of the 128- / 64-row workgroup tiles (and empty inputs): the split-precision
+    kernels must agree with the exact ones row for row."""
+    from robir_amd import ops, packing, synth
+    g = torch.Generator(device=dev).manual_seed(2)
+    sdf3, sdf = packing.pack_sdf_h3(synth_weights, dev, full=False), packing.pack_sdf(synth_weights, dev, full=False)
+    vis3, vis = packing.pack_vis_h3(synth_weights, dev), packing.pack_vis(synth_weights, dev)
+    ill3, ill = packing.pack_illum_h3(synth_weights, dev), packing.pack_illum(synth_weights, dev)
+    for M in (0, 1, 17, 129, 1000):
+        x = (torch.rand(M, 3, device=dev, generator=g) - 0.5) * 0.8
+        d = torch.nn.functional.normalize(torch.rand(M, 3, device=dev, generator=g) - 0.5, dim=-1) if M else x
+        a, ga = ops.sdf_mlp_h3(ops.feat_pe10(x, scale=2.0, jvp=True), M, sdf3, 2, packing.H3_SCALE_LOG2, 0.5, 1.0)
+        b, gb = ops.sdf_mlp(ops.feat_pe10(x, scale=2.0, jvp=True), M, sdf, 2, 0.5, 1.0)
+        assert a.shape == (M,) and ga.shape == (M, 3)
+        X = ops.feat_vis(x, d)
+        v3, v = ops.vis_mlp_h3(X, vis3, packing.H3_SCALE_LOG2), ops.vis_mlp(X, vis)
+        Xi = ops.feat_pe10(x, extra=torch.full((M, 1), 0.5, device=dev))
+        i3, i = ops.wide_mlp_h3(Xi, ill3, False, packing.H3_SCALE_LOG2), ops.illum_mlp(Xi, ill)
+        if M:
+            assert rel_err(a.cpu(), b.cpu()) <= 1e-5 and rel_err(ga.cpu(), gb.cpu()) <= 1e-5
+            assert rel_err(v3.cpu(), v.cpu()) <= 1e-5 and rel_err(i3.cpu(), i.cpu()) <= 1e-5
+        else:
+            assert v3.shape == (0, 2) and i3.shape == (0, 144)
