@@ -161,3 +161,29 @@ def test_split_precision_kernels_ragged_row_counts(dev, synth_weights):
             assert rel_err(v3.cpu(), v.cpu()) <= 1e-5 and rel_err(i3.cpu(), i.cpu()) <= 1e-5
         else:
             assert v3.shape == (0, 2) and i3.shape == (0, 144)
+
+
+def test_visibility_point_without_front_facing_directions(dev, oracle_sd):
+    """A point whose normal has no direction with n.d > 1e-6 (here: a zero normal) evaluates nothing and gets
+    visibility 0 on every lobe, like the reference's scatter into zeros (sg_render.py:155-183); its neighbours in the
+    batch are unaffected."""
+    from robir_amd import renderer, sg_render, synth
+    from robir_oracle import nets as on, sg as osg
+    m = renderer.build_synthetic_model(dev, build_octrees=False)
+    lgt = torch.from_numpy(synth.synth_light_sgs(0, 128))
+    g = torch.Generator().manual_seed(4)
+    pts = (torch.rand(6, 3, generator=g) - 0.5) * 0.4
+    nrm = torch.nn.functional.normalize(torch.rand(6, 3, generator=g) - 0.5, dim=-1)
+    nrm[2] = 0.0
+    u = torch.rand(2, 128, 32, generator=g)
+    for prec in ("f16x3-v2", "f16x3", "fp32"):
+        sg_render.VIS_PRECISION = prec
+        try:
+            v = sg_render._diffuse_vis_core(pts.to(dev), nrm.to(dev), m.visibility_network, lgt.to(dev), u[0].to(dev),
+                                            u[1].to(dev), 1.0, False, None, 1, None).cpu()
+        finally:
+            sg_render.VIS_PRECISION = "f16x3-v2"
+        assert float(v[2].abs().max()) == 0.0, prec
+        lobe = lgt[:, :3] / (lgt[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
+        ref = osg.diffuse_visibility(pts, nrm, lambda p, d: on.vis_logits(oracle_sd, p, d), lobe, lgt[:, 3:4].abs(), u[0], u[1]).t()
+        assert rel_err(v, ref) <= 1e-4, prec
