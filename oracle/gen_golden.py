@@ -481,6 +481,20 @@ def main():
                  **{"out_" + k: ref_rn[k].detach() for k in rk})
         impl.neus_model.deviation_network.variance.data.fill_(0.3)
 
+        # tone mapping (model/color_correction.py, hdr_mode 0), scalar and per-row shifts incl. values outside [1e-4, 1]
+        tmr = net.gamma.hdr_shift
+        gt = torch.Generator().manual_seed(9)
+        tx = torch.rand(257, 3, generator=gt) * 4.0
+        ty = torch.rand(257, 3, generator=gt) * 0.9
+        tsh = torch.rand(257, 1, generator=gt) * 1.4 - 0.2
+        tone = {"x": tx, "y": ty, "shift_rows": tsh, "shift_scalar": torch.tensor([[0.37]])}
+        for tag, sh in (("rows", tsh), ("scalar", tone["shift_scalar"])):
+            tone["ldr_" + tag] = tmr.hdr2ldr(tx, sh).detach()
+            tone["hdr_" + tag] = tmr.ldr2hdr(ty, sh).detach()
+        report("tonemap", **{k: relerr(f(a, tone["shift_" + tag]), tone[o + tag]) for tag in ("rows", "scalar")
+                             for k, f, a, o in (("hdr2ldr_" + tag, orend.hdr2ldr, tx, "ldr_"), ("ldr2hdr_" + tag, orend.ldr2hdr, ty, "hdr_"))})
+        save("tonemap", **tone)
+
         # stage-1 renderer (neus/volume_render/sdf_render.py: cos-annealed alpha), same model, same rays
         for name in ("absl", "absl.flags", "absl.app", "absl.logging"):
             ref_shim._mod(name)

@@ -207,3 +207,14 @@ def test_idr_ray_tracing(oracle_sd, tag):
     assert rel_err(x[both], g["points"][both.numpy()]) <= TOL
     # rays without surface end on the minimal-SDF sample of a flat SDF profile: the argmin may move by one sample
     assert bad_frac(dist[~both], g["dist"][~both.numpy()], 1e-2) <= 0.02
+
+
+def test_tone_mapping():
+    """ACESToneMapping hdr_mode 0 (model/color_correction.py:31-60,116-134) against the reference class's own output."""
+    from robir_oracle import renderer
+    g = load_golden("tonemap")
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for tag in ("rows", "scalar"):
+        sh = torch.from_numpy(g["shift_" + tag])
+        assert rel_err(renderer.hdr2ldr(x, sh), g["ldr_" + tag]) == 0.0
+        assert rel_err(renderer.ldr2hdr(y, sh), g["hdr_" + tag]) == 0.0

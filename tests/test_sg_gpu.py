@@ -151,3 +151,28 @@ def test_specular_term_conditioning(dev):
         print(f"{k}: fp32 oracle vs fp64 {e_oracle:.2e}, kernel vs fp64 {e_kernel:.2e}")
     # the well-conditioned diffuse term keeps the strict bound
     assert rel_err(out["sg_diffuse_rgb"].cpu(), o32["sg_diffuse_rgb"]) <= TOL
+
+
+def test_tone_mapping(dev):
+    """ACESToneMapping hdr_mode 0 (color_correction.py:31-60,116-134): hdr2ldr = aces(x) / t^0.2, ldr2hdr = aces^-1(x t^0.2),
+    t clamped to [1e-4, 1]; scalar and per-row shifts; round trip."""
+    from robir_amd import nets
+    from robir_oracle import renderer as orend
+    tm = nets.ACESToneMapping(0).to(dev)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(513, 3, generator=g) * 4.0
+    for shift in (torch.tensor([[0.37]]), torch.rand(513, 1, generator=g) * 1.4 - 0.2):      # incl. values outside [1e-4, 1]
+        ldr = tm.hdr2ldr(x.to(dev), shift.to(dev)).cpu()
+        assert rel_err(ldr, orend.hdr2ldr(x, shift)) <= 1e-5
+        y = torch.rand(513, 3, generator=g) * 0.9
+        hdr = tm.ldr2hdr(y.to(dev), shift.to(dev)).cpu()
+        assert rel_err(hdr, orend.ldr2hdr(y, shift)) <= 1e-5
+        back = tm.ldr2hdr(tm.hdr2ldr(x.to(dev) * 0.2, shift.to(dev)), shift.to(dev)).cpu()
+        assert rel_err(back, x * 0.2) <= 1e-4
+    assert float(tm.as_input()) == 0.5                                                           # adapt_illum = 0 at init
+    gold = load_golden("tonemap")                                                                # the reference's own output
+    gx, gy = torch.from_numpy(gold["x"]).to(dev), torch.from_numpy(gold["y"]).to(dev)
+    for tag in ("rows", "scalar"):
+        sh = torch.from_numpy(gold["shift_" + tag]).to(dev)
+        assert rel_err(tm.hdr2ldr(gx, sh).cpu(), gold["ldr_" + tag]) <= 1e-5
+        assert rel_err(tm.ldr2hdr(gy, sh).cpu(), gold["hdr_" + tag]) <= 1e-5
