@@ -168,6 +168,9 @@ int rb_sg_shade(const float* normal, const float* view, const float* lgt, int pe
                 float* out_diff, float* out_shadow, rb_stream_t stream);
 /* render_envmap_sg (model/sg_render.py:26-42): rgb[n,3] = sum_k |mu_k| exp(|lambda_k| (d . lobe_k/|lobe_k| - 1)), lgt[M,7] */
 int rb_envmap_sg(const float* lgt, int M, const float* dirs, long n, float* rgb, rb_stream_t stream);
+/* render_envmap (model/sg_render.py:45-59): bilinear lookup of env[H,W,3] (lat-long, row-major) along dirs[n,3]; same
+ * coordinates and border handling as the reference's F.grid_sample(align_corners=True). */
+int rb_envmap_lookup(const float* env, int H, int W, const float* dirs, long n, float* rgb, rb_stream_t stream);
 /* y = x/(|x|+eps) (mode 0) or x/max(|x|,eps) (mode 1) on rows of 3 */
 int rb_normalize3(const float* x, long n, float eps, int mode, float* y, rb_stream_t stream);
 

@@ -308,7 +308,41 @@ __global__ void k_normalize3(const float* __restrict__ x, long n, float eps, int
 
 using namespace rb;
 
+// render_envmap (model/sg_render.py:45-59): bilinear lat-long lookup, torch.grid_sample(align_corners=True, zero padding)
+// semantics: phi = acos(d.z) - 1e-6, theta = atan2(d.y, d.x), x = -theta/pi, y = 2 phi/pi - 1 in [-1, 1].
+__global__ void k_envmap_lookup(const float* __restrict__ env, int H, int W, const float* __restrict__ dirs, long n,
+                                float* __restrict__ rgb) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float pi = (float)3.14159265358979323846;
+  const float phi = acosf(dirs[3 * i + 2]) - 1e-6f;
+  const float theta = atan2f(dirs[3 * i + 1], dirs[3 * i]);
+  const float gx = -theta / pi, gy = (phi / pi) * 2.f - 1.f;
+  const float ix = ((gx + 1.f) / 2.f) * (float)(W - 1), iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float wnw = ((fx + 1.f) - ix) * ((fy + 1.f) - iy), wne = (ix - fx) * ((fy + 1.f) - iy);
+  const float wsw = ((fx + 1.f) - ix) * (iy - fy), wse = (ix - fx) * (iy - fy);
+  auto tex = [&](int y, int x, int c) { return (x >= 0 && x < W && y >= 0 && y < H) ? env[((long)y * W + x) * 3 + c] : 0.f; };
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = 0.f;
+    a += tex(y0, x0, c) * wnw;
+    a += tex(y0, x1, c) * wne;
+    a += tex(y1, x0, c) * wsw;
+    a += tex(y1, x1, c) * wse;
+    rgb[3 * i + c] = a;
+  }
+}
+
 extern "C" {
+
+int rb_envmap_lookup(const float* env, int H, int W, const float* dirs, long n, float* rgb, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(env && dirs && rgb && H >= 1 && W >= 1, "null pointer / empty map");
+  hipLaunchKernelGGL(k_envmap_lookup, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, env, H, W, dirs, n, rgb);
+  return check_launch("k_envmap_lookup");
+}
 
 int rb_envmap_sg(const float* lgt, int M, const float* dirs, long n, float* rgb, rb_stream_t stream) {
   if (n <= 0) return 0;

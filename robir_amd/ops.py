@@ -404,6 +404,15 @@ def envmap_sg(lgt, dirs):
     return rgb
 
 
+def envmap_lookup(env, dirs):
+    env, dirs = _f32(env), _f32(dirs)
+    H, W = env.shape[0], env.shape[1]
+    n = dirs.shape[0]
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dirs.device)
+    call("rb_envmap_lookup", ptr(env), c_int(H), c_int(W), ptr(dirs), c_long(n), ptr(rgb), stream_ptr())
+    return rgb
+
+
 def cesr_net(X, M, kind, blob, n_label=1):
     """kind 0 normal_net (X[M,64] -> [M,3]); 1 shadow_net dense rows (X[M,192] -> [M,2]);
     2 shadow_net on (point, label) pairs (X = point features [M/n_label,64], M rows -> [M,2])."""

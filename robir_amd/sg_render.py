@@ -48,13 +48,9 @@ def compute_envmap(lgtSGs, H, W, upper_hemi=False):
 
 
 def render_envmap(envmap, viewdirs):
-    """Bilinear lat-long lookup (sg_render.py:45-59)."""
-    import torch.nn.functional as F
-    envmap = envmap.permute(2, 0, 1).unsqueeze(0)
-    phi = torch.arccos(viewdirs[:, 2]).reshape(-1) - TINY_NUMBER
-    theta = torch.atan2(viewdirs[:, 1], viewdirs[:, 0]).reshape(-1)
-    grid = torch.stack(((-theta / np.pi), (phi / np.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)
-    return F.grid_sample(envmap, grid, align_corners=True).squeeze().permute(1, 0)
+    """Bilinear lat-long lookup (sg_render.py:45-59): envmap [H,W,3], viewdirs [n,3] -> [n,3]."""
+    d = viewdirs.reshape(-1, 3).float().contiguous()
+    return ops.envmap_lookup(envmap.to(d.device).float().contiguous(), d)
 
 
 # ----------------------------------------------------------------------------------------- visibility

@@ -176,3 +176,24 @@ def test_tone_mapping(dev):
         sh = torch.from_numpy(gold["shift_" + tag]).to(dev)
         assert rel_err(tm.hdr2ldr(gx, sh).cpu(), gold["ldr_" + tag]) <= 1e-5
         assert rel_err(tm.ldr2hdr(gy, sh).cpu(), gold["hdr_" + tag]) <= 1e-5
+
+
+def test_envmap_sg_grid_and_lookup(dev):
+    """compute_envmap / render_envmap_sg against the reference's golden grid, render_envmap (bilinear lat-long lookup)
+    against torch's grid_sample with the reference's coordinate convention (sg_render.py:9-59)."""
+    import torch.nn.functional as F
+    from robir_amd import sg_render
+    g = load_golden("envmap")
+    lgt = torch.from_numpy(g["lgtSGs"]).to(dev)
+    grid = sg_render.compute_envmap(lgt, 8, 16).cpu()
+    assert rel_err(grid, g["grid"]) <= 1e-5
+    gen = torch.Generator().manual_seed(2)
+    env = torch.rand(9, 20, 3, generator=gen)
+    d = torch.nn.functional.normalize(torch.randn(4000, 3, generator=gen), dim=-1)
+    d[:6] = torch.tensor([[0, 0, 1.0], [0, 0, -1.0], [1.0, 0, 0], [-1.0, 0, 0], [0, 1.0, 0], [-1.0, -1e-7, 0]])   # poles, seam
+    phi = torch.arccos(d[:, 2]) - 1e-6
+    theta = torch.atan2(d[:, 1], d[:, 0])
+    q = torch.stack((-theta / np.pi, (phi / np.pi) * 2 - 1)).permute(1, 0)[None, None]
+    ref = F.grid_sample(env.permute(2, 0, 1)[None], q, align_corners=True).squeeze().permute(1, 0)
+    out = sg_render.render_envmap(env.to(dev), d.to(dev)).cpu()
+    assert rel_err(out, ref) <= 1e-4
