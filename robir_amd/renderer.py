@@ -99,7 +99,12 @@ class IDRNetwork(nn.Module):
         if uv.shape[0] != 1:
             raise NotImplementedError("batch size 1 (every runner uses 1)")
         N = uv.shape[1]
-        return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), N,
+        # A call normally is one lock-step chunk, whatever its size (the reference's semantics).  With
+        # `model.lockstep_chunk = 1024` a larger call is rendered as consecutive 1024-pixel chunks in one batched pass --
+        # the same outputs as the runner's split_input(n_pixels=1024) loop at the batched rate.
+        chunk = getattr(self, "lockstep_chunk", None)
+        chunk = N if not chunk or N <= chunk else int(chunk)
+        return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), chunk,
                             trainstage, fun_spec, lin_diff, draws, stats, input.get("albedo_ratio"))
 
     def render_chunks(self, uv, pose, K, hdr_shift, chunk=1024, trainstage="Material", draws=None, stats=None):

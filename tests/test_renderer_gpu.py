@@ -166,6 +166,17 @@ def test_batched_chunks_equal_per_chunk_forward(dev, model):
         for k in FIELDS + ("points", "sdf_output"):
             e = rel_err(big[k][sl].cpu(), one[k].cpu())
             assert e <= 1e-6, (i, k, e)
+    # forward() itself with model.lockstep_chunk = 1024: one call on all 3072 pixels == the batched render
+    model.lockstep_chunk = 1024
+    try:
+        inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+               "object_mask": torch.ones(1, 3072, dtype=torch.bool, device=dev), "hdr_shift": hdr}
+        whole = model(inp, trainstage="Material", train_spec=True, draws=cat)
+    finally:
+        model.lockstep_chunk = None
+    assert torch.equal(whole["network_object_mask"], big["network_object_mask"])
+    for k in FIELDS + ("points", "sdf_output"):
+        assert rel_err(whole[k].cpu(), big[k].cpu()) == 0.0, k          # NaN-aware (axis-parallel rays)
 
 
 def test_illum_and_trace_radiance_vs_golden(dev, model_oracle_tables):
