@@ -541,4 +541,37 @@ __device__ __forceinline__ void load_features(const float* __restrict__ X, long 
   }
 }
 
+// float4s of one packed layer (N/16 chunks)
+template <int K, int N>
+__host__ __device__ constexpr long layer_f4() { return (long)(N / 16) * chunk_f4(K); }
+
+// Softplus(beta=100) of a layer's pre-activations (two tiles).  JVP: rows come in groups of four (value row + three tangent
+// rows of a point, lane & 3): the value row gets softplus, the tangent rows z' * sigmoid(100 z) with z read from the
+// value lane.  `zs` un-scales the MFMA result first (split-precision layers), `scale` scales the output (skip: 1/sqrt 2).
+template <int NREG, int HREG, bool JVP, bool PRECISE = false>
+__device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (&h)[2][HREG], int lane, float scale,
+                                              float zs = 1.0f) {
+  if constexpr (JVP) {
+    const bool is_val = (lane & 3) == 0;
+    const int src = lane & ~3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) {
+        const float zi = z[t][i] * zs;
+        const float zv = __shfl(zi, src);
+        float sig;
+        const float sp = softplus100<PRECISE>(zv, &sig);   // value row: softplus; tangent rows: z' * sigmoid(100 z)
+        const float v = is_val ? sp : zi * sig;
+        h[t][i] = v * scale;
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < NREG; ++i) h[t][i] = softplus100<PRECISE>(z[t][i] * zs, nullptr) * scale;
+  }
+}
+
+
 }  // namespace rb
