@@ -79,3 +79,27 @@ def test_mlp_precision_switch(monkeypatch):
     import pytest
     with pytest.raises(ValueError):
         nets.mlp_precision()
+
+
+def test_object_surface_of_the_reference_model():
+    """Attributes the reference's runners touch on the model (SURVEY 8b 'Object surface'): present, callable where the
+    runners call them, `get_sg_render` assignable per instance (train_pbr.py:413)."""
+    import types
+    from robir_amd import renderer
+    m = renderer.IDRNetwork(renderer.hotdog_conf())
+    for path in ("implicit_network.gradient", "implicit_network.batch_borrow_color", "implicit_network.neus_model.dev",
+                 "ray_tracer.generate", "octree_ray_tracer.generate", "indirect_illum_network", "visibility_network",
+                 "envmap_material_network.get_light", "envmap_material_network.load_light", "envmap_material_network.lgtSGs",
+                 "envmap_material_network.specular_reflectance", "envmap_material_network.upper_hemi",
+                 "envmap_material_network.spec_brdf_encoder_layer.var", "envmap_material_network.spec_brdf_encoder_layer.lc_act",
+                 "gamma.hdr_shift.as_input", "gamma.hdr_shift.hdr2ldr", "gamma.hdr_shift.ldr2hdr", "gamma.hdr_shift.fit_data",
+                 "get_idr_render", "get_sg_render", "trace_radiance", "state_dict", "load_state_dict"):
+        obj = m
+        for part in path.split("."):
+            assert hasattr(obj, part), path
+            obj = getattr(obj, part)
+    assert hasattr(m.envmap_material_network, "envmap")
+    hook = lambda self, *a, **k: "hooked"
+    m.get_sg_render = types.MethodType(hook, m)
+    assert m.get_sg_render() == "hooked"
+    assert m.octree_ray_tracer.max_iter == 32
