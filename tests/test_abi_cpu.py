@@ -103,3 +103,33 @@ def test_object_surface_of_the_reference_model():
     m.get_sg_render = types.MethodType(hook, m)
     assert m.get_sg_render() == "hooked"
     assert m.octree_ray_tracer.max_iter == 32
+
+
+def test_overlay_exports_reference_names():
+    """overlay/model/*.py (PEP-420 namespace overlay put in front of the reference's model/ directory) re-export the public
+    names the reference's runners and scripts import from those modules."""
+    import importlib
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "overlay")
+    sys.path.insert(0, root)
+    try:
+        want = {
+            "model.sg_render": ["render_with_all_sg", "render_with_sg", "compute_envmap", "render_envmap", "render_envmap_sg",
+                                "get_diffuse_visibility", "get_specular_visibility", "norm_axis", "TINY_NUMBER"],
+            "model.implicit_differentiable_renderer": ["IDRNetwork", "IndirctIllumNetwork", "VisNetwork"],
+            "model.octree_tracing": ["OctreeTracing", "OctreeVisModel"],
+            "model.ray_tracing": ["RayTracing"],
+            "model.sg_envmap_material": ["SparseAE", "EnvmapMaterialNetwork", "fibonacci_sphere", "compute_energy"],
+            "model.neus_model": ["SDFNetwork", "RenderingNetwork", "SingleVarianceNetwork", "NeuSModel", "ImplicitNetworkMy"],
+            "model.embedder": ["get_embedder"],
+            "model.color_correction": ["ACESToneMapping", "GammaCorrect"],
+            "model.sdf_render": ["render_neus", "Rays"],
+        }
+        for mod, names in want.items():
+            m = importlib.import_module(mod)
+            for n in names:
+                assert hasattr(m, n), (mod, n)
+    finally:
+        sys.path.remove(root)
+        for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
+            del sys.modules[k]
