@@ -133,3 +133,25 @@ def test_overlay_exports_reference_names():
         sys.path.remove(root)
         for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
             del sys.modules[k]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/model"), reason="needs the reference checkout (build container only)")
+def test_overlay_shadows_reference_modules_by_path_order():
+    """INTEGRATION.md seam B: with overlay/ ahead of the reference on the path, `model.<overlaid>` comes from this repo and
+    every other `model.*` module still comes from the reference (PEP-420: `model/` has no __init__.py on either side).
+    Run in a subprocess so that the module cache of the test session stays clean."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, importlib.util\n"
+        "a = importlib.util.find_spec('model.sg_render').origin\n"
+        "b = importlib.util.find_spec('model.octree_tracing').origin\n"
+        "c = importlib.util.find_spec('model.loss').origin\n"
+        "print(a); print(b); print(c)\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "overlay"), root, "/root/reference"]))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    a, b, c = out.stdout.strip().splitlines()[-3:]
+    assert a.startswith(os.path.join(root, "overlay")) and b.startswith(os.path.join(root, "overlay"))
+    assert c.startswith("/root/reference/model")
