@@ -227,6 +227,8 @@ int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv,
                    rb_stream_t stream);
 int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,
                     float* pts, rb_stream_t stream);
+/* ACESToneMapping (model/color_correction.py:31-73,116-134): mode = op + 16 * curve; op 0 hdr2ldr, 1 ldr2hdr, 2 ldr2hdr(x^2.2);
+ * curve 0 = hdr_mode 0 (scale_aces, every shipped conf), 1 = hdr_mode 1 (warp_aces), 2 = hdr_mode 2 (ln_space), 3 = identity. */
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream);
 /* Element-wise heads of the hooks / networks:
  * rb_material_decode: EnvmapMaterialNetwork outputs from the spec-AE's [n,5] (model/sg_envmap_material.py:205-211);

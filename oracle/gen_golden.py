@@ -493,6 +493,16 @@ def main():
             tone["hdr_" + tag] = tmr.ldr2hdr(ty, sh).detach()
         report("tonemap", **{k: relerr(f(a, tone["shift_" + tag]), tone[o + tag]) for tag in ("rows", "scalar")
                              for k, f, a, o in (("hdr2ldr_" + tag, orend.hdr2ldr, tx, "ldr_"), ("ldr2hdr_" + tag, orend.ldr2hdr, ty, "hdr_"))})
+        # the other curve pairs of the class (hdr_mode 1 warp_aces, 2 ln_space, -1 identity)
+        from model.color_correction import ACESToneMapping as RefTone
+        for hm in (1, 2, -1):
+            rt = RefTone(hdr_mode=hm)
+            for tag, sh in (("rows", tsh), ("scalar", tone["shift_scalar"])):
+                key = "m%d_%s" % (hm if hm >= 0 else 9, tag)
+                tone["ldr_" + key] = rt.hdr2ldr(tx, sh).detach()
+                tone["hdr_" + key] = rt.ldr2hdr(ty * 0.7, sh).detach()
+                report("tonemap_" + key, hdr2ldr=relerr(orend.hdr2ldr(tx, sh, hm), tone["ldr_" + key]),
+                       ldr2hdr=relerr(orend.ldr2hdr(ty * 0.7, sh, hm), tone["hdr_" + key]))
         save("tonemap", **tone)
 
         # stage-1 renderer (neus/volume_render/sdf_render.py: cos-annealed alpha), same model, same rays

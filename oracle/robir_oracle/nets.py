@@ -132,7 +132,7 @@ def sparse_ae(sd, prefix, x, noise, smooth_on_latent, latent_act, out_act, var=N
 def indirect_illum(sd, pts, hdr_shift, noise):
     """IndirctIllumNetwork.forward (implicit_differentiable_renderer.py:199-222).
     -> lgt_sgs [n,24,7] (unit lobe from two sigmoids, lambda = sigmoid*30+0.1, mu = relu), env_int [n,3]."""
-    feat = torch.cat([pe(pts, 10), hdr_shift], -1)
+    feat = pe(pts, 10) if hdr_shift is None else torch.cat([pe(pts, 10), hdr_shift], -1)   # None: no_hdr (hdr_mode -1)
     out = _seq(sd, ILL + "lobe_layer.", 5, feat, torch.relu).reshape(-1, 24, 6)
     ab = torch.sigmoid(out[..., :2])
     theta, phi = ab[..., :1] * 2 * math.pi, ab[..., 1:2] * math.pi

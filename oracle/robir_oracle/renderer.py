@@ -46,14 +46,32 @@ def make_shift(t):
     return torch.clamp(t, 1e-4, 1)
 
 
-def hdr2ldr(x, t):
-    """hdr_mode 0: aces(x) / t**0.2 (color_correction.py:57-60,128-130)."""
-    return aces(x) / make_shift(t) ** 0.2
+def hdr2ldr(x, t, hdr_mode=0):
+    """ACESToneMapping.hdr2ldr (color_correction.py:128-130) with the curve pair of color_correction.py:82-93:
+    hdr_mode 0 scale_aces_fn (57-60), 1 warp_aces_fn (48-49), 2 ln_space_fn (67-69), anything else identity."""
+    t = make_shift(t)
+    if hdr_mode == 0:
+        return aces(x) / t ** 0.2
+    if hdr_mode == 1:
+        return aces(aces_inverse(0.73 * t) / 0.73 * x) / t
+    if hdr_mode == 2:
+        x = x * (0.5 + t) / 0.5
+        return x / (1 + t * x)
+    return x
 
 
-def ldr2hdr(x, t):
-    """hdr_mode 0: aces^-1(x * t**0.2) (color_correction.py:52-55,132-134)."""
-    return aces_inverse(x * make_shift(t) ** 0.2)
+def ldr2hdr(x, t, hdr_mode=0):
+    """ACESToneMapping.ldr2hdr (color_correction.py:132-134): hdr_mode 0 scale_aces_inv (52-55), 1 warp_aces_inv (44-45),
+    2 ln_space_inv (72-74), anything else identity."""
+    t = make_shift(t)
+    if hdr_mode == 0:
+        return aces_inverse(x * t ** 0.2)
+    if hdr_mode == 1:
+        return 0.73 * aces_inverse(x * t) / aces_inverse(0.73 * t)
+    if hdr_mode == 2:
+        y = x / (1 - t * x)
+        return y * 0.5 / (0.5 + t)
+    return x
 
 
 def hdr_shift_as_input(sd):

@@ -48,22 +48,37 @@ __device__ __forceinline__ float aces_inv(float x) {
   const float q = 0.59f * x - 0.03f;
   return (q + sqrtf(q * q + 4.f * (2.51f - 2.43f * x) * 0.14f * x)) / (2.f * (2.51f - 2.43f * x));
 }
-// mode 0: hdr2ldr = aces(x)/t^0.2 ; mode 1: ldr2hdr = aces^-1(x * t^0.2) ; mode 2: ldr2hdr(x^2.2) (trace_radiance)
-// shift: [n] per row (rows of 3 channels) or a single value (shift_stride 0); clamped to [1e-4, 1]
+// ACESToneMapping.hdr2ldr / ldr2hdr (color_correction.py:31-73,116-134).  op 0: hdr2ldr, 1: ldr2hdr, 2: ldr2hdr(x^2.2)
+// (trace_radiance); hdr_mode 0: aces(x) / t^0.2 | aces^-1(x t^0.2) (every shipped conf); 1: energy-warped ACES;
+// 2: log-space curve; anything else: identity.  shift: [n] per row (rows of 3 channels) or a single value
+// (shift_stride 0), clamped to [1e-4, 1].
 __global__ void k_tonemap(const float* __restrict__ x, long n, const float* __restrict__ shift, int shift_stride,
-                          int mode, float* __restrict__ y) {
+                          int op, int hdr_mode, float* __restrict__ y) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= 3 * n) return;
   float t = shift[(i / 3) * shift_stride];
   t = fminf(fmaxf(t, 1e-4f), 1.f);
-  const float tp = powf(t, 0.2f);
   float v = x[i];
-  if (mode == 0) {
-    y[i] = aces(v) / tp;
+  if (op == 2) v = powf(v, 2.2f);
+  const bool inverse = op != 0;
+  float r;
+  if (hdr_mode == 0) {
+    const float tp = powf(t, 0.2f);
+    r = inverse ? aces_inv(v * tp) : aces(v) / tp;
+  } else if (hdr_mode == 1) {
+    r = inverse ? 0.73f * aces_inv(v * t) / aces_inv(0.73f * t) : aces(aces_inv(0.73f * t) / 0.73f * v) / t;
+  } else if (hdr_mode == 2) {
+    if (inverse) {
+      const float u = v / (1.f - t * v);
+      r = u * 0.5f / (0.5f + t);
+    } else {
+      const float u = v * (0.5f + t) / 0.5f;
+      r = u / (1.f + t * u);
+    }
   } else {
-    if (mode == 2) v = powf(v, 2.2f);
-    y[i] = aces_inv(v * tp);
+    r = v;
   }
+  y[i] = r;
 }
 
 // ---- secondary-ray pieces (implicit_differentiable_renderer.py:583-641, neus_model.py:828-871)
@@ -307,8 +322,9 @@ int rb_lin_diff_combine(const float* diffuse, const float* albedo, const float* 
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream) {
   if (n <= 0) return 0;
   RB_REQUIRE(x && shift && y, "null pointer");
-  RB_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0..2");
-  hipLaunchKernelGGL(k_tonemap, grid1d(3 * n, 256), dim3(256), 0, (hipStream_t)stream, x, n, shift, shift_stride, mode, y);
+  RB_REQUIRE((mode & 15) <= 2 && mode >= 0, "mode = op (0 hdr2ldr, 1 ldr2hdr, 2 ldr2hdr(x^2.2)) + 16 * hdr_mode code (0, 1, 2, 3 = identity)");
+  hipLaunchKernelGGL(k_tonemap, grid1d(3 * n, 256), dim3(256), 0, (hipStream_t)stream, x, n, shift, shift_stride, mode & 15,
+                     mode >> 4, y);
   return check_launch("k_tonemap");
 }
 

@@ -195,27 +195,28 @@ class IndirctIllumNetwork(nn.Module):
 
     def __init__(self, multires=0, dims=[128, 128, 128, 128], num_lgt_sgs=24, no_hdr=False):
         super().__init__()
-        if multires != 10 or num_lgt_sgs != 24 or no_hdr:
-            raise NotImplementedError("HIP indirect-illumination kernels: multires=10, 24 lobes, hdr input")
+        if multires != 10 or num_lgt_sgs != 24:
+            raise NotImplementedError("HIP indirect-illumination kernels: multires=10, 24 lobes")
         _require_dims("indirect_illum_network", dims, [512] * 4)
         self.num_lgt_sgs = num_lgt_sgs
-        self.use_hdr = True
-        layers, dim = [], 64
+        self.use_hdr = not no_hdr              # hdr_mode == -1: no hdr-shift input column (feature 63 stays zero)
+        in_dim = 64 if self.use_hdr else 63
+        layers, dim = [], in_dim
         for d in dims:
             layers += [nn.Linear(dim, d), nn.ReLU()]
             dim = d
         layers.append(nn.Linear(dim, num_lgt_sgs * 6))
         self.lobe_layer = nn.Sequential(*layers)
-        self.integral_layer = SparseAE(64, 3, out_act=None, smooth_on_latent=False)
+        self.integral_layer = SparseAE(in_dim, 3, out_act=None, smooth_on_latent=False)
         self.integral_layer.lc_act = torch.nn.functional.softplus
         self._packed = _Packed()
 
-    def forward(self, points, hdr_shift, noise=None):
+    def forward(self, points, hdr_shift=None, noise=None):
         n = points.shape[0]
         dev = points.device
         blob = self._packed.get("lobe", self.lobe_layer, lambda sd: packing.pack_illum(
             {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
-        X = ops.feat_pe10(points.float().contiguous(), extra=hdr_shift.float().contiguous())
+        X = ops.feat_pe10(points.float().contiguous(), extra=hdr_shift.float().contiguous() if self.use_hdr else None)
         if mlp_precision() == "f16x3":
             blob3 = self._packed.get("lobe_h3", self.lobe_layer, lambda sd: packing.pack_illum_h3(
                 {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
@@ -224,6 +225,8 @@ class IndirctIllumNetwork(nn.Module):
             sgs = ops.illum_decode(ops.illum_mlp(X, blob))
         if noise is None:
             noise = torch.randn(n, 64, device=dev)
+        elif noise.shape[1] < 64:                # no_hdr: the reference draws randn_like of the 63 embedded columns
+            noise = torch.nn.functional.pad(noise, (0, 64 - noise.shape[1]))
         Xn = ops.axpy(X, noise.float().contiguous(), 0.02)
         _, second = self.integral_layer.run(X, X_noisy=Xn, need_first=False)
         return sgs, ops.abs_scale(second, 1.0)
@@ -575,14 +578,13 @@ class ImplicitNetworkMy(nn.Module):
 
 # ----------------------------------------------------------------------------------------- tone mapping
 class ACESToneMapping(nn.Module):
-    """color_correction.py:76-137, hdr_mode 0 (scale_aces pair)."""
+    """color_correction.py:76-137: hdr_mode 0 scale_aces (every shipped conf), 1 warp_aces, 2 ln_space, else identity."""
 
     def __init__(self, hdr_mode=0):
         super().__init__()
-        if hdr_mode != 0:
-            raise NotImplementedError("only hdr_mode = 0 (every shipped conf) is built")
         self.adapt_illum = nn.Parameter(torch.tensor(0.0))
         self.hdr_mode = hdr_mode
+        self._curve = hdr_mode if hdr_mode in (0, 1, 2) else 3
 
     def as_input(self):
         return torch.clamp(self.adapt_illum * 10 + 0.5, 0, 1).view(1, 1)
@@ -602,7 +604,7 @@ class ACESToneMapping(nn.Module):
         sh = self.make_shift(raw_shift).reshape(-1).to(xs.device)
         if sh.numel() != 1 and sh.numel() != xs.shape[0]:
             sh = sh.expand(xs.shape[0]) if sh.numel() == 1 else sh.reshape(-1)
-        return ops.tonemap(xs, sh.contiguous(), mode).reshape(shape)
+        return ops.tonemap(xs, sh.contiguous(), mode + 16 * self._curve).reshape(shape)
 
     def hdr2ldr(self, x, raw_shift=None):
         return self._apply_tm(x, raw_shift, 0)

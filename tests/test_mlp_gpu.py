@@ -194,3 +194,24 @@ def test_wide_nets_split_precision(dev, synth_weights):
         a = ops.ae_encode(feats, enc).cpu()
         b = ops.wide_mlp_h3(feats, enc3, True, packing.H3_SCALE_LOG2).cpu()
         assert rel_err(b, a) <= 1e-5, prefix
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_illum_network_without_hdr_input(dev, precision, monkeypatch):
+    """IndirctIllumNetwork(no_hdr=True) -- conf hdr_mode = -1 (implicit_differentiable_renderer.py:181-203,285): 63 embedded
+    inputs, no hdr-shift column, for the lobe net and the integral SparseAE alike."""
+    from robir_amd import nets as hnets
+    from robir_oracle import nets as onets
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", precision)
+    torch.manual_seed(5)
+    net = hnets.IndirctIllumNetwork(multires=10, dims=[512] * 4, num_lgt_sgs=24, no_hdr=True)
+    assert net.lobe_layer[0].weight.shape[1] == 63 and net.integral_layer.brdf_encoder_layer[0].weight.shape[1] == 63
+    sd = {"indirect_illum_network." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(6)
+    pts = torch.rand(777, 3, generator=g) * 1.6 - 0.8
+    noise = torch.randn(777, 63, generator=g)
+    sgs, integ = net(pts.to(dev), None, noise=noise.to(dev))
+    ref_sgs, ref_int = onets.indirect_illum(sd, pts, None, noise)
+    assert rel_err(sgs.cpu(), ref_sgs) <= TOL
+    assert rel_err(integ.cpu(), ref_int) <= TOL

@@ -210,7 +210,7 @@ def test_idr_ray_tracing(oracle_sd, tag):
 
 
 def test_tone_mapping():
-    """ACESToneMapping hdr_mode 0 (model/color_correction.py:31-60,116-134) against the reference class's own output."""
+    """ACESToneMapping, every hdr_mode (model/color_correction.py:31-93,116-134), against the reference class's own output."""
     from robir_oracle import renderer
     g = load_golden("tonemap")
     x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
@@ -218,3 +218,6 @@ def test_tone_mapping():
         sh = torch.from_numpy(g["shift_" + tag])
         assert rel_err(renderer.hdr2ldr(x, sh), g["ldr_" + tag]) == 0.0
         assert rel_err(renderer.ldr2hdr(y, sh), g["hdr_" + tag]) == 0.0
+        for hm, key in ((1, "m1_"), (2, "m2_"), (-1, "m9_")):                      # warp_aces, ln_space, identity
+            assert rel_err(renderer.hdr2ldr(x, sh, hm), g["ldr_" + key + tag]) == 0.0
+            assert rel_err(renderer.ldr2hdr(y * 0.7, sh, hm), g["hdr_" + key + tag]) == 0.0

@@ -154,8 +154,8 @@ def test_specular_term_conditioning(dev):
 
 
 def test_tone_mapping(dev):
-    """ACESToneMapping hdr_mode 0 (color_correction.py:31-60,116-134): hdr2ldr = aces(x) / t^0.2, ldr2hdr = aces^-1(x t^0.2),
-    t clamped to [1e-4, 1]; scalar and per-row shifts; round trip."""
+    """ACESToneMapping (color_correction.py:31-93,116-134): hdr_mode 0 hdr2ldr = aces(x) / t^0.2, ldr2hdr = aces^-1(x t^0.2),
+    t clamped to [1e-4, 1]; scalar and per-row shifts; round trip; then the hdr_mode 1 / 2 / -1 curve pairs."""
     from robir_amd import nets
     from robir_oracle import renderer as orend
     tm = nets.ACESToneMapping(0).to(dev)
@@ -176,6 +176,13 @@ def test_tone_mapping(dev):
         sh = torch.from_numpy(gold["shift_" + tag]).to(dev)
         assert rel_err(tm.hdr2ldr(gx, sh).cpu(), gold["ldr_" + tag]) <= 1e-5
         assert rel_err(tm.ldr2hdr(gy, sh).cpu(), gold["hdr_" + tag]) <= 1e-5
+        for hm, key in ((1, "m1_"), (2, "m2_"), (-1, "m9_")):                      # warp_aces, ln_space, identity curves
+            tmh = nets.ACESToneMapping(hm).to(dev)
+            assert rel_err(tmh.hdr2ldr(gx, sh).cpu(), gold["ldr_" + key + tag]) <= 1e-5, (hm, tag)
+            assert rel_err(tmh.ldr2hdr(gy * 0.7, sh).cpu(), gold["hdr_" + key + tag]) <= 1e-5, (hm, tag)
+            if hm != 1:                                                            # (mode 1 divides by aces^-1(0.73 t): ill-conditioned at t = 1e-4)
+                back = tmh.ldr2hdr(tmh.hdr2ldr(gx * 0.2, sh), sh).cpu()
+                assert rel_err(back, gx.cpu() * 0.2) <= 1e-4, (hm, tag)
 
 
 def test_envmap_sg_grid_and_lookup(dev):
