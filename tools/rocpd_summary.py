@@ -35,5 +35,33 @@ def main(path):
         print(f"\n(no PMC data: {e})")
 
 
+def gaps(path, anchor="k_dvis_v2", min_us=30.0):
+    """Idle time of the GPU between consecutive kernels inside one step = the span between the ends of the last two
+    launches of `anchor`: total and the largest gaps with their neighbours."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else cols[0]
+    ks = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+    ends = [i for i, k in enumerate(ks) if anchor in k[0]]
+    if len(ends) < 2:
+        print("(fewer than two launches of", anchor, ")")
+        return
+    i0, i1 = ends[-2], ends[-1]
+    span = ks[i1][2] - ks[i0][2]
+    busy = sum(k[2] - k[1] for k in ks[i0 + 1:i1 + 1])
+    print(f"\n## one step ({anchor} end -> {anchor} end): {span/1e6:.2f} ms, kernels {busy/1e6:.2f} ms, idle {(span-busy)/1e6:.2f} ms, "
+          f"{i1 - i0} launches\n")
+    print("| idle us | after | before |\n|---|---|---|")
+    g = []
+    for a, b in zip(ks[i0:i1], ks[i0 + 1:i1 + 1]):
+        g.append((b[1] - a[2], a[0].split("(")[0][:60], b[0].split("(")[0][:60]))
+    for d, a, b in sorted(g, reverse=True)[:25]:
+        if d / 1e3 >= min_us:
+            print(f"| {d/1e3:.0f} | `{a}` | `{b}` |")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+        gaps(sys.argv[1])
