@@ -47,27 +47,41 @@ __device__ __forceinline__ bool in_root(const Root& r, const float x[3]) {
   return ok;
 }
 
-// Octree.query for a point known to be strictly inside the root (octree.py:231-262)
-__device__ __forceinline__ int descend(const Oct& T, const float x[3]) {
+// first-level cell of a point strictly inside the root
+__device__ __forceinline__ int base_cell(const Oct& T, const float x[3]) {
   int ci[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) ci[c] = (int)floorf(((x[c] - T.root.mn[c]) / T.root.sz[c]) * (float)T.root.res[c]);
-  int ptr = (ci[0] * T.root.res[1] + ci[1]) * T.root.res[2] + ci[2];
-  while (true) {
-    const f4 a = T.node[2 * (long)ptr];
-    const int fc = __float_as_int(a[3]);
-    if (fc < 0) break;
-    const f4 b = T.node[2 * (long)ptr + 1];
-    int o[3];
-    const float mn[3] = {a[0], a[1], a[2]}, sz[3] = {b[0], b[1], b[2]};
+  return (ci[0] * T.root.res[1] + ci[1]) * T.root.res[2] + ci[2];
+}
+// child of a split node that contains x: truncation toward zero, then clip (octree.py:32-38)
+__device__ __forceinline__ int child_of(const f4& a, const f4& b, int fc, const float x[3]) {
+  int o[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      int v = (int)(((x[c] - mn[c]) / sz[c]) * 2.f);  // truncation toward zero, then clip (octree.py:32-38)
-      o[c] = v < 0 ? 0 : (v > 1 ? 1 : v);
+  for (int c = 0; c < 3; ++c) {
+    const int v = (int)(((x[c] - a[c]) / b[c]) * 2.f);
+    o[c] = v < 0 ? 0 : (v > 1 ? 1 : v);
+  }
+  return fc + 4 * o[0] + 2 * o[1] + o[2];
+}
+// Octree.query for a point known to be strictly inside the root (octree.py:231-262); also returns the leaf's cached SDF.
+// Both halves of a node are fetched together: one memory latency per level.
+__device__ __forceinline__ int descend(const Oct& T, const float x[3], float& leaf_sdf) {
+  int ptr = base_cell(T, x);
+  while (true) {
+    const f4 a = T.node[2 * (long)ptr], b = T.node[2 * (long)ptr + 1];
+    const int fc = __float_as_int(a[3]);
+    if (fc < 0) {
+      leaf_sdf = b[3];
+      break;
     }
-    ptr = fc + 4 * o[0] + 2 * o[1] + o[2];
+    ptr = child_of(a, b, fc, x);
   }
   return ptr;
+}
+__device__ __forceinline__ int descend(const Oct& T, const float x[3]) {
+  float sv;
+  return descend(T, x, sv);
 }
 
 __device__ __forceinline__ int locate(const Oct& T, const float x[3]) { return in_root(T.root, x) ? descend(T, x) : -1; }
@@ -128,19 +142,49 @@ __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const 
   float near;
   float far = slab(mn, sz, pos, d, near);
   if (far < (float)((double)m * step)) {   // python: far < multi_samp * step_size (double product, cast to fp32)
-    // fine march on the cached cell SDF: sample i at t_(i+1), stop one step before the first cell with sdf <= step
+    // fine march on the cached cell SDF: sample i at t_(i+1), stop one step before the first cell with sdf <= step.
+    // FB samples descend the tree together (branch-free, so their node reads are in flight at the same time): the walk
+    // is a chain of dependent L2 reads per sample, and a lock-step batch of 1024 rays has no other work to hide it.
     const float stepf = (float)step;
+    constexpr int FB = 4;
     int j = m;
-    for (int i = 0; i < m; ++i) {
-      const float tm = lin01(i + 1, m) * (float)m * stepf + stepf;
-      const float q[3] = {pos[0] + d[0] * tm, pos[1] + d[1] * tm, pos[2] + d[2] * tm};
-      int ptr = locate(T, q);
-      if (ptr < 0) ptr = (int)(T.B - 1);  // sdf_val[-1] (octree.py:465-466)
-      const float sv = T.node[2 * (long)ptr + 1][3];
-      if (sv <= stepf) {
-        j = i;
-        break;
+    for (int i0 = 0; i0 < m && j == m; i0 += FB) {
+      float q[FB][3], sv[FB];
+      int ptr[FB];
+      bool done[FB];
+#pragma unroll
+      for (int k = 0; k < FB; ++k) {
+        const float tm = lin01(i0 + k + 1, m) * (float)m * stepf + stepf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[k][c] = pos[c] + d[c] * tm;
+        const bool inside = (i0 + k < m) && in_root(T.root, q[k]);
+        ptr[k] = inside ? base_cell(T, q[k]) : (int)(T.B - 1);   // outside: sdf_val[-1] (octree.py:465-466)
+        done[k] = !inside;
+        sv[k] = 0.f;
       }
+      bool any = true;
+      while (any) {
+        f4 a[FB], b[FB];
+#pragma unroll
+        for (int k = 0; k < FB; ++k) {
+          a[k] = T.node[2 * (long)ptr[k]];
+          b[k] = T.node[2 * (long)ptr[k] + 1];
+        }
+        any = false;
+#pragma unroll
+        for (int k = 0; k < FB; ++k) {
+          const int fc = __float_as_int(a[k][3]);
+          const bool leaf = done[k] || fc < 0;
+          sv[k] = b[k][3];
+          const int nxt = child_of(a[k], b[k], fc, q[k]);
+          ptr[k] = leaf ? ptr[k] : nxt;
+          done[k] = leaf;
+          any = any || !leaf;
+        }
+      }
+#pragma unroll
+      for (int k = FB - 1; k >= 0; --k)
+        if (i0 + k < m && sv[k] <= stepf) j = i0 + k;
     }
     far = lin01(j, m) * (float)m * stepf + stepf;
   }
@@ -152,8 +196,76 @@ __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const 
     s.leaf = -1;
     s.active = false;
   } else {
-    s.leaf = descend(T, pos);
-    s.active = !(T.node[2 * (long)s.leaf + 1][3] <= 1e-4f);
+    float sv;
+    s.leaf = descend(T, pos, sv);
+    s.active = !(sv <= 1e-4f);
+  }
+}
+
+// ---- pieces of cast_step for the workgroup-cooperative form of k_cast_batched
+// first half: exit distance of the current cell; `need` = the fine march applies (octree.py:540-546)
+__device__ __forceinline__ float step_begin(const Oct& T, const float o[3], const float d[3], const RayState& s, int m,
+                                            double step, float pos[3], bool& need) {
+  pos[0] = o[0] + s.t * d[0];
+  pos[1] = o[1] + s.t * d[1];
+  pos[2] = o[2] + s.t * d[2];
+  const f4 a = T.node[2 * (long)s.leaf], b = T.node[2 * (long)s.leaf + 1];
+  const float mn[3] = {a[0], a[1], a[2]}, sz[3] = {b[0], b[1], b[2]};
+  float near;
+  const float far = slab(mn, sz, pos, d, near);
+  need = far < (float)((double)m * step);
+  return far;
+}
+// FB fine-march samples (ray slot, sample index), any rays: cached SDF of the cell each one falls in
+template <int FB>
+__device__ __forceinline__ void march_samples(const Oct& T, const float (*req)[6], const int (&slot)[FB], const int (&idx)[FB],
+                                              const bool (&valid)[FB], int m, float stepf, float (&sv)[FB]) {
+  float q[FB][3];
+  int ptr[FB];
+  bool done[FB];
+#pragma unroll
+  for (int k = 0; k < FB; ++k) {
+    const float tm = lin01(idx[k] + 1, m) * (float)m * stepf + stepf;
+    const float* r = req[slot[k]];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[k][c] = r[c] + r[3 + c] * tm;
+    const bool inside = valid[k] && in_root(T.root, q[k]);
+    ptr[k] = inside ? base_cell(T, q[k]) : (int)(T.B - 1);   // outside: sdf_val[-1] (octree.py:465-466)
+    done[k] = !inside;
+    sv[k] = 0.f;
+  }
+  bool any = true;
+  while (any) {
+    f4 a[FB], b[FB];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      a[k] = T.node[2 * (long)ptr[k]];
+      b[k] = T.node[2 * (long)ptr[k] + 1];
+    }
+    any = false;
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      const int fc = __float_as_int(a[k][3]);
+      const bool leaf = done[k] || fc < 0;
+      sv[k] = b[k][3];
+      const int nxt = child_of(a[k], b[k], fc, q[k]);
+      ptr[k] = leaf ? ptr[k] : nxt;
+      done[k] = leaf;
+      any = any || !leaf;
+    }
+  }
+}
+// second half: advance by `far`, next cell (octree.py:560-573)
+__device__ __forceinline__ void step_end(const Oct& T, const float o[3], const float d[3], RayState& s, float far) {
+  s.t = s.t + (far + 1e-3f);
+  const float pos[3] = {o[0] + s.t * d[0], o[1] + s.t * d[1], o[2] + s.t * d[2]};
+  if (!in_root(T.root, pos)) {
+    s.leaf = -1;
+    s.active = false;
+  } else {
+    float sv;
+    s.leaf = descend(T, pos, sv);
+    s.active = !(sv <= 1e-4f);
   }
 }
 
@@ -208,13 +320,16 @@ __global__ __launch_bounds__(1024) void k_cast_batched(Oct T, const float* __res
                                                         float* __restrict__ t_out, int* __restrict__ sched,
                                                         int sched_cap) {
   __shared__ int s_cnt[2];
+  __shared__ int s_nreq;
+  __shared__ float req[1024][6];   // fine-march requests of this iteration: sample origin and direction
+  __shared__ int jmin[1024];       // first sample of a request whose cell has sdf <= step (m = none)
   const int tid = threadIdx.x;
   const long base = (long)blockIdx.x * batch;
   const long rem = R_total - base;
   const int R = (int)(rem < batch ? rem : batch);
   const long ray = base + tid;
   const bool mine = tid < R;
-  float o[3] = {0.f, 0.f, 0.f}, oc[3], d[3] = {1.f, 0.f, 0.f};
+  float o[3] = {0.f, 0.f, 0.f}, oc[3] = {0.f, 0.f, 0.f}, d[3] = {1.f, 0.f, 0.f};
   RayState s;
   s.t = -1.f;
   s.leaf = -1;
@@ -232,6 +347,7 @@ __global__ __launch_bounds__(1024) void k_cast_batched(Oct T, const float* __res
   if (tid == 0) {
     s_cnt[0] = 0;
     s_cnt[1] = 0;
+    s_nreq = 0;
   }
   __syncthreads();
   {
@@ -239,6 +355,7 @@ __global__ __launch_bounds__(1024) void k_cast_batched(Oct T, const float* __res
     if ((tid & 63) == 0 && m) atomicAdd(&s_cnt[0], __popcll(m));
   }
   __syncthreads();
+  const float stepf = (float)step;
   int it = 0;
   while (true) {
     const int n_act = s_cnt[it & 1];
@@ -252,8 +369,53 @@ __global__ __launch_bounds__(1024) void k_cast_batched(Oct T, const float* __res
         sched[((long)blockIdx.x * sched_cap + it) * 2 + 1] = m;
       }
     }
+    // -- every active ray: exit distance of its cell; the rays that need the fine march queue a request
+    float far = 0.f;
+    bool need = false;
+    int my_slot = -1;
+    if (s.active) {
+      float pos[3];
+      far = step_begin(T, oc, d, s, m, step, pos, need);
+      if (need) {
+        my_slot = atomicAdd(&s_nreq, 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          req[my_slot][c] = pos[c];
+          req[my_slot][3 + c] = d[c];
+        }
+        jmin[my_slot] = m;
+      }
+    }
     __syncthreads();
-    if (s.active) cast_step(T, oc, d, s, m, step);
+    // -- the n_req x m samples of the iteration (the reference's flat [n_act * multi_samp] query, octree.py:546-558;
+    // at most ~10 R of them by construction of multi_samp) spread over all 1024 threads, four tree walks in flight each
+    {
+      constexpr int FB = 4;
+      const int total = s_nreq * m;
+      for (int w0 = tid; w0 < total; w0 += 1024 * FB) {
+        int slot[FB], idx[FB];
+        bool valid[FB];
+        float sv[FB];
+#pragma unroll
+        for (int k = 0; k < FB; ++k) {
+          const int w = w0 + 1024 * k;
+          valid[k] = w < total;
+          const int wc = valid[k] ? w : 0;
+          slot[k] = wc / m;
+          idx[k] = wc - slot[k] * m;
+        }
+        march_samples<FB>(T, req, slot, idx, valid, m, stepf, sv);
+#pragma unroll
+        for (int k = 0; k < FB; ++k)
+          if (valid[k] && sv[k] <= stepf) atomicMin(&jmin[slot[k]], idx[k]);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_nreq = 0;
+    if (s.active) {
+      if (need) far = lin01(jmin[my_slot], m) * (float)m * stepf + stepf;
+      step_end(T, oc, d, s, far);
+    }
     const unsigned long long bm = __ballot(s.active);
     if ((tid & 63) == 0 && bm) atomicAdd(&s_cnt[(it + 1) & 1], __popcll(bm));
     __syncthreads();
