@@ -318,6 +318,12 @@ int rb_raytrace_pick(const float* sdf, const float* z, const float* P, const uns
 int rb_raytrace_secant(const float* cam, int cam_stride, const float* dirs, const unsigned char* on, const float* smid, long m, int phase,
                        float* bracket, float* zp, float* pmid, rb_stream_t stream);
 
+/* Host-only helper (no GPU work): one PIZ-compressed OpenEXR chunk -> 16-bit words, channel-major
+ * ([channel][line][pixel][word]); chan = n_ch rows of (pixels per line, lines, words per pixel: 1 HALF, 2 FLOAT/UINT).
+ * Used by robir_amd/exr.py to read the relighting environment maps that EnvmapMaterialNetwork.load_light
+ * (model/sg_envmap_material.py:266-268) reads through imageio in the reference. */
+int rb_exr_piz_decode(const unsigned char* src, long n_src, const int* chan, int n_ch, unsigned short* out, long n_out);
+
 #ifdef __cplusplus
 }
 #endif

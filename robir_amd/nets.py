@@ -305,16 +305,12 @@ class EnvmapMaterialNetwork(nn.Module):
         return self.restrict_lobes_upper(lgtSGs) if self.upper_hemi else lgtSGs
 
     def load_light(self, path):
-        """sg_envmap_material.py:257-268 (the .npy light; an .exr background is loaded only if a reader exists)."""
+        """sg_envmap_material.py:257-268: `<path>/sg_128.npy` light SGs + `<path>.exr` background map (read by robir_amd.exr:
+        the reference goes through imageio)."""
         sg = torch.from_numpy(np.load(os.path.join(path, "sg_128.npy"))).to(self.lgtSGs.data.device)
         self.lgtSGs.data = sg
-        exr = path + ".exr"
-        if os.path.exists(exr):
-            try:
-                import imageio
-                self.envmap = torch.from_numpy(np.float32(imageio.imread(exr)[:, :, :3])).to(sg.device)
-            except Exception as e:  # pragma: no cover
-                raise RuntimeError(f"cannot read {exr}: {e}")
+        from .exr import read_exr
+        self.envmap = torch.from_numpy(np.ascontiguousarray(read_exr(path + ".exr")[:, :, :3])).to(sg.device)
 
     def parameter_groups(self, lr=0.0005):
         return [{"lr": lr, "params": self.brdf_encoder_layer.parameters()},
