@@ -143,15 +143,18 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
       a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
       b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
     }
-    // same product order as H3Ring::chunk (hi*lo, hi*hi, lo*hi; corrections share an accumulator)
+    // same product order as H3Ring::chunk (hi*lo, hi*hi, lo*hi; corrections share an accumulator).  The three MFMAs of
+    // a tile are issued back to back: consecutive MFMAs on ONE accumulator hide up to two filler instructions each for
+    // free, MFMAs that alternate between two accumulators do not (tools/ubench/mfma_fill.hip: 0.74 vs 0.45 of the f16
+    // peak at two fillers per MFMA)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
       acc.a[t][V2_CH - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b[t], acc.a[t][V2_CH - 1], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) acc.a[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc.a[t][0], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      acc.a[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a[t], acc.a[t][0], 0, 0, 0);
       acc.a[t][V2_CH - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a[t], acc.a[t][V2_CH - 1], 0, 0, 0);
+      // (no instruction: orders the two tiles' MFMA groups, which the scheduler would otherwise interleave)
+      if (t == 0) asm volatile("" : "+a"(acc.a[0][0]), "+a"(acc.a[1][0]));
+    }
   };
   // relu(z * unscale) of output block jb -> packed operands of the next layer: k-block jb/2, registers 2*(jb&1)+{0,1}.
   // piece = (tile, register pair): four pieces per chunk, spread over the next chunk's k-blocks
