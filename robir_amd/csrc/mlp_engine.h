@@ -298,11 +298,12 @@ __device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl
                                                const unsigned (&xh)[NT][K / 32][4], const unsigned (&xl)[NT][K / 32][4],
                                                float (&out)[NT][N / 4], int lane, float bias_mul) {
   // bias_mul: 0 for rows without bias (tangent columns), otherwise the scale the operands of this lane carry.
-  // Accumulators: two tiles alternate on one chain each; a single tile uses one chain per product (hi*lo, hi*hi, lo*hi)
-  // so that consecutive MFMAs never wait on each other.
+  // Accumulators: one chain per tile.  Consecutive MFMAs on ONE accumulator issue back to back and hide up to two other
+  // instructions each; spreading a tile's three products over three accumulators (the first version, on the assumption
+  // that dependent MFMAs wait on each other) costs 5-6 % here (tools/ubench/mfma_fill.hip, profiles/r01_ubench_mfma_fill.md).
   static_assert(K % 32 == 0 && N % 16 == 0 && (NT == 1 || NT == 2), "split-precision layers: K % 32 == 0, 1 or 2 tiles");
   constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
-  constexpr int CH = NT == 1 ? 3 : 1;
+  constexpr int CH = 1;
   const int g = lane >> 4;
 #pragma unroll
   for (int jb = 0; jb < NJB; ++jb) {
