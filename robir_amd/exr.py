@@ -111,6 +111,16 @@ def _unpiz(data, chans, width, lines):
 
 
 def read_exr(path):
+    """float32 [H, W, C] (C in R, G, B, A order).  Anything malformed or unsupported raises ExrError."""
+    try:
+        return _read(path)
+    except ExrError:
+        raise
+    except (struct.error, IndexError, zlib.error, ValueError, RuntimeError) as e:
+        raise ExrError(f"{path}: malformed OpenEXR file ({type(e).__name__}: {e})") from e
+
+
+def _read(path):
     b = open(path, "rb").read()
     attrs, p = _header(b)
     for need in ("channels", "compression", "dataWindow"):

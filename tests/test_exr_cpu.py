@@ -112,6 +112,12 @@ def test_rejects_what_it_cannot_read(tmp_path):
     open(p, "wb").write(bytes(b))
     with pytest.raises(exr.ExrError, match="DWAA"):
         exr.read_exr(p)
+    # truncated files (header cut, offset table cut, chunk cut) raise the reader's own error type
+    whole = open(os.path.join(GOLD, "envmap3_rows0_15.exr"), "rb").read()
+    for cut in (40, 330, len(whole) // 2):
+        open(p, "wb").write(whole[:cut])
+        with pytest.raises(exr.ExrError):
+            exr.read_exr(p)
     # a corrupted PIZ chunk fails loudly instead of returning noise
     src = bytearray(open(os.path.join(GOLD, "envmap6_rows0_31.exr"), "rb").read())
     src[len(src) // 2] ^= 0xFF
@@ -119,7 +125,7 @@ def test_rejects_what_it_cannot_read(tmp_path):
     open(p, "wb").write(bytes(src))
     try:
         out = exr.read_exr(p)
-    except Exception:
+    except exr.ExrError:
         return
     ref = exr.read_exr(os.path.join(GOLD, "envmap6_rows0_31.exr"))
     assert not np.array_equal(out, ref)
