@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 1
+#define RB_ABI_VERSION 2
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -118,6 +118,9 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  * Light-SG ("diffuse") visibility -- get_diffuse_visibility, model/sg_render.py:111-195.
  * rb_dvis_dirs: per chunk c (C chunks share the light lgt[L,7] but have their own draws u_theta/u_phi[C,L,nsamp]):
  *   dirs[C*L*nsamp,3], wdir[C*L*nsamp] = exp(lambda(d.axis-1)), wsum[C*L] = sum_s wdir + 1e-6.
+ *   direct = 0: lgt holds RAW light SGs (render_with_sg's call chain: lobe normalised twice, |lambda|, sg_render.py:364-366,126);
+ *   direct = 1: lgt[:, :3] / lgt[:, 3] are the lgtSGLobes / lgtSGLambdas of a direct get_diffuse_visibility call
+ *   (normalised once, lambda as given and only clamped >= 1e-4 for the cone, :126-134,179).
  * rb_dvis_fused: one workgroup per point.  A[n,256] = W0[:, :63].PE10(p)+b0 and Bd[C*L*nsamp,256] = W0[:,63:].PE10(d)
  *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
  *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
@@ -128,7 +131,7 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  *                workgroup per CU.  All give identical results up to fp32 summation order.  The production path is
  *                rb_dvis_fused_v2 below.
  * ------------------------------------------------------------------------------------------------------------ */
-int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta, const float* u_phi, float thr,
+int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, int direct, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream);
 int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                   const float* wdir, const float* wsum, const float* Whid, const float* wlast, const float* blast, int L,
@@ -160,9 +163,10 @@ int rb_spec_vis_reduce(const float* logits, const unsigned char* front, const fl
 /* ------------------------------------------------------------------------------------------------------------
  * SG shading -- render_with_sg (model/sg_render.py:343-565) incl. lambda_trick (:84-104), hemisphere_int (:62-81).
  * lgt: [M,7] (per_point_lgt=0) or [n,M,7]; light_vis[n,M] or NULL (comp_vis=False); metallic[n] or NULL;
- * indir_integral[n,3] or NULL (replaces the diffuse term).  Outputs [n,3]; out_shadow may be NULL.
+ * indir_integral[n,3] or NULL (replaces the diffuse term).  f0: DEVICE pointer to the scalar specular reflectance
+ * (|specular_reflectance|, sg_envmap_material.py:160; read by the kernel, no host copy).  Outputs [n,3]; out_shadow may be NULL.
  * ------------------------------------------------------------------------------------------------------------ */
-int rb_sg_shade(const float* normal, const float* view, const float* lgt, int per_point_lgt, int M, float f0,
+int rb_sg_shade(const float* normal, const float* view, const float* lgt, int per_point_lgt, int M, const float* f0,
                 const float* rough, const float* albedo, const float* metallic, const float* light_vis,
                 const float* bvis, const float* indir_integral, int lin_diff, long n, float* out_rgb, float* out_spec,
                 float* out_diff, float* out_shadow, rb_stream_t stream);

@@ -2,7 +2,8 @@
 /root/reference) run on CPU inside the build container.
 
 TEST INFRASTRUCTURE ONLY.  Used by oracle/gen_golden.py to record golden vectors
-and by oracle/check_oracle_vs_ref.py to pin the CPU restatement in oracle/robir_oracle.
+and oracle/gen_golden_r2.py to record golden vectors and, in the same runs, to pin the CPU restatement in
+oracle/robir_oracle (reports: oracle/PINNING.json, oracle/PINNING_r2.json).
 Nothing in robir_amd/, bench.py or the gpu tests imports this file and
 /root/reference does not exist on the GPU box.
 
@@ -27,6 +28,7 @@ def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
     m.__dict__.setdefault("__getattr__", lambda k: _Anything())      # PEP 562: any other attribute is a sink
+    m.__dict__.setdefault("__file__", None)                          # ... except what `inspect` probes on every module
     sys.modules[name] = m
     return m
 

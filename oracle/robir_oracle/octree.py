@@ -179,3 +179,11 @@ def trace(T, cam_loc, ray_dirs, max_iter=-1, trace_log=None):
     d = ray_dirs.reshape(-1, 3)
     t, hit = cast(T, o, d, max_iter, trace_log)
     return t[:, None] * d + o, hit, t
+
+
+def octree_vis_logits(T, points, view_dirs):
+    """OctreeVisModel.forward (model/octree_tracing.py:77-85): the secondary cast (max_iter = 32, set at :68) of ONE lock-step
+    batch of rays `points + s*view_dirs`, returned as the float pair [is_hit, ~is_hit] that callers push through softmax
+    (class 1 = visible, model/loss.py:174-177)."""
+    _, hit = cast(T, points, view_dirs, 32)
+    return torch.stack([hit, ~hit], -1).float()

@@ -201,7 +201,8 @@ __global__ void k_spec_reduce(const float* __restrict__ logits, const unsigned c
 // indir_integral: [n,3] or null (replaces the diffuse term, sg_render.py:532-536).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sg_shade(const float* __restrict__ normal, const float* __restrict__ view,
-                                                   const float* __restrict__ lgt, int per_point_lgt, int M, float f0,
+                                                   const float* __restrict__ lgt, int per_point_lgt, int M,
+                                                   const float* __restrict__ f0_dev,
                                                    const float* __restrict__ rough, const float* __restrict__ albedo,
                                                    const float* __restrict__ metallic,
                                                    const float* __restrict__ light_vis, const float* __restrict__ bvis,
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_sg_shade(const float* __restrict__ norm
   const V3 nn = v3(normal[3 * p], normal[3 * p + 1], normal[3 * p + 2]);
   const V3 vv = v3(view[3 * p], view[3 * p + 1], view[3 * p + 2]);
   const float alb[3] = {albedo[3 * p], albedo[3 * p + 1], albedo[3 * p + 2]};
+  const float f0 = f0_dev[0];      // scalar Fresnel F0 read on the device: no host copy of the parameter
   const SpecLobe sl = spec_lobe(nn, vv, rough[p], f0, alb, metallic ? metallic + p : nullptr);
   const float bv = bvis[p];
   const float* L = lgt + (per_point_lgt ? p * (long)M * 7 : 0L);
@@ -381,12 +383,12 @@ int rb_spec_vis_reduce(const float* logits, const unsigned char* front, const fl
   return check_launch("k_spec_reduce");
 }
 
-int rb_sg_shade(const float* normal, const float* view, const float* lgt, int per_point_lgt, int M, float f0,
+int rb_sg_shade(const float* normal, const float* view, const float* lgt, int per_point_lgt, int M, const float* f0,
                 const float* rough, const float* albedo, const float* metallic, const float* light_vis,
                 const float* bvis, const float* indir_integral, int lin_diff, long n, float* out_rgb, float* out_spec,
                 float* out_diff, float* out_shadow, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(normal && view && lgt && rough && albedo && bvis && out_rgb && out_spec && out_diff, "null pointer");
+  RB_REQUIRE(normal && view && lgt && f0 && rough && albedo && bvis && out_rgb && out_spec && out_diff, "null pointer");
   RB_REQUIRE(M >= 1, "need at least one lobe");
   hipLaunchKernelGGL(k_sg_shade, grid1d(n, 4), dim3(256), 0, (hipStream_t)stream, normal, view, lgt, per_point_lgt, M, f0,
                      rough, albedo, metallic, light_vis, bvis, indir_integral, lin_diff, n, out_rgb, out_spec, out_diff,

@@ -41,7 +41,11 @@ __device__ __forceinline__ void cone_dir(const float axis[3], float u_theta, flo
 
 // One thread per (chunk, lobe): sample directions, SG weights and their per-lobe sum.
 // lgt[L,7] raw light SGs (first row's light is used for every point: sg_render.py:388-390).
-__global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int C, const float* __restrict__ u_theta,
+// direct = 0: lgt are RAW light SGs as render_with_sg receives them (it normalises the lobe and takes |lambda| before the
+// call, sg_render.py:364-366, and get_diffuse_visibility normalises again, :126);  direct = 1: lgt[:, :3] / lgt[:, 3] are
+// the lgtSGLobes / lgtSGLambdas arguments of a direct get_diffuse_visibility call (one normalisation, lambda as given).
+__global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int C, int direct,
+                            const float* __restrict__ u_theta,
                             const float* __restrict__ u_phi, float thr, float* __restrict__ dirs,
                             float* __restrict__ wdir, float* __restrict__ wsum) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,12 +53,12 @@ __global__ void k_dvis_dirs(const float* __restrict__ lgt, int L, int nsamp, int
   const int l = i % L;
   // batch-global minimum sharpness over the lobes (sg_render.py:131-133)
   float mn = 3.0e38f;
-  for (int k = 0; k < L; ++k) mn = fminf(mn, fmaxf(fabsf(lgt[k * 7 + 3]), 1e-4f));
+  for (int k = 0; k < L; ++k) mn = fminf(mn, fmaxf(direct ? lgt[k * 7 + 3] : fabsf(lgt[k * 7 + 3]), 1e-4f));
   const float rng = fminf(mn, thr);
   float a[3] = {lgt[l * 7], lgt[l * 7 + 1], lgt[l * 7 + 2]};
-  unit_eps(a);  // render_with_sg normalisation (sg_render.py:364)
-  unit_eps(a);  // norm_axis inside get_diffuse_visibility (sg_render.py:126)
-  const float lam = fabsf(lgt[l * 7 + 3]);
+  if (!direct) unit_eps(a);  // render_with_sg normalisation (sg_render.py:364)
+  unit_eps(a);               // norm_axis inside get_diffuse_visibility (sg_render.py:126)
+  const float lam = direct ? lgt[l * 7 + 3] : fabsf(lgt[l * 7 + 3]);
   const float sharp = fmaxf(lam, 1e-4f);
   const float phi_range = acosf((-0.95f * rng) / sharp + 1.f);
   float s = 0.f;
@@ -243,11 +247,11 @@ using namespace rb;
 
 extern "C" {
 
-int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, const float* u_theta, const float* u_phi, float thr,
+int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, int direct, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream) {
   RB_REQUIRE(lgt && u_theta && u_phi && dirs && wdir && wsum, "null pointer");
   RB_REQUIRE(L > 0 && nsamp > 0 && C > 0, "bad sizes");
-  hipLaunchKernelGGL(k_dvis_dirs, grid1d((long)C * L, 64), dim3(64), 0, (hipStream_t)stream, lgt, L, nsamp, C, u_theta,
+  hipLaunchKernelGGL(k_dvis_dirs, grid1d((long)C * L, 64), dim3(64), 0, (hipStream_t)stream, lgt, L, nsamp, C, direct, u_theta,
                      u_phi, thr, dirs, wdir, wsum);
   return check_launch("k_dvis_dirs");
 }

@@ -40,6 +40,8 @@ def _header(b):
         p = e + 1
         size = struct.unpack_from("<i", b, p)[0]
         p += 4
+        if size < 0 or p + size > len(b):
+            raise ExrError(f"header attribute {name!r} has an impossible size ({size})")
         attrs[name] = (typ, b[p:p + size])
         p += size
 
@@ -132,13 +134,21 @@ def _read(path):
         raise ExrError(f"compression {_NAMES.get(comp, comp)} is not supported (NONE, RLE, ZIPS, ZIP, PIZ are)")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
+    if not (0 < W <= 65536 and 0 < H <= 65536):
+        raise ExrError(f"implausible dataWindow ({x0},{y0})-({x1},{y1})")
     per = _LINES[comp]
     n_chunks = (H + per - 1) // per
     offsets = struct.unpack_from("<%dQ" % n_chunks, b, p)
     line_bytes = sum(_SIZE[t] for _, t in chans) * W
     planes = {name: np.empty((H, W), dtype=np.float32) for name, _ in chans}
     for off in offsets:
+        if off + 8 > len(b):
+            raise ExrError("chunk offset beyond the end of the file")
         y, size = struct.unpack_from("<ii", b, off)
+        if not (y0 <= y <= y1) or (y - y0) % per != 0:
+            raise ExrError(f"chunk starts at scan line {y}, outside the data window / chunk grid")
+        if size < 0 or off + 8 + size > len(b):
+            raise ExrError("chunk size runs past the end of the file")
         data = b[off + 8:off + 8 + size]
         lines = min(per, y1 + 1 - y)
         raw_n = line_bytes * lines

@@ -6,8 +6,9 @@ model/sg_envmap_material.py:40-275 (SparseAE, EnvmapMaterialNetwork),
 model/neus_model.py:312-438,489-560,644-650,682-884 (SDFNetwork, RenderingNetwork, SingleVarianceNetwork,
 NeuSModel, ImplicitNetworkMy).
 
-Forward-only: the kernels carry no autograd.  A parameter that requires grad while torch.is_grad_enabled() and the
-module is in training mode raises (the drop-in is for inference / --plot_only rendering).
+Forward-only: the kernels carry no autograd.  A forward pass of a module that is in training mode, with grad enabled and
+a parameter that requires grad, raises ForwardOnlyError (`forward_only_guard`; the drop-in is for inference /
+--plot_only rendering) instead of handing detached outputs to a loss.
 Every forward that the reference randomises takes the draws as an optional explicit tensor (`noise=`); when omitted
 they are drawn with torch.randn on the device, in the reference's order.
 """
@@ -41,6 +42,18 @@ class _Packed:
             ent = (sig, builder(sd))
             self._cache[key] = ent
         return ent[1]
+
+
+class ForwardOnlyError(RuntimeError):
+    pass
+
+
+def forward_only_guard(module):
+    """The HIP kernels have no backward: a training-mode call that autograd would have to differentiate must not silently
+    return detached tensors (loss.backward() would then train only whatever still carries a graph)."""
+    if module.training and torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise ForwardOnlyError(f"{type(module).__name__}: robir_amd kernels are forward-only -- call .eval(), wrap the call in "
+                               "torch.no_grad(), or freeze the parameters (training stays on the reference's modules)")
 
 
 def _require_dims(name, got, want):
@@ -93,11 +106,13 @@ class VisNetwork(nn.Module):
 
     def logits_from_features(self, X):
         """X [M,128] = [PE10(p) | PE10(d)] (ops.feat_vis) -> logits [M,2]; arithmetic per robir_amd.MLP_PRECISION."""
+        forward_only_guard(self)
         if mlp_precision() == "fp32":
             return ops.vis_mlp(X, self.packed_full())
         return ops.vis_mlp_h3(X, self.packed_full_h3(), packing.H3_SCALE_LOG2)
 
     def forward(self, points, view_dirs):
+        forward_only_guard(self)
         if points.shape[0] == 0:
             return torch.zeros(0, 2, device=points.device)
         return self.logits_from_features(ops.feat_vis(points.float().contiguous(), view_dirs.float().contiguous()))
@@ -159,6 +174,7 @@ class SparseAE(nn.Module):
     def run(self, X, noise=None, X_noisy=None, need_first=True):
         """X [n,64] padded features.  smooth_on_latent: noise [n,32]; else X_noisy [n,64] = features of the perturbed input.
         need_first=False skips the un-perturbed pass (the indirect-illumination integral only uses the second output)."""
+        forward_only_guard(self)
         enc, dec = self._blobs()
         dev = X.device
         sig_out = self.out_act is not None
@@ -212,6 +228,7 @@ class IndirctIllumNetwork(nn.Module):
         self._packed = _Packed()
 
     def forward(self, points, hdr_shift=None, noise=None):
+        forward_only_guard(self)
         n = points.shape[0]
         dev = points.device
         blob = self._packed.get("lobe", self.lobe_layer, lambda sd: packing.pack_illum(
@@ -268,6 +285,7 @@ class EnvmapMaterialNetwork(nn.Module):
 
     def forward(self, points, train_spec=False, train_norm=False, noise=None):
         """noise: dict with optional 'spec' [n,32] and 'normal' [n,60]."""
+        forward_only_guard(self)
         noise = noise or {}
         n, dev = points.shape[0], points.device
         pts = points.float().contiguous()
@@ -367,6 +385,7 @@ class SDFNetwork(nn.Module):
         """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
         precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
         assert self.kind == "neus"
+        forward_only_guard(self)
         x = x.float().contiguous()
         M = x.shape[0]
         assert not (precise and full)
@@ -381,6 +400,7 @@ class SDFNetwork(nn.Module):
             {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
 
     def _cesr(self, X, M, kind, n_label=1):
+        forward_only_guard(self)
         if mlp_precision() == "f16x3":
             return ops.cesr_net_h3(X, M, kind, self.packed_w512_h3(), packing.H3_SCALE_LOG2, n_label)
         return ops.cesr_net(X, M, kind, self.packed(), n_label)
@@ -437,6 +457,7 @@ class RenderingNetwork(nn.Module):
             {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
 
     def forward(self, points, normals, view_dirs, feature_vectors, x_scale=1.0, feat_scale=1.0):
+        forward_only_guard(self)
         X = ops.feat_color(points.float().contiguous(), view_dirs.float().contiguous(), normals.float().contiguous(),
                            feature_vectors, x_scale=x_scale, feat_scale=feat_scale)
         if mlp_precision() == "f16x3":
@@ -497,6 +518,25 @@ class NeuSModel(nn.Module):
         return rgb.view(shape), out[:, :1].reshape(shape)
 
 
+def load_neus_checkpoint(neus_model, path):
+    """Stage-1 checkpoint `{step:06d}.tar` = {'global_step', 'resume_time', 'model': state_dict, ...} written by
+    neus/optimization/log.py:75-88, read like neus_model.py:779-781 (strict=False).  Keys of the three networks this
+    build evaluates (sdf_network, color_network, deviation_network) must all be present; anything else the checkpoint
+    carries (e.g. an outside-NeRF) is reported, not loaded."""
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    if "model" not in state:
+        raise KeyError(f"{path}: no 'model' entry (found {sorted(state)}) -- not a NeuS stage-1 checkpoint")
+    res = neus_model.load_state_dict(state["model"], strict=False)
+    if res.missing_keys:
+        raise KeyError(f"{path}: NeuS checkpoint lacks {len(res.missing_keys)} tensors of the SDF / colour / variance "
+                       f"networks, e.g. {res.missing_keys[:4]}")
+    if res.unexpected_keys:
+        import warnings
+        warnings.warn(f"{path}: {len(res.unexpected_keys)} tensors not used by this build "
+                      f"(e.g. {res.unexpected_keys[:4]})", RuntimeWarning, stacklevel=2)
+    return int(state.get("global_step", 0))
+
+
 class ImplicitNetworkMy(nn.Module):
     """neus_model.py:755-884: stage-2 wrapper around the NeuS model (points x2 in, all 257 outputs /2 out).
     The constructor arguments of the conf (dims, multires, ...) are ignored exactly like the reference does; the NeuS
@@ -509,12 +549,18 @@ class ImplicitNetworkMy(nn.Module):
         self.bgr = bgr
         try:
             from confs_sg.env_path import NEUS_LOG_DIR, NEUS_ITER      # reference-side global (confs_sg/env_path.py)
-            path = os.path.join(NEUS_LOG_DIR, "{:06d}.tar".format(NEUS_ITER))
-            if os.path.exists(path):
-                state = torch.load(path, map_location="cpu", weights_only=False)
-                self.neus_model.load_state_dict(state["model"], strict=False)
         except ImportError:
-            pass
+            # stand-alone use (tests, bench, robir_amd.render): the caller loads the NeuS weights itself
+            import warnings
+            warnings.warn("ImplicitNetworkMy: confs_sg.env_path is not set up -- the NeuS SDF / colour networks keep their "
+                          "random initialisation until a state dict is loaded", RuntimeWarning, stacklevel=2)
+        else:
+            # the reference raises here when the checkpoint is missing (neus_model.py:779); so do we -- a wrong
+            # NEUS_LOG_DIR / NEUS_ITER must not silently render a randomly initialised surface
+            path = os.path.join(NEUS_LOG_DIR, "{:06d}.tar".format(NEUS_ITER))
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"NeuS checkpoint {path} (confs_sg.env_path) does not exist")
+            load_neus_checkpoint(self.neus_model, path)
 
     def normalize(self, x):
         return x * 2.0

@@ -166,7 +166,7 @@ def normalize3(x, eps, mode):
     return y
 
 
-def dvis_dirs(lgt, u_theta, u_phi, thr=1.0):
+def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
     """lgt [L,7]; u_theta/u_phi [C,L,nsamp] (or [L,nsamp]).  -> dirs [C*L*nsamp,3], wdir [C*L*nsamp], wsum [C*L]."""
     lgt, u_theta, u_phi = _f32(lgt), _f32(u_theta), _f32(u_phi)
     if u_theta.dim() == 2:
@@ -176,7 +176,7 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0):
     dirs = torch.empty(C * L * ns, 3, dtype=torch.float32, device=dev)
     wdir = torch.empty(C * L * ns, dtype=torch.float32, device=dev)
     wsum = torch.empty(C * L, dtype=torch.float32, device=dev)
-    call("rb_dvis_dirs", ptr(lgt), c_int(L), c_int(ns), c_int(C), ptr(u_theta.contiguous()), ptr(u_phi.contiguous()),
+    call("rb_dvis_dirs", ptr(lgt), c_int(L), c_int(ns), c_int(C), c_int(1 if direct else 0), ptr(u_theta.contiguous()), ptr(u_phi.contiguous()),
          c_float(thr), ptr(dirs), ptr(wdir), ptr(wsum), stream_ptr())
     return dirs, wdir, wsum
 
@@ -240,7 +240,10 @@ def sg_shade(normal, view, lgt, f0, rough, albedo, bvis, light_vis=None, metalli
     dev = normal.device
     rgb, spec, diff = (torch.empty(n, 3, dtype=torch.float32, device=dev) for _ in range(3))
     shadow = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_shadow else None
-    call("rb_sg_shade", ptr(normal), ptr(view), ptr(lgt), c_int(1 if per_point else 0), c_int(M), c_float(f0), ptr(rough),
+    # f0: device tensor holding the scalar |specular_reflectance| (read by the kernel -- no host copy, no cache to go stale)
+    f0 = (f0.detach().to(device=dev, dtype=torch.float32).reshape(-1)[:1].contiguous() if isinstance(f0, torch.Tensor)
+          else torch.full((1,), float(f0), device=dev))
+    call("rb_sg_shade", ptr(normal), ptr(view), ptr(lgt), c_int(1 if per_point else 0), c_int(M), ptr(f0), ptr(rough),
          ptr(albedo), ptr(_f32(metallic).reshape(-1) if metallic is not None else None),
          ptr(_f32(light_vis) if light_vis is not None else None), ptr(bvis),
          ptr(_f32(indir_integral) if indir_integral is not None else None), c_int(1 if lin_diff else 0), c_long(n),

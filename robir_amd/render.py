@@ -18,17 +18,36 @@ def blender_camera(transforms_json, index, H, W):
     """SynDataset conventions (datasets/syn_dataset.py:25-84): focal from camera_angle_x, translation / 2."""
     meta = json.load(open(transforms_json))
     focal = 0.5 * W / math.tan(0.5 * float(meta["camera_angle_x"]))
-    pose = np.array(meta["frames"][index]["transform_matrix"], dtype=np.float32)
-    pose[:3, 3] /= 2.0
+    pose = np.array(meta["frames"][index]["transform_matrix"])
+    pose[..., 3] /= 2.0            # the whole 4th column, homogeneous 1 included, exactly like syn_dataset.py:56-58
+    pose = pose.astype(np.float32)
     K = np.array([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1]], np.float32)
     ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
-    return np.stack([xs, ys], -1).reshape(-1, 2), pose, K
+    return np.stack([xs, ys], -1).reshape(-1, 2), pose, K       # uv = (column, row) as floats (syn_dataset.py:124-126)
 
 
-def load_stage_checkpoint(model, path):
-    """{'epoch', 'model_state_dict'} written by the stage runners (training/train_pbr.py:215-233)."""
-    sd = torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"]
-    return model.load_state_dict(sd, strict=False)
+def load_stage_checkpoint(model, path, only=None):
+    """{'epoch', 'model_state_dict'} written by the stage runners (training/train_pbr.py:215-233), loaded with
+    strict=False like the runners do (train_pbr.py:155-203).  `only`: substrings selecting the keys to take (the PBR runner
+    takes only `normal_decoder_layer` from a Norm checkpoint and `indirect_illum_network` / `visibility_network` from a
+    Vis checkpoint).  Missing / unexpected keys are returned AND reported: strict=False hides a key mismatch otherwise."""
+    import warnings
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    if "model_state_dict" not in blob:
+        raise KeyError(f"{path}: no 'model_state_dict' entry (found {sorted(blob)}) -- not a stage checkpoint")
+    sd = blob["model_state_dict"]
+    if only is not None:
+        sd = {k: v for k, v in sd.items() if any(s in k for s in only)}
+        if not sd:
+            raise KeyError(f"{path}: no key matches {only}")
+    res = model.load_state_dict(sd, strict=False)
+    if res.unexpected_keys:
+        warnings.warn(f"{path}: {len(res.unexpected_keys)} checkpoint tensors have no counterpart in the model "
+                      f"(e.g. {res.unexpected_keys[:4]})", RuntimeWarning, stacklevel=2)
+    if only is None and res.missing_keys:
+        warnings.warn(f"{path}: {len(res.missing_keys)} model tensors are not in the checkpoint and keep their current "
+                      f"values (e.g. {res.missing_keys[:4]})", RuntimeWarning, stacklevel=2)
+    return res
 
 
 def render_view(model, uv, pose, K, chunks_per_pass=125, chunk=1024, hdr_shift=None):
@@ -102,9 +121,12 @@ def main():
         model = renderer.build_synthetic_model(dev)
         uv, pose, K = synth.synth_camera(H, W)
     else:
-        model = renderer.IDRNetwork(renderer.hotdog_conf())
-        state = torch.load(a.neus_ckpt, map_location="cpu", weights_only=False)
-        model.implicit_network.neus_model.load_state_dict(state["model"], strict=False)
+        import warnings
+        with warnings.catch_warnings():  # the NeuS checkpoint is loaded explicitly on the next lines
+            warnings.simplefilter("ignore", RuntimeWarning)
+            model = renderer.IDRNetwork(renderer.hotdog_conf())
+        from .nets import load_neus_checkpoint
+        load_neus_checkpoint(model.implicit_network.neus_model, a.neus_ckpt)
         if a.stage_ckpt:
             load_stage_checkpoint(model, a.stage_ckpt)
         model = model.to(dev).eval()

@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 
 from . import ops, sg_render
-from .nets import (ImplicitNetworkMy, IndirctIllumNetwork, VisNetwork, EnvmapMaterialNetwork, GammaCorrect)
+from .nets import (ImplicitNetworkMy, IndirctIllumNetwork, VisNetwork, EnvmapMaterialNetwork, GammaCorrect,
+                   forward_only_guard)
 from .octree_tracing import OctreeTracing
 from .ray_tracing import RayTracing
 
@@ -93,6 +94,7 @@ class IDRNetwork(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, input, trainstage="IDR", fun_spec=False, lin_diff=False, train_spec=False, draws=None, stats=None):
         """implicit_differentiable_renderer.py:290-479, uv/pose/intrinsics input form, batch size 1."""
+        forward_only_guard(self)
         if "intrinsics" not in input:
             return self._forward_points_dirs(input, trainstage, fun_spec, lin_diff, draws, stats)
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
@@ -110,6 +112,7 @@ class IDRNetwork(nn.Module):
     def render_chunks(self, uv, pose, K, hdr_shift, chunk=1024, trainstage="Material", draws=None, stats=None):
         """uv [N,2] for any number of consecutive `chunk`-pixel chunks (chunk <= 1024); pose [4,4], K [3,3];
         hdr_shift [N,1].  draws: dict as synth.pbr_draws but with 'dvis_*' stacked [C,L,32]."""
+        forward_only_guard(self)
         N = uv.shape[0]
         mask = torch.ones(N, dtype=torch.bool, device=uv.device)
         return self._render(uv, pose, K, mask, hdr_shift, chunk, trainstage, False, False, draws, stats, None)
@@ -230,6 +233,7 @@ class IDRNetwork(nn.Module):
     def trace_radiance(self, input, nsamp=16, test_dir=None, draws=None):
         """implicit_differentiable_renderer.py:566-650.  draws: (u1, u2) uniform [n*nsamp] replacing the two
         torch.rand calls of spherical_uniform."""
+        forward_only_guard(self)
         if test_dir is not None:
             raise NotImplementedError("test_dir (debug option) is not built")
         points, shift, mask = input["points"], input["hdr_shift"], input["network_object_mask"]
@@ -392,8 +396,11 @@ def hotdog_conf(use_octree=True):
 def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True, use_octree=True):
     """IDRNetwork with the synthetic weights of robir_amd.synth (the configuration tests and bench.py use)."""
     from . import synth
+    import warnings
     sd = synth.synth_state_dict(seed, variance=variance, sharp_light=sharp_light)
-    model = IDRNetwork(hotdog_conf(use_octree))
+    with warnings.catch_warnings():      # the full state dict is loaded two lines down
+        warnings.simplefilter("ignore", RuntimeWarning)
+        model = IDRNetwork(hotdog_conf(use_octree))
     missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     assert not unexpected and not missing, (missing, unexpected)
     model = model.to(device).eval()

@@ -33,6 +33,36 @@ def norm_axis(x):
     return ops.normalize3(x.reshape(-1, 3).float().contiguous(), TINY_NUMBER, 0).reshape(x.shape)
 
 
+def hemisphere_int(lambda_val, cos_beta):
+    """Integral of exp(lambda (w.p - 1)) over the hemisphere whose pole makes angle beta with the lobe axis p
+    (sg_render.py:62-81, the Meder & Bruederlin fit).  Public helper for callers of the reference's module; the renderer
+    itself evaluates this inside rb_sg_shade.  Plain element-wise torch on the inputs' device."""
+    lam = lambda_val + TINY_NUMBER
+    r = 1.0 / lam
+    t = lam.sqrt() * (1.6988 + 10.8438 * r) / (1.0 + 6.2201 * r + 10.2415 * r * r)
+    ea = torch.exp(-t)
+    up = cos_beta >= 0
+    eb = torch.exp(-t * cos_beta.clamp(min=0.0))
+    s_up = (1.0 - ea * eb) / (1.0 - ea + eb - ea * eb)
+    b = torch.exp(t * cos_beta.clamp(max=0.0))
+    s_dn = (b - ea) / ((1.0 - ea) * (b + 1.0))
+    s = up.to(s_up.dtype) * s_up + (~up).to(s_up.dtype) * s_dn           # blend, not where(): NaN propagates like the reference
+    e1 = torch.exp(-lam)
+    lower = 2.0 * np.pi / lam * (e1 - torch.exp(-2.0 * lam))
+    upper = 2.0 * np.pi / lam * (1.0 - e1)
+    return lower * (1.0 - s) + upper * s
+
+
+def lambda_trick(lobe1, lambda1, mu1, lobe2, lambda2, mu2):
+    """Product of two SGs as one SG, arranged for lambda1 << lambda2 (sg_render.py:84-104).  Public helper, see above."""
+    q = lambda1 / lambda2
+    a1 = lobe1 / (torch.norm(lobe1, dim=-1, keepdim=True) + TINY_NUMBER)
+    a2 = lobe2 / (torch.norm(lobe2, dim=-1, keepdim=True) + TINY_NUMBER)
+    c = (a1 * a2).sum(-1, keepdim=True)
+    m = torch.minimum(torch.sqrt(q * q + 1.0 + 2.0 * q * c), q + 1.0)
+    return (q / m) * a1 + (1.0 / m) * a2, lambda2 * m, mu1 * mu2 * torch.exp(lambda2 * (m - q - 1.0))
+
+
 def render_envmap_sg(lgtSGs, viewdirs):
     """sum_k mu_k exp(lambda_k (d.lobe_k - 1)) (sg_render.py:26-42)."""
     shape = list(viewdirs.shape[:-1]) + [3]
@@ -54,22 +84,6 @@ def render_envmap(envmap, viewdirs):
 
 
 # ----------------------------------------------------------------------------------------- visibility
-_SCALARS = {}
-
-
-def _host_scalar(t):
-    """First element of a (parameter) tensor as a Python float.  Reading it is a device->host copy, i.e. a full stream
-    synchronisation, twice per forward(); the value only changes when the parameter does, so it is cached per
-    (storage, version)."""
-    key = (t.data_ptr(), t._version)
-    v = _SCALARS.get(key)
-    if v is None:
-        if len(_SCALARS) > 64:
-            _SCALARS.clear()
-        v = _SCALARS[key] = float(t.detach().reshape(-1)[0])
-    return v
-
-
 def _rand(shape, device):
     return torch.rand(*shape, device=device)
 
@@ -94,23 +108,18 @@ def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, 
         u_t, u_p = draws["dvis_theta"], draws["dvis_phi"]
     else:
         u_t, u_p = _rand((C, L, nsamp), dev), _rand((C, L, nsamp), dev)
-    return _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats,
-                             lobes_prenormalised=True).t()
+    return _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats, direct=True).t()
 
 
-def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats,
-                      lobes_prenormalised=False):
-    """-> [n, L].  lgt [L,7] raw light SGs."""
+def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats, direct=False):
+    """-> [n, L].  lgt [L,7]: raw light SGs (direct=False, render_with_sg's chain: lobe normalised twice, |lambda|) or the
+    lobes / lambdas of a direct get_diffuse_visibility call (direct=True: normalised once, lambda as given)."""
     dev = points.device
     if u_t.dim() == 2:
         u_t, u_p = u_t[None], u_p[None]
     assert u_t.shape[0] == C
     _, L, nsamp = u_t.shape
-    if lobes_prenormalised:
-        # caller already applied lobe/(|lobe|+eps) once; rb_dvis_dirs applies it twice like the reference's call chain,
-        # so undo nothing: x/(|x|+eps) of an (almost) unit vector differs by 1e-6 -- keep the exact chain instead
-        lgt = lgt.clone()
-    dirs, wdir, wsum = ops.dvis_dirs(lgt, u_t.to(dev), u_p.to(dev), thr)
+    dirs, wdir, wsum = ops.dvis_dirs(lgt, u_t.to(dev), u_p.to(dev), thr, direct=direct)
     if isinstance(VisModel, VisNetwork):
         sp = VisModel.packed_split()
         A = ops.linear_64_256(ops.feat_pe10(points.float().contiguous()), sp["point"])
@@ -195,7 +204,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     nrm = normal.float().contiguous()
     vd = viewdirs.float().contiguous()
     rough = roughness.float().contiguous().reshape(-1)
-    f0 = _host_scalar(specular_reflectance)
+    f0 = specular_reflectance          # stays on the device: rb_sg_shade reads the scalar itself
     shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
     lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
     light_vis = None

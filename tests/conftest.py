@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode_like_the_plot_path():
+    """The kernels are forward-only and guard against training-mode calls (robir_amd.nets.forward_only_guard); tests render
+    the way `--plot_only` / relight do: grad disabled.  The guard's own test re-enables grad explicitly."""
+    with torch.no_grad():
+        yield
+
+
 def rel_err(a, b):
     """max |a-b| / (|b| + mean|b|) over the tensor; NaN==NaN and inf==inf count as equal.
     The mean-|b| floor is the tolerance convention of this repo ('Parity tolerances')."""

@@ -14,7 +14,7 @@ def test_library_exports_header_symbols():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     L = _lib.lib()
-    assert L.rb_abi_version() == 1
+    assert L.rb_abi_version() == 2
     hdr = open(os.path.join(ROOT, "include", "robir_hip.h")).read()
     syms = sorted(set(re.findall(r"\b(rb_[a-z0-9_]+)\s*\(", hdr)))
     assert len(syms) >= 40
@@ -155,3 +155,34 @@ def test_overlay_shadows_reference_modules_by_path_order():
     a, b, c = out.stdout.strip().splitlines()[-3:]
     assert a.startswith(os.path.join(root, "overlay")) and b.startswith(os.path.join(root, "overlay"))
     assert c.startswith("/root/reference/model")
+
+
+def test_forward_only_guard():
+    """The kernels have no backward: a training-mode forward with grad enabled raises instead of returning detached tensors
+    (checked before any kernel is launched, so this runs without a GPU)."""
+    import warnings
+    import torch
+    from robir_amd import nets, renderer
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = renderer.IDRNetwork(renderer.hotdog_conf())
+    x = torch.zeros(4, 3)
+    inp = {"uv": torch.zeros(1, 4, 2), "pose": torch.eye(4)[None], "intrinsics": torch.eye(3)[None],
+           "object_mask": torch.ones(1, 4, dtype=torch.bool)}
+    with torch.enable_grad():
+        m.train()
+        for call in (lambda: m(inp, trainstage="Material"), lambda: m.visibility_network(x, x),
+                     lambda: m.implicit_network(x), lambda: m.implicit_network.gradient(x),
+                     lambda: m.envmap_material_network(x, train_spec=True), lambda: m.indirect_illum_network(x, x[:, :1]),
+                     lambda: m.trace_radiance({"points": x, "hdr_shift": x[:, :1], "network_object_mask": x[:, 0] > 1})):
+            with pytest.raises(nets.ForwardOnlyError):
+                call()
+        # frozen parameters, eval mode or no_grad are all fine for the guard (the call then proceeds to the kernels,
+        # which need the GPU: only the guard itself is exercised here)
+        nets.forward_only_guard(m.eval())
+        m.train()
+        with torch.no_grad():
+            nets.forward_only_guard(m)
+        for p in m.parameters():
+            p.requires_grad_(False)
+        nets.forward_only_guard(m)

@@ -131,6 +131,40 @@ def test_rejects_what_it_cannot_read(tmp_path):
     assert not np.array_equal(out, ref)
 
 
+def test_hostile_header_and_chunk_fields(tmp_path):
+    """Attribute sizes, the data window, chunk offsets and chunk scan lines are validated (a negative attribute size used to
+    move the cursor backwards and spin forever)."""
+    import struct
+    from robir_amd import exr
+    p = str(tmp_path / "h.exr")
+    img = np.arange(8 * 4 * 3, dtype=np.float32).reshape(8, 4, 3)
+    _write_exr(p, img, 0, 2)
+    good = bytes(open(p, "rb").read())
+    assert np.array_equal(exr.read_exr(p), img)
+
+    def patched(edit):
+        b = bytearray(good)
+        edit(b)
+        open(p, "wb").write(bytes(b))
+        with pytest.raises(exr.ExrError):
+            exr.read_exr(p)
+
+    key = b"compression\0compression\0"
+    i_size = good.index(key) + len(key)
+    # size = -(len(name) + len(type) + 8): the cursor would land on the same attribute again
+    patched(lambda b: b.__setitem__(slice(i_size, i_size + 4), struct.pack("<i", -(len(key) + 8))))
+    patched(lambda b: b.__setitem__(slice(i_size, i_size + 4), struct.pack("<i", 1 << 30)))
+    dw = good.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    patched(lambda b: b.__setitem__(slice(dw, dw + 16), struct.pack("<4i", 0, 0, -5, 7)))            # W <= 0
+    patched(lambda b: b.__setitem__(slice(dw, dw + 16), struct.pack("<4i", 0, 0, 3, 1 << 28)))       # absurd H
+    _, end = exr._header(good)
+    first = struct.unpack_from("<Q", good, end)[0]
+    patched(lambda b: b.__setitem__(slice(first, first + 4), struct.pack("<i", 99)))                 # y beyond the window
+    patched(lambda b: b.__setitem__(slice(first, first + 4), struct.pack("<i", -3)))                 # y before it
+    patched(lambda b: b.__setitem__(slice(first + 4, first + 8), struct.pack("<i", -1)))             # negative chunk size
+    patched(lambda b: b.__setitem__(slice(end, end + 8), struct.pack("<Q", len(good) + 100)))        # offset past the end
+
+
 def test_load_light_reads_sgs_and_background(tmp_path):
     """EnvmapMaterialNetwork.load_light (sg_envmap_material.py:257-268): <dir>/sg_128.npy + <dir>.exr."""
     import shutil

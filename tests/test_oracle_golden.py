@@ -221,3 +221,47 @@ def test_tone_mapping():
         for hm, key in ((1, "m1_"), (2, "m2_"), (-1, "m9_")):                      # warp_aces, ln_space, identity
             assert rel_err(renderer.hdr2ldr(x, sh, hm), g["ldr_" + key + tag]) == 0.0
             assert rel_err(renderer.ldr2hdr(y * 0.7, sh, hm), g["hdr_" + key + tag]) == 0.0
+
+
+def test_sg_algebra_helpers():
+    """hemisphere_int / lambda_trick (model/sg_render.py:62-104): the oracle's restatement AND the public helpers of
+    robir_amd.sg_render (plain element-wise torch, device-agnostic) against the reference's outputs."""
+    from robir_oracle import sg
+    from robir_amd import sg_render as product
+    g = {k: torch.from_numpy(v) for k, v in load_golden("sg_helpers").items()}
+    for impl_h, impl_t in ((sg.hemisphere_int, sg.sg_product), (product.hemisphere_int, product.lambda_trick)):
+        assert rel_err(impl_h(g["lam"], g["cos_beta"]), g["hemi"]) <= 1e-6
+        lobe, lam, mu = impl_t(g["lobe1"], g["lam1"], g["mu1"], g["lobe2"], g["lam2"], g["mu2"])
+        assert rel_err(lobe, g["out_lobe"]) <= 1e-6 and rel_err(lam, g["out_lam"]) <= 1e-6 and rel_err(mu, g["out_mu"]) <= 1e-6
+
+
+def test_octree_vis_model(oracle_sd, oracle_octree):
+    """Traced visibility (OctreeVisModel, model/octree_tracing.py:63-85) with the octree the ORACLE built here (one hit cell
+    of 233 k differs from the reference's build, PINNING.json): direct logits and the lock-step schedule of a 512-ray batch,
+    then render_with_all_sg with it as the VisModel (131 k culled pairs in one batch: the R > 100000 step size)."""
+    from robir_oracle import octree as ooct, sg
+    g = load_golden("octree_vis")
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.dtype.kind == "f"}
+    log = []
+    _, hit = ooct.cast(oracle_octree, t["direct_points"], t["direct_dirs"], 32, log)
+    lg = ooct.octree_vis_logits(oracle_octree, t["direct_points"], t["direct_dirs"])
+    assert torch.equal(lg[:, 0].bool(), hit) and torch.equal(lg.sum(-1), torch.ones(512))
+    assert int((lg != t["direct_logits"]).any(-1).sum()) <= 2
+    assert [m for _, m in log] == list(g["direct_sched_m"])
+    assert 100 < int(t["direct_logits"][:, 0].sum()) < 400                 # the fixture does contain occluded rays
+    draws = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("draw_")}
+    sizes = []
+
+    def vis_fn(p, d):
+        sizes.append(p.shape[0])
+        return ooct.octree_vis_logits(oracle_octree, p, d)
+
+    out = sg.render_with_all_sg(t["points"], t["normal"], t["view"], t["lgtSGs"], t["f0"], t["roughness"], t["albedo"],
+                                draws, indir_integral=t["indir_int"], indir_lgt_sgs=t["indir_sgs"], vis_fn=vis_fn,
+                                testing=True)
+    assert sizes == list(g["cast_sizes"]) and sizes[0] > 100000
+    for k in ("sg_rgb", "sg_specular_rgb", "sg_diffuse_rgb", "vis_shadow", "indir_rgb", "indir_diffuse_rgb",
+              "indir_specular_rgb"):
+        # a flipped ray changes one of 32 samples of one lobe of one point: bounded, rare
+        assert bad_frac(out[k], g["out_" + k], 1e-5) <= 0.02, (k, bad_frac(out[k], g["out_" + k], 1e-5))
+        assert rel_err(out[k], g["out_" + k]) <= 2e-2, (k, rel_err(out[k], g["out_" + k]))
