@@ -10,8 +10,10 @@ synthetic 800x800 view -- camera rays, octree sphere trace of 625 lock-step chun
 ray, per-hit indirect-illumination / material networks, 128-lobe light-SG visibility (32 samples per lobe through the
 visibility MLP), 8+8 BRDF-lobe visibility samples, SG shading (128 direct + 24 indirect lobes), scatter to per-ray
 outputs.  Synthetic weights (robir_amd.synth, seed 0), random draws generated on the device inside the step.
-One step = one such image per GPU ("weak": rank r renders view r of an N-view job, tiles all-gathered over RCCL at
-the end of the step).  The octree build is one-off set-up and is reported separately.
+One step = ONE such image rendered by all N GPUs together ("strong": rank r renders chunks {c : c mod N = r} of the view,
+robir_amd.parallel.render_view_sharded, and the 17-float tiles are all-gathered over RCCL at the end of the step -- the
+partition SURVEY.md 8e / north_star name).  `value` = rays of that image / step time.  For N > 1 a secondary figure times the
+weak form (rank r renders its own view r).  The octree build is one-off set-up and is reported separately.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fused light-SG visibility, fp32 MFMA bound) and, at
 N=1, `cpu_baseline` (the oracle restatement timed on this box's host cores on a bounded sample of the same workload).
@@ -32,6 +34,7 @@ sys.path.insert(0, ROOT)
 VIS_MACS_PER_EVAL = 229376          # 126*256 + 3*256*256 + 256*2
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
+TRAFFIC_B_PER_PAIR = 30.0          # profiles/r01_dvis_f16x3_pmc.md: 28-31 B per pair at 16 and 128 chunks per launch
 H = W = 800
 CHUNK = 1024
 
@@ -46,7 +49,11 @@ def parse():
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact", action="store_true",
-                    help="skip the exact-fp32 cross-check step that follows the timed region (rank 0, N = 1)")
+                    help="skip the exact-fp32 leg (N = 1): the same view with every MLP on the f32-input MFMA, timed over "
+                         "--exact-steps steps of its own, and the image distance of the default run from it")
+    ap.add_argument("--exact-steps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-1thread-pixels", type=int, default=256,
+                    help="pixels of the single-thread CPU baseline sample (the runners force torch.set_num_threads(1))")
     ap.add_argument("--vis-precision", default="f16x3-v2", choices=["fp32", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
@@ -88,23 +95,12 @@ class KernelTimer:
         return (sum(ms) / len(ms), len(ms)) if ms else (0.0, 0)
 
 
-def render_image(model, uv_d, pose_d, K_d, hdr, chunks_per_batch, stats):
-    """One full image in passes of `chunks_per_batch` chunks.  Returns the per-ray tiles a consumer needs."""
-    N = uv_d.shape[0]
-    per = chunks_per_batch * CHUNK
-    outs = []
-    for s in range(0, N, per):
-        o = model.render_chunks(uv_d[s:s + per], pose_d, K_d, hdr[s:s + per], chunk=CHUNK, stats=stats)
-        outs.append(torch.cat([o["sg_rgb"], o["indir_rgb"], o["diffuse_albedo"], o["roughness"][:, :1],
-                               o["vis_shadow"], o["normal_map"], o["network_object_mask"][:, None].float()], -1))
-    return torch.cat(outs, 0)                                        # [N, 17]
-
-
-def cpu_baseline(model, n_chunks, uv, pose, K):
-    """Oracle (CPU restatement of the reference) on `n_chunks` central chunks of the same image, all host cores."""
+def cpu_baseline(model, n_chunks, uv, pose, K, cores=None, pixels=CHUNK):
+    """Oracle (CPU restatement of the reference) on `n_chunks` central chunks of `pixels` pixels of the same image."""
     from robir_oracle import nets as on, octree as ooct, renderer as orend
     from robir_amd import synth
-    cores = min(16, os.cpu_count() or 1)      # more threads make the many small tensor ops of the reference slower
+    if cores is None:
+        cores = min(16, os.cpu_count() or 1)  # more threads make the many small tensor ops of the reference slower
     torch.set_num_threads(cores)
     sd = on.as_torch(synth.synth_state_dict(0, variance=0.3))
     # geometry: the octree the device built, converted to the oracle's table format (same cells, no 10 s CPU rebuild)
@@ -124,19 +120,19 @@ def cpu_baseline(model, n_chunks, uv, pose, K):
     t0 = time.time()
     rays = hits = 0
     for c in range(first, first + n_chunks):
-        sl = slice(c * CHUNK, (c + 1) * CHUNK)
+        sl = slice(c * CHUNK, c * CHUNK + pixels)
         uv_t = torch.from_numpy(uv[sl])[None]
         dirs, cam = orend.camera_rays(uv_t, torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
         _, hit, _ = ooct.trace(T, cam, dirs, -1)
         n_hit = int(hit.sum())
         dr = {k: torch.from_numpy(v) for k, v in synth.pbr_draws(7, n_hit, chunk_id=c).items()}
         orend.forward(sd, T, uv_t, torch.from_numpy(pose)[None], torch.from_numpy(K)[None],
-                      torch.ones(1, CHUNK, dtype=torch.bool), torch.full((CHUNK, 1), 0.5), dr, "Material", testing=True)
-        rays += CHUNK
+                      torch.ones(1, pixels, dtype=torch.bool), torch.full((pixels, 1), 0.5), dr, "Material", testing=True)
+        rays += pixels
         hits += n_hit
     dt = time.time() - t0
     return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n_chunks} central 1024-px chunks of the 800x800 view ({hits} hit rays, {dt:.1f} s, "
+            "sample": f"{n_chunks} central {pixels}-px chunks of the 800x800 view ({hits} hit rays, {dt:.1f} s, "
                       f"oracle = PyTorch-CPU restatement of the reference, torch threads = {cores})",
             "hit_rays_per_s": hits / dt}
 
@@ -164,8 +160,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from robir_amd import ops, renderer, synth, sg_render
-    from robir_amd.parallel import all_gather_tiles
+    from robir_amd import ops, renderer, synth, sg_render, parallel
     if "ROBIR_VIS_PRECISION" not in os.environ:
         sg_render.VIS_PRECISION = args.vis_precision
     precision = sg_render.VIS_PRECISION
@@ -181,14 +176,15 @@ def main():
     timer = KernelTimer()
     ops.dvis_fused = timer.wrap(ops.dvis_fused)
     uv, _, K = synth.synth_camera(H, W)
-    pose = view_pose(rank)
+    pose = view_pose(0)                                  # every rank works on the SAME view: the N = 1 workload
     uv_d, pose_d, K_d = torch.from_numpy(uv).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
     hdr = torch.full((H * W, 1), 0.5, device=dev)
     stats = {}
+    plan = parallel.plan_view(H * W, CHUNK, dev, interleave=True, chunks_per_pass=args.chunks_per_batch)
 
     def step():
-        tiles = render_image(model, uv_d, pose_d, K_d, hdr, args.chunks_per_batch, stats)
-        return all_gather_tiles(tiles) if world > 1 else tiles
+        """One image: this rank's chunks (all of them at N = 1), then the all-gather of the tiles -> [H*W, 17] on every rank."""
+        return parallel.render_view_sharded(model, uv_d, pose_d, K_d, hdr, CHUNK, stats=stats, plan=plan)
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,40 +192,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        return dt, out
+
     for _ in range(args.warmup):
         step()
     barrier()
     stats.clear()
     timer.on = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, out = timed(step, args.steps)
     timer.on = False
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    rays_total = world * H * W * args.steps
-    hit_frac = float(out[: H * W, 16].mean())
+    ops.range_check(sync=True)                           # split-precision activation-range sentinel: raises on overflow
+    rays_total = H * W * args.steps
+    hit_frac = float(out[:, 16].mean())
     evals = int(stats["diffuse_vis_evals"]) if "diffuse_vis_evals" in stats else 0
     k_ms, k_n = timer.stats()
     flops_per_launch = 2.0 * VIS_MACS_PER_EVAL * evals / max(k_n, 1)
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    weak = None
+    if world > 1:
+        # secondary figure: the weak form (rank r renders its own whole view r, tiles all-gathered)
+        pose_r = torch.from_numpy(view_pose(rank)).to(dev)
+        plan1 = dict(parallel.plan_view(H * W, CHUNK, dev), world=1)
+        plan1["passes"] = [(list(range(H * W // CHUNK)), slice(0, H * W), False)]
+
+        def weak_step():
+            t = parallel.render_view_sharded(model, uv_d, pose_r, K_d, hdr, CHUNK, plan=plan1)
+            return parallel.all_gather_tiles(t)
+        weak_step()
+        wdt, _ = timed(weak_step, 2)
+        weak = {"value": world * H * W * 2 / wdt, "unit": "rays/s", "steps": 2, "ms_per_step": wdt / 2 * 1e3,
+                "note": "one whole view per GPU (views differ in cost: hit fraction 0.65 .. 0.53)"}
 
     if rank == 0:
         h3 = precision.startswith("f16x3")
         # peak of the pipe the dominant kernel runs on, per ALGORITHMIC flop: exact mode = dense f32-input MFMA;
         # f16x3 = dense f16 MFMA (2.5 PFLOP/s) / 3 products per algorithmic multiply-add
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": ("k_dvis_v2" if precision == "f16x3-v2" else "k_dvis_fused") + " (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
+        roofline = {"bound": "mfma", "kernel": ops.DVIS_KERNEL_NAMES.get(precision, "k_dvis_fused") + " (light-SG visibility MLP)",
+                    "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak,
-                    # HBM bytes per launch: 30 B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
-                    # correction) + WRITE_SIZE on this kernel at 16 and at 128 chunks per launch (28-31 B/pair,
-                    # profiles/r01_dvis_f16x3_pmc.md), scaled to this launch's pair count: ~0.4 % of the HBM roofline --
-                    # the bound is the matrix pipe
-                    "traffic": 30.0 * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                    # HBM bytes per launch: B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
+                    # correction) + WRITE_SIZE on this kernel (profiles/), scaled to this launch's pair count: well under 1 % of
+                    # the HBM roofline -- the bound is the matrix pipe
+                    "traffic": TRAFFIC_B_PER_PAIR * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
                     "precision": precision,
                     "peak_note": ("dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)" if h3
                                   else "dense f32-input MFMA"),
@@ -239,46 +256,60 @@ def main():
         line = {
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if precision == "fp32" else "f32 (MLP layers as 3x f16 hi/lo-split MFMA products, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "hotdog-like synthetic 800x800 full PBR forward (BASELINE.json configs[3]): "
-                                   "625 lock-step chunks of 1024 px per view, one view per GPU",
+            "config": {"workload": "hotdog-like synthetic 800x800 full PBR forward (BASELINE.json configs[3]): ONE view = "
+                                   "625 lock-step chunks of 1024 px, chunks sharded over the GPUs (c mod N), tiles all-gathered",
                        "image": [H, W], "chunk": CHUNK, "chunks_per_pass": args.chunks_per_batch,
                        "hit_fraction": round(hit_frac, 4), "octree_build_s": round(build_s, 2),
-                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "parallelism": f"ray-shard x{world} (views)"},
+                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B,
+                       "parallelism": f"chunk-shard x{world} of one view + all-gather"},
             "roofline": roofline,
         }
-        if world == 1 and precision != "fp32" and not args.no_exact:
-            # Outside the timed region: the same view with every MLP on the exact f32-input MFMA and the same random
-            # draws -- the conservative rate, and how far the split-precision image is from it.
-            torch.manual_seed(20260928)
-            split_img = step()
-            sg_render.VIS_PRECISION = "fp32"
-            os.environ["ROBIR_MLP_PRECISION"] = "fp32"
-            torch.manual_seed(20260928)
-            step()                                      # packs the fp32 weight blobs
-            torch.cuda.synchronize()
-            torch.manual_seed(20260928)
-            t1 = time.perf_counter()
-            exact_img = step()
-            torch.cuda.synchronize()
-            t_exact = time.perf_counter() - t1
-            ok = torch.isfinite(exact_img).all(-1) & torch.isfinite(split_img).all(-1)
-            a, b = split_img[ok], exact_img[ok]
-            rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
-            line["exact_fp32"] = {"value": H * W / t_exact, "unit": "rays/s", "ms_per_step": t_exact * 1e3,
-                                  "max_rel_diff_of_split_precision_image": float(rel.max()),
-                                  "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
-                                  "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum()),
-                                  "note": "same view and draws, every MLP on v_mfma_f32_16x16x4_f32; diff = |a-b|/(|b|+mean|b|) "
-                                          "over the 17 output channels of all rays; the outliers are rays where a sampled "
-                                          "direction sits on the n.d > 1e-6 cull (a 1e-6 change of the normal flips one "
-                                          "visibility sample), the same effect as between two exact runs on different hardware"}
-            sg_render.VIS_PRECISION = precision
-            os.environ["ROBIR_MLP_PRECISION"] = "f16x3"
+        if weak is not None:
+            line["weak_views"] = weak
+    if world == 1 and precision != "fp32" and not args.no_exact:
+        # Second first-class figure: the same view with EVERY MLP on the exact f32-input MFMA (v_mfma_f32_16x16x4_f32),
+        # timed over its own loop -- the rate at the reference's own precision -- and how far the default image is from it
+        # under identical random draws.
+        torch.manual_seed(20260928)
+        split_img = step()
+        sg_render.VIS_PRECISION = "fp32"
+        os.environ["ROBIR_MLP_PRECISION"] = "fp32"
+        torch.manual_seed(20260928)
+        exact_img = step()                              # warm-up: packs the fp32 weight blobs
+        timer.pairs.clear()
+        timer.on = True
+        stats.clear()
+        t_exact, _ = timed(step, args.exact_steps)
+        timer.on = False
+        e_ms, e_n = timer.stats()
+        e_evals = int(stats["diffuse_vis_evals"]) if "diffuse_vis_evals" in stats else 0
+        e_tflops = 2.0 * VIS_MACS_PER_EVAL * e_evals / max(e_n, 1) / (e_ms * 1e-3) / 1e12 if e_ms > 0 else 0.0
+        ok = torch.isfinite(exact_img).all(-1) & torch.isfinite(split_img).all(-1)
+        a, b = split_img[ok], exact_img[ok]
+        rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
+        line["exact_fp32"] = {"value": H * W * args.exact_steps / t_exact, "unit": "rays/s", "steps": args.exact_steps,
+                              "warmup": 1, "ms_per_step": t_exact / args.exact_steps * 1e3, "dtype": "f32",
+                              "roofline": {"bound": "mfma", "kernel": "k_dvis_fused<fp32>", "achieved": e_tflops,
+                                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": e_tflops / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": e_ms, "launches": e_n},
+                              "max_rel_diff_of_split_precision_image": float(rel.max()),
+                              "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
+                              "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum()),
+                              "note": "same view and draws, every MLP on v_mfma_f32_16x16x4_f32; diff = |a-b|/(|b|+mean|b|) "
+                                      "over the 17 output channels of all rays; the outliers are rays where a sampled "
+                                      "direction sits on the n.d > 1e-6 cull (tests/test_precision_gpu.py anchors both modes "
+                                      "on a float64 evaluation of the reference's formulas)"}
+        sg_render.VIS_PRECISION = precision
+        os.environ["ROBIR_MLP_PRECISION"] = "f16x3"
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline_chunks, uv, pose, K)
+            # the reference's runners pin torch to one thread (training/train_pbr.py:24): that figure too, on a smaller sample
+            one = cpu_baseline(model, 1, uv, pose, K, cores=1, pixels=args.cpu_baseline_1thread_pixels)
+            line["cpu_baseline"]["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample", "hit_rays_per_s")}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -24,6 +24,19 @@ extern "C" {
 typedef void* rb_stream_t; /* hipStream_t */
 
 int rb_abi_version(void);
+
+/* Activation-range sentinel of the split-precision ("f16x3") kernels.  Those kernels carry each fp32 operand as an (hi, lo)
+ * pair of halves after lifting it by a power of two; an operand whose lifted magnitude reaches 65504 no longer fits (the hi
+ * half saturates -- round-toward-zero conversion -- and the pair silently loses precision).  Every split-precision kernel
+ * therefore tracks the largest |hi| half it consumed and, when one saturates (or is inf / NaN), stores 1 into a per-family
+ * word of a process-wide block of pinned, mapped host memory.  rb_range_check reads and clears the words:
+ *   mask bit 0 light-visibility (rb_dvis_fused*), 1 rb_vis_mlp_h3, 2 rb_sdf_mlp_h3, 3 rb_color_mlp_h3, 4 rb_wide_mlp_h3,
+ *   5 rb_cesr_net_h3.
+ * synchronize != 0: wait for `stream` first, so every kernel enqueued on it so far has reported; 0: no wait -- reports what
+ * completed kernels have flagged (free of charge; call it at the next natural sync point for a complete answer).
+ * A set bit means: re-run that family with the exact f32-input MFMA kernels (the non-_h3 entry points).  Nothing like this
+ * exists in the reference (PyTorch fp32 throughout); it guards the precision mode this library adds. */
+int rb_range_check(int synchronize, rb_stream_t stream, unsigned* mask_out);
 const char* rb_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------

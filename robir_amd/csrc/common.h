@@ -21,6 +21,13 @@ inline dim3 grid1d(long n, int per_block) {
   return dim3(blocks > RB_MAX_BLOCKS ? 0u : (unsigned)blocks);
 }
 
+// Activation-range sentinel of the split-precision (f16 hi/lo) kernels: RB_RANGE_WORDS 32-bit words in pinned, mapped host
+// memory (allocated on first use; nullptr if that fails -- rb_range_check then reports the failure).  A kernel family stores
+// 1 into its word when an operand's hi half saturates (|value * lift| >= 65504: beyond that the pair no longer carries
+// fp32-like precision).  Words are only ever SET by kernels; the host reads and clears them in rb_range_check.
+enum { RB_RANGE_DVIS = 0, RB_RANGE_VIS, RB_RANGE_SDF, RB_RANGE_COLOR, RB_RANGE_WIDE, RB_RANGE_SOFTPLUS512, RB_RANGE_WORDS = 8 };
+unsigned* range_flags();
+
 }  // namespace rb
 
 #define RB_REQUIRE(cond, msg)                     \

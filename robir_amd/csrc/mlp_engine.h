@@ -82,12 +82,14 @@ struct WStream {
   f4* lds;  // 2 * BUF_F4 float4s
   int cur;
   int tid;
+  unsigned sat;  // running max of |hi half| over every split-precision operand this thread fed to an MFMA (range sentinel)
   f4 stage[NST];
 
   __device__ __forceinline__ void init(f4* lds_base, int tid_) {
     lds = lds_base;
     cur = 0;
     tid = tid_;
+    sat = 0u;
   }
   // Chunk copies are branch-free: a ragged tail (CF4 not a multiple of 256) is handled by clamping the element
   // index, so surplus threads re-copy the last element (same value to the same address: benign).  A per-element
@@ -212,6 +214,26 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __fp16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
+// ---- activation-range sentinel ------------------------------------------------------------------------------------
+// v_cvt_pkrtz rounds toward zero, so a value beyond the f16 range does not become inf: its hi half saturates at 65504
+// (0x7BFF) and the pair silently loses precision.  Kernels keep a running packed max of the |hi| halves they consume and
+// flag the launch (common.h: range_flags) when one reaches 0x7BFF (also catches inf / NaN operands: 0x7C00, 0x7E00).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+// signed operands: max over |hi| as unsigned 16-bit patterns (2 VALU ops per register pair)
+__device__ __forceinline__ unsigned sat_acc(unsigned sat, unsigned packed_hi) {
+  const us2 m = __builtin_elementwise_max(__builtin_bit_cast(us2, sat), __builtin_bit_cast(us2, packed_hi & 0x7fff7fffu));
+  return __builtin_bit_cast(unsigned, m);
+}
+// operands known to be >= 0 (ReLU outputs): signed 16-bit max, -0.0 (0x8000) sorts below everything (1 VALU op)
+__device__ __forceinline__ unsigned sat_acc_nonneg(unsigned sat, unsigned packed_hi) {
+  const ss2 m = __builtin_elementwise_max(__builtin_bit_cast(ss2, sat), __builtin_bit_cast(ss2, packed_hi));
+  return __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ void range_report(unsigned sat, unsigned* word) {
+  if (word && ((sat & 0xffffu) >= 0x7bffu || (sat >> 16) >= 0x7bffu)) *reinterpret_cast<volatile unsigned*>(word) = 1u;
+}
+
 // Two fp32 values -> (packed hi halves, packed lo halves) with lo = v - float(hi).  One v_cvt_pkrtz per pair:
 // round-toward-zero only changes how the value is divided between hi and lo (|lo| <= 2^-10 |v|, stored to 2^-21 |v|).
 __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
@@ -305,6 +327,12 @@ __device__ __forceinline__ void dense_layer_h3(WS& ws, const f4* __restrict__ wl
   constexpr int NJB = N / 16, KB = K / 32, CF4 = chunk_f4(K), NCF4 = chunk_f4(NEXTK);
   constexpr int CH = 1;
   const int g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ws.sat = sat_acc(ws.sat, xh[t][kb][q]);
 #pragma unroll
   for (int jb = 0; jb < NJB; ++jb) {
     if (jb + 1 < NJB) {

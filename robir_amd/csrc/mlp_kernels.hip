@@ -8,10 +8,40 @@ namespace rb {
 
 static thread_local char g_err[512] = "";
 char* err_buf() { return g_err; }
+
+// Range sentinel words (common.h): pinned host memory mapped into every device's address space, allocated once.
+static unsigned* g_range_host = nullptr;
+static unsigned* g_range_dev = nullptr;
+static void range_init() {
+  void* h = nullptr;
+  if (hipHostMalloc(&h, RB_RANGE_WORDS * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  memset(h, 0, RB_RANGE_WORDS * sizeof(unsigned));
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    return;
+  }
+  g_range_host = static_cast<unsigned*>(h);
+  g_range_dev = static_cast<unsigned*>(d);
+}
+unsigned* range_flags() {
+  static const bool once = (range_init(), true);
+  (void)once;
+  return g_range_dev;
+}
+unsigned* range_flags_host() {
+  (void)range_flags();
+  return g_range_host;
+}
 int fail(const char* what, const char* detail) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, detail);
   return 1;
 }
+unsigned* range_flags_host();
 int check_launch(const char* kernel) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -646,6 +676,24 @@ using namespace rb;
 extern "C" {
 
 int rb_abi_version(void) { return RB_ABI_VERSION; }
+
+int rb_range_check(int synchronize, rb_stream_t stream, unsigned* mask_out) {
+  RB_REQUIRE(mask_out, "null pointer");
+  *mask_out = 0u;
+  unsigned* w = rb::range_flags_host();
+  RB_REQUIRE(w, "range sentinel: pinned host memory could not be allocated / mapped");
+  if (synchronize && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return rb::fail(__func__, hipGetErrorString(hipGetLastError()));
+  unsigned m = 0u;
+  for (int i = 0; i < RB_RANGE_WORDS; ++i) {
+    volatile unsigned* p = w + i;
+    if (*p) {
+      m |= 1u << i;
+      *p = 0u;
+    }
+  }
+  *mask_out = m;
+  return 0;
+}
 const char* rb_last_error(void) { return rb::err_buf(); }
 
 long rb_packed_layer_floats(int n_pad, int k_pad) { return (long)(n_pad / 16) * (16 + (long)k_pad * 16); }

@@ -11,7 +11,7 @@ namespace rb {
 
 // Same network with split-precision (f16x3) layers: Wp from rb_pack_layer_h3 (all five layers, one scale), `unscale` = 2^-s.
 __global__ __launch_bounds__(256, 1) void k_vis_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                        float unscale, float* __restrict__ Y) {
+                                                        float unscale, float* __restrict__ Y, unsigned* __restrict__ range_word) {
   __shared__ f4 lds[2 * chunk_f4(256)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<256> ws;
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 1) void k_vis_mlp_h3(const float* __restrict__
   act_split<256, 2, ACT_RELU>(z, unscale, xh, xl);
   float o[2][4];
   dense_layer_h3<256, 16, 2, 0>(ws, wl4, nullptr, xh, xl, o, lane, 1.0f);
+  range_report(ws.sat, range_word);
   if ((lane >> 4) == 0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void k_vis_mlp_h3(const float* __restrict__
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
                                                         float us, float out_scale, float grad_scale,
-                                                        float* __restrict__ out0, float* __restrict__ grad) {
+                                                        float* __restrict__ out0, float* __restrict__ grad, unsigned* __restrict__ range_word) {
   constexpr bool JVP = MODE >= 2;
   constexpr bool FULL = (MODE == 1 || MODE == 3);
   constexpr int NL = FULL ? 272 : 16;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
   }
   float zo[2][NL / 4];
   dense_layer_h3<256, NL, 2, 0>(ws, w8, nullptr, xh, xl, zo, lane, bm);
+  range_report(ws.sat, range_word);
 
   const int g = lane >> 4;
   const float os = out_scale * us * (1.0f / AS), gs = grad_scale * us * (1.0f / TS);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
 // Split-precision (f16x3) form of the colour network: Wp from rb_pack_layer_h3 with k_pad 320 (same column permutation),
 // 256 x3, 256; operands lifted by 2^4 before the hi/lo split.
 __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                          float us, float* __restrict__ rgb) {
+                                                          float us, float* __restrict__ rgb, unsigned* __restrict__ range_word) {
   constexpr float AS = 16.0f;
   __shared__ f4 lds[2 * chunk_f4(320)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict
   act_split<256, 2, ACT_RELU>(z, zs, xh, xl, AS);
   float o[2][4];
   dense_layer_h3<256, 16, 2, 0>(ws, w4, nullptr, xh, xl, o, lane, AS);
+  range_report(ws.sat, range_word);
   if ((lane >> 4) == 0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict
 // padded to 16), operands lifted by 2^4 before the hi/lo split.
 template <bool ENC>
 __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                         float us, float* __restrict__ Y) {
+                                                         float us, float* __restrict__ Y, unsigned* __restrict__ range_word) {
   constexpr int NO = ENC ? 32 : 144;
   constexpr int ACT = ENC ? ACT_LEAKY02 : ACT_RELU;
   constexpr float AS = 16.0f;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict_
   act_split<512, 1, ACT>(z, zs, xh, xl, AS);
   float o[1][NO / 4];
   dense_layer_h3<512, NO, 1, 0>(ws, w4, nullptr, xh, xl, o, lane, AS);
+  range_report(ws.sat, range_word);
   if (row < M) {
     const int g = lane >> 4;
 #pragma unroll
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict_
 template <int K0P, int N3P, bool ONEHOT>
 __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restrict__ X, long M, int n_label,
                                                             const f4* __restrict__ Wp, float us, int n_out,
-                                                            float* __restrict__ Y) {
+                                                            float* __restrict__ Y, unsigned* __restrict__ range_word) {
   constexpr int K4 = N3P + K0P, K4P = 544;
   static_assert(K4 == 528 && K0P % 32 == 0, "both CESR nets give a 528-wide skip layer");
   constexpr float AS = 64.0f;
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
   act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
   float o[1][4];
   dense_layer_h3<512, 16, 1, 0>(ws, w8, nullptr, xh, xl, o, lane, AS);
+  range_report(ws.sat, range_word);
   if (row < M && g == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -351,7 +356,7 @@ int rb_vis_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && logits, "null pointer");
   hipLaunchKernelGGL(k_vis_mlp_h3, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
-                     ldexpf(1.0f, -scale_log2), logits);
+                     ldexpf(1.0f, -scale_log2), logits, range_flags() ? range_flags() + RB_RANGE_VIS : nullptr);
   return check_launch("k_vis_mlp_h3");
 }
 
@@ -367,10 +372,10 @@ int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_l
   const f4* W = (const f4*)Wp;
   const float us = ldexpf(1.0f, -scale_log2);
   switch (mode) {
-    case 0: hipLaunchKernelGGL(k_sdf_mlp_h3<0>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad); break;
-    case 1: hipLaunchKernelGGL(k_sdf_mlp_h3<1>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad); break;
-    case 2: hipLaunchKernelGGL(k_sdf_mlp_h3<2>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad); break;
-    default: hipLaunchKernelGGL(k_sdf_mlp_h3<3>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad); break;
+    case 0: hipLaunchKernelGGL(k_sdf_mlp_h3<0>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, range_flags() ? range_flags() + RB_RANGE_SDF : nullptr); break;
+    case 1: hipLaunchKernelGGL(k_sdf_mlp_h3<1>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, range_flags() ? range_flags() + RB_RANGE_SDF : nullptr); break;
+    case 2: hipLaunchKernelGGL(k_sdf_mlp_h3<2>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, range_flags() ? range_flags() + RB_RANGE_SDF : nullptr); break;
+    default: hipLaunchKernelGGL(k_sdf_mlp_h3<3>, grid, block, 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, range_flags() ? range_flags() + RB_RANGE_SDF : nullptr); break;
   }
   return check_launch("k_sdf_mlp_h3");
 }
@@ -379,7 +384,7 @@ int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, flo
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && rgb, "null pointer");
   hipLaunchKernelGGL(k_color_mlp_h3, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
-                     ldexpf(1.0f, -scale_log2), rgb);
+                     ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
   return check_launch("k_color_mlp_h3");
 }
 
@@ -388,9 +393,9 @@ int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int sca
   RB_REQUIRE(X && Wp && Y, "null pointer");
   const float us = ldexpf(1.0f, -scale_log2);
   if (encoder) {
-    hipLaunchKernelGGL(k_wide_mlp_h3<true>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y);
+    hipLaunchKernelGGL(k_wide_mlp_h3<true>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y, range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr);
   } else {
-    hipLaunchKernelGGL(k_wide_mlp_h3<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y);
+    hipLaunchKernelGGL(k_wide_mlp_h3<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y, range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr);
   }
   return check_launch("k_wide_mlp_h3");
 }
@@ -404,11 +409,11 @@ int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* W
   const f4* W = (const f4*)Wp;
   const float us = ldexpf(1.0f, -scale_log2);
   switch (kind) {
-    case 0: hipLaunchKernelGGL((k_softplus512_h3<64, 464, false>), grid, block, 0, s, X, M, 1, W, us, 3, Y); break;
-    case 1: hipLaunchKernelGGL((k_softplus512_h3<192, 336, false>), grid, block, 0, s, X, M, 1, W, us, 2, Y); break;
+    case 0: hipLaunchKernelGGL((k_softplus512_h3<64, 464, false>), grid, block, 0, s, X, M, 1, W, us, 3, Y, range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr); break;
+    case 1: hipLaunchKernelGGL((k_softplus512_h3<192, 336, false>), grid, block, 0, s, X, M, 1, W, us, 2, Y, range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr); break;
     case 2:
       RB_REQUIRE(n_label >= 1 && n_label <= 128, "n_label must be 1..128");
-      hipLaunchKernelGGL((k_softplus512_h3<192, 336, true>), grid, block, 0, s, X, M, n_label, W, us, 2, Y);
+      hipLaunchKernelGGL((k_softplus512_h3<192, 336, true>), grid, block, 0, s, X, M, n_label, W, us, 2, Y, range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr);
       break;
     default: return rb::fail("rb_cesr_net_h3", "kind: 0 normal_net, 1 shadow_net (dense rows), 2 shadow_net (point x one-hot label)");
   }

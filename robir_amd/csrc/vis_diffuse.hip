@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
     const float* __restrict__ wsum, const f4* __restrict__ Whid, const float* __restrict__ wlast,
     const float* __restrict__ blast, int L, int nsamp, int argmax_vis, float w_unscale, float* __restrict__ vis_out,
-    unsigned long long* __restrict__ eval_count) {
+    unsigned long long* __restrict__ eval_count, unsigned* __restrict__ range_word) {
+  unsigned sat = 0u;   // range sentinel of the split-precision path (operands are ReLU outputs: >= 0)
   __shared__ f4 lds_w[(H3 ? 3 : 2) * chunk_f4(256)];
   __shared__ float vis_tab[DV_MAX_DIRS];
   __shared__ unsigned short idx_list[DV_MAX_DIRS];
@@ -182,6 +183,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
       for (int l = 0; l < 3; ++l) {
         if (l > 0) relu_split<256, NT>(z, w_unscale, xh, xl);
 #pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sat = sat_acc_nonneg(sat, xh[t][kb][q]);
+#pragma unroll
         for (int jb = 0; jb < 16; ++jb) {
           f4 res[NT];
           ring.template chunk<CH>(xh, xl, res);
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
       }
     }
   }
+  if constexpr (H3) range_report(sat, range_word);
   // drain the weight ring (the LDS-DMA variant still has chunks in flight that target this workgroup's LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -268,12 +276,14 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   if (precision == 0) {
     hipLaunchKernelGGL((k_dvis_fused<false, 1, 2>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A,
-                       Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count);
+                       Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count,
+                       (unsigned*)nullptr);
   } else {
 #define RB_LAUNCH_H3(CH, NT, ...)                                                                                     \
   hipLaunchKernelGGL((k_dvis_fused<true, CH, NT, ##__VA_ARGS__>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
                      n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
-                     ldexpf(1.0f, -scale_log2), vis_out, eval_count)
+                     ldexpf(1.0f, -scale_log2), vis_out, eval_count,                                                   \
+                     range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr)
     if (precision == 1) {
       RB_LAUNCH_H3(2, 2);       // two tiles per wave, one workgroup per CU, register staging
     } else if (precision == 4) {

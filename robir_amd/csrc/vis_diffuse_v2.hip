@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
     const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
     const float* __restrict__ wsum, const f4* __restrict__ W49, int L, int nsamp, int argmax_vis, float w_unscale,
-    float* __restrict__ vis_out, unsigned long long* __restrict__ eval_count) {
+    float* __restrict__ vis_out, unsigned long long* __restrict__ eval_count, unsigned* __restrict__ range_word) {
   __shared__ f4 ring[V2_SLOTS * V2_WF4];   // 64 KB
   __shared__ f4 headw[V2_WF4];             // 16 KB: chunk 48 (256 -> 2 head, rows 2..15 zero)
   __shared__ f4 bias_tab[49 * 4];
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
   }
 
   V2_T(1)
+  unsigned sat = 0u;                   // range sentinel: running max of the hi halves (all >= 0 here: ReLU outputs)
   unsigned xh[2][8][4], xl[2][8][4];   // B operands of the current layer (packed hi / lo halves)
   unsigned yh[2][8][4], yl[2][8][4];   // ... of the next layer, filled chunk by chunk
 
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     }
     const float v0 = fmaxf(r0 * w_unscale, 0.f), v1 = fmaxf(r1 * w_unscale, 0.f);
     v2_split_pair(v0, v1, yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
+    sat = sat_acc_nonneg(sat, yh[t][jb >> 1][(jb & 1) * 2 + q]);
   };
   auto epilogue = [&](const V2Acc& acc, int jb) {
 #pragma unroll
@@ -199,9 +201,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
         const f4 bv = raw[t][kb];
         const f4 av = a_row[kb * 4 + g];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < 2; ++q) {
           v2_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f),
                         xh[t][kb / 2][(kb & 1) * 2 + q], xl[t][kb / 2][(kb & 1) * 2 + q]);
+          sat = sat_acc_nonneg(sat, xh[t][kb / 2][(kb & 1) * 2 + q]);
+        }
       }
     }
     V2_T(2)
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     }
     V2_T(4)
   }
+  range_report(sat, range_word);
   // drain the ring (copies still target this workgroup's LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -334,7 +339,8 @@ extern "C" int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long 
   static const char* const tm = getenv("RB_V2_TIMED");   // read once
 #define RB_V2(T)                                                                                                          \
   hipLaunchKernelGGL(k_dvis_v2<T>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, \
-                     wdir, wsum, (const f4*)W49, L, nsamp, argmax_vis, ldexpf(1.0f, -scale_log2), vis_out, eval_count)
+                     wdir, wsum, (const f4*)W49, L, nsamp, argmax_vis, ldexpf(1.0f, -scale_log2), vis_out, eval_count,       \
+                     range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr)
   if (tm && tm[0] == '1') {
     RB_V2(true);
   } else {

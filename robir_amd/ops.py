@@ -15,6 +15,24 @@ def _f32(t):
     return t.contiguous()
 
 
+RANGE_FAMILIES = ("light-visibility kernel (rb_dvis_fused*)", "visibility MLP (rb_vis_mlp_h3)", "SDF MLP (rb_sdf_mlp_h3)",
+                  "colour MLP (rb_color_mlp_h3)", "512-wide nets (rb_wide_mlp_h3)", "CESR nets (rb_cesr_net_h3)")
+
+
+def range_check(sync=False):
+    """Raise RobirHipError if a split-precision kernel saw an activation beyond the f16 range of its hi/lo operand pairs
+    (include/robir_hip.h: rb_range_check).  sync=False costs nothing and reports kernels that have completed; sync=True waits
+    for the current stream first."""
+    mask = ctypes.c_uint(0)
+    call("rb_range_check", c_int(1 if sync else 0), stream_ptr(), ctypes.byref(mask))
+    if mask.value:
+        fams = [RANGE_FAMILIES[i] for i in range(len(RANGE_FAMILIES)) if mask.value >> i & 1]
+        raise _lib.RobirHipError(
+            "split-precision (f16x3) arithmetic overflowed its activation range in: " + "; ".join(fams) + " -- the outputs of "
+            "the call(s) since the last check are not fp32-accurate.  Select the exact f32-input MFMA kernels for this "
+            "checkpoint: ROBIR_MLP_PRECISION=fp32 and ROBIR_VIS_PRECISION=fp32 (INTEGRATION.md, 'range limits')")
+
+
 def feat_vis(p, d, rep=1):
     """p [M/rep,3] points, d [M,3] directions (rep consecutive directions per point)."""
     p, d = _f32(p), _f32(d)
@@ -179,6 +197,9 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
     call("rb_dvis_dirs", ptr(lgt), c_int(L), c_int(ns), c_int(C), c_int(1 if direct else 0), ptr(u_theta.contiguous()), ptr(u_phi.contiguous()),
          c_float(thr), ptr(dirs), ptr(wdir), ptr(wsum), stream_ptr())
     return dirs, wdir, wsum
+
+
+DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
 
 
 def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,

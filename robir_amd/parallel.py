@@ -25,8 +25,11 @@ def all_gather_tiles(tiles):
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(out, tiles.contiguous())
     else:
-        parts = list(out.chunk(world, 0))
-        dist.all_gather(parts, tiles.contiguous())
+        # gloo (CPU tests; two ranks sharing one GPU): stage through host memory, which every gloo build supports
+        host = tiles.detach().cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        out.copy_(torch.cat(parts, 0))
     return out
 
 
@@ -44,3 +47,57 @@ def gather_image(local_tiles, n_chunks, chunk, interleave=True):
         ids = shard_chunks(n_chunks, r, world, interleave)
         img[ids] = allt[r, : len(ids)]
     return img.reshape(n_chunks * chunk, F)
+
+
+TILE_FIELDS = ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "vis_shadow", "normal_map", "network_object_mask")
+
+
+def pack_tiles(o):
+    """The 17 floats per ray a consumer of a rendered view needs (plot_to_disk / relight keep exactly these)."""
+    return torch.cat([o["sg_rgb"], o["indir_rgb"], o["diffuse_albedo"], o["roughness"][:, :1], o["vis_shadow"],
+                      o["normal_map"], o["network_object_mask"][:, None].float()], -1)
+
+
+def plan_view(N, chunk, device, interleave=True, chunks_per_pass=None):
+    """Row indices of the passes this rank renders of an N-pixel view: [(chunk_ids, rows[int64] | slice, ragged)]."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    n_chunks = (N + chunk - 1) // chunk
+    ids = shard_chunks(n_chunks, rank, world, interleave)
+    full = [c for c in ids if (c + 1) * chunk <= N]
+    ragged = [c for c in ids if (c + 1) * chunk > N]            # at most the last chunk of the view
+    per = chunks_per_pass or max(1, len(full))
+    passes = []
+    for s in range(0, len(full), per):
+        grp = full[s:s + per]
+        if grp == list(range(grp[0], grp[0] + len(grp))):
+            rows = slice(grp[0] * chunk, (grp[-1] + 1) * chunk)
+        else:
+            rows = (torch.tensor(grp, device=device)[:, None] * chunk + torch.arange(chunk, device=device)[None]).reshape(-1)
+        passes.append((grp, rows, False))
+    for c in ragged:
+        passes.append(([c], slice(c * chunk, N), True))
+    return {"passes": passes, "n_chunks": n_chunks, "world": world, "N": N, "chunk": chunk, "interleave": interleave}
+
+
+def render_view_sharded(model, uv, pose, K, hdr_shift, chunk=1024, draws_for=None, interleave=True, stats=None,
+                        chunks_per_pass=None, plan=None):
+    """Strong-scaling render of ONE view: this rank renders chunks {c : c mod world = rank} through
+    IDRNetwork.render_chunks -- every chunk keeps its own lock-step tracer schedule and specular-cone minimum, i.e. exactly
+    what the reference computes rendering the chunks one after another -- then one all-gather of the 17-float tiles puts the
+    whole image [N, 17] on every rank.  Works without an initialised process group (world = 1).
+    uv [N,2], hdr_shift [N,1] on the device; draws_for(chunk_ids) -> explicit draws dict for those chunks (tests) or None."""
+    N = uv.shape[0]
+    plan = plan or plan_view(N, chunk, uv.device, interleave, chunks_per_pass)
+    parts = []
+    for grp, rows, is_ragged in plan["passes"]:
+        o = model.render_chunks(uv[rows], pose, K, hdr_shift[rows], chunk=chunk, stats=stats,
+                                draws=draws_for(grp) if draws_for else None)
+        t = pack_tiles(o)
+        if is_ragged:                                           # its own lock-step batch, like the reference's last chunk
+            t = torch.cat([t, t.new_zeros(chunk - t.shape[0], t.shape[1])])
+        parts.append(t)
+    local = torch.cat(parts) if len(parts) != 1 else parts[0]
+    if plan["world"] == 1:
+        return local[:N]
+    return gather_image(local, plan["n_chunks"], chunk, plan["interleave"])[:N]

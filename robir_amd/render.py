@@ -66,6 +66,8 @@ def render_view(model, uv, pose, K, chunks_per_pass=125, chunk=1024, hdr_shift=N
         for k in keys:
             acc[k].append(o[k])
     out = {k: torch.cat(v) for k, v in acc.items()}
+    from . import ops
+    ops.range_check(sync=True)          # a finished view is a natural sync point: raise if split precision overflowed
     tm = model.gamma.hdr_shift
     hit = out["network_object_mask"][:, None]
     pred = tm.hdr2ldr(out["sg_rgb"] + out["indir_rgb"], shift)

@@ -27,6 +27,8 @@ from .octree_tracing import OctreeTracing
 from .ray_tracing import RayTracing
 
 TINY_NUMBER = 1e-6
+import os as _os
+_RANGE_SYNC = _os.environ.get("ROBIR_RANGE_CHECK", "") == "sync"
 
 
 def _cfg(conf, key):
@@ -129,6 +131,17 @@ class IDRNetwork(nn.Module):
 
     def _render(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
                 albedo_ratio, origins=None, dirs_in=None):
+        # split-precision range sentinel (ops.range_check): free of charge without a sync -- an overflow in an earlier call is
+        # reported here at the latest; ROBIR_RANGE_CHECK=sync waits for this call's own kernels before returning
+        ops.range_check(sync=False)
+        out = self._render_impl(uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
+                                albedo_ratio, origins, dirs_in)
+        if _RANGE_SYNC:
+            ops.range_check(sync=True)
+        return out
+
+    def _render_impl(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
+                     albedo_ratio, origins=None, dirs_in=None):
         draws = draws or {}
         if origins is not None:
             dev, N = origins.device, origins.shape[0]

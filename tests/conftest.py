@@ -25,6 +25,31 @@ def _inference_mode_like_the_plot_path():
         yield
 
 
+def record_metric(name, **values):
+    """Append measured distances to gpurun_out/test_metrics.jsonl (travels back from the GPU box): the evidence behind the
+    tolerance bounds asserted in the GPU tests.  Best effort -- never fails a test."""
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_metrics.jsonl"), "a") as f:
+            f.write(json.dumps({"name": name, **{k: (float(v) if isinstance(v, (int, float, np.floating)) else v)
+                                                  for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass
+
+
+def err_entries(a, b):
+    """Per-entry |a-b| / (|b| + mean|b|) as a flat float64 tensor (the repo's tolerance convention), NaN==NaN -> 0."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    fin = torch.isfinite(b)
+    scale = b[fin].abs().mean() if fin.any() else torch.tensor(1.0, dtype=torch.float64)
+    e = (a - b).abs() / (b.abs() + scale + 1e-30)
+    return torch.nan_to_num(torch.where(same, torch.zeros_like(e), e), nan=float("inf")).reshape(-1)
+
+
 def rel_err(a, b):
     """max |a-b| / (|b| + mean|b|) over the tensor; NaN==NaN and inf==inf count as equal.
     The mean-|b| floor is the tolerance convention of this repo ('Parity tolerances')."""

@@ -1,0 +1,105 @@
+"""The multi-GPU partition with the renderer in the loop: two ranks render the chunks {c : c mod 2 = rank} of ONE
+view and all-gather the tiles; the gathered image must equal the single-rank image BIT FOR BIT (a chunk keeps its own
+lock-step tracer schedule, specular-cone minimum and random draws wherever it is rendered).  Both ranks share cuda:0 here
+(one-GPU box), so the collective runs over gloo; on a node it is the same code over RCCL (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+H = W = 96                       # 9 chunks of 1024 px: 5 for rank 0, 4 for rank 1 (exercises the padding of the gather)
+H_RAGGED, W_RAGGED = 72, 100     # 7200 px = 7 chunks + 32 px: the ragged last chunk is its own lock-step batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _draws_for(synth, counts, dev):
+    """Explicit per-chunk draws (hit rows concatenated in chunk order, light-visibility draws stacked per chunk)."""
+    def fn(chunk_ids):
+        per = [synth.pbr_draws(0, counts[c], chunk_id=c) for c in chunk_ids]
+        cat = {k: torch.from_numpy(np.concatenate([p[k] for p in per])).to(dev) for k in per[0] if not k.startswith("dvis")}
+        for k in ("dvis_theta", "dvis_phi"):
+            cat[k] = torch.from_numpy(np.stack([p[k] for p in per])).to(dev)
+        return cat
+    return fn
+
+
+def _worker(rank, world, port, hw, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from robir_amd import parallel, renderer, synth
+        with torch.no_grad():
+            model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+            h, w = hw
+            uv, pose, K = synth.synth_camera(h, w)
+            N = h * w
+            uv_d, pose_d, K_d = torch.from_numpy(uv).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+            hdr = torch.full((N, 1), 0.5, device=dev)
+            n_chunks = (N + 1023) // 1024
+            # hit counts per chunk (sizes of the per-hit draws) from a draw-free Illum pass over the full chunks + the ragged one
+            hit = torch.cat([model.render_chunks(uv_d[: (N // 1024) * 1024], pose_d, K_d, hdr[: (N // 1024) * 1024],
+                                                 trainstage="Illum", draws={})["network_object_mask"]] +
+                            ([model.render_chunks(uv_d[(N // 1024) * 1024:], pose_d, K_d, hdr[(N // 1024) * 1024:],
+                                                  trainstage="Illum", draws={})["network_object_mask"]] if N % 1024 else [])).cpu()
+            counts = [int(hit[c * 1024:(c + 1) * 1024].sum()) for c in range(n_chunks)]
+            draws_for = _draws_for(synth, counts, dev)
+            img = parallel.render_view_sharded(model, uv_d, pose_d, K_d, hdr, 1024, draws_for=draws_for)
+            mine = parallel.shard_chunks(n_chunks, rank, world)
+            ok_shape = tuple(img.shape) == (N, 17)
+            same = None
+            if rank == 0:
+                # the single-rank image: chunk by chunk through plain forward(), the reference's call shape
+                ref = []
+                for c in range(n_chunks):
+                    sl = slice(c * 1024, min(N, (c + 1) * 1024))
+                    o = model({"uv": uv_d[None, sl], "pose": pose_d[None], "intrinsics": K_d[None],
+                               "object_mask": torch.ones(1, sl.stop - sl.start, dtype=torch.bool, device=dev),
+                               "hdr_shift": hdr[sl]}, trainstage="Material", train_spec=True, draws=draws_for([c]))
+                    ref.append(parallel.pack_tiles(o))
+                ref = torch.cat(ref)
+                eq = (img == ref) | (torch.isnan(img) & torch.isnan(ref))
+                same = bool(eq.all())
+            torch.cuda.synchronize()
+        q.put((rank, ok_shape, same, len(mine), float(img[:, 16].mean()), None))
+        dist.destroy_process_group()
+    except Exception as e:       # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, False, False, 0, 0.0, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("hw", [(H, W), (H_RAGGED, W_RAGGED)])
+def test_two_ranks_render_one_view_bit_identically(hw):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, hw, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+    for r in res:
+        assert r[5] is None, r[5]
+        assert r[1], "gathered image has the wrong shape"
+    n_chunks = (hw[0] * hw[1] + 1023) // 1024
+    assert res[0][3] + res[1][3] == n_chunks and abs(res[0][3] - res[1][3]) <= 1
+    assert res[0][2] is True, "2-rank gathered image differs from the single-rank image"
+    assert res[0][4] == res[1][4] and 0.2 < res[0][4] < 0.9          # both ranks hold the same full image
