@@ -216,22 +216,29 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 // ---- activation-range sentinel ------------------------------------------------------------------------------------
 // v_cvt_pkrtz rounds toward zero, so a value beyond the f16 range does not become inf: its hi half saturates at 65504
-// (0x7BFF) and the pair silently loses precision.  Kernels keep a running packed max of the |hi| halves they consume and
-// flag the launch (common.h: range_flags) when one reaches 0x7BFF (also catches inf / NaN operands: 0x7C00, 0x7E00).
+// (0x7BFF) and the pair silently loses precision.  Kernels keep a running packed maximum over the hi halves they consume
+// and flag the launch (common.h: range_flags) when one is saturated or infinite.  NaN operands are NOT an overflow: they
+// come from NaN inputs (rays exactly parallel to an axis give NaN points in the reference too) and stay visible as NaN
+// outputs, so the tracker maps them below everything: key = (|h| + 0x03FF) as a SIGNED 16-bit number -- finite 0..0x7BFE
+// -> 0x03FF..0x7FFD, saturated 0x7BFF -> 0x7FFE, inf 0x7C00 -> 0x7FFF, NaN 0x7C01.. wraps negative.
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
-// signed operands: max over |hi| as unsigned 16-bit patterns (2 VALU ops per register pair)
 __device__ __forceinline__ unsigned sat_acc(unsigned sat, unsigned packed_hi) {
-  const us2 m = __builtin_elementwise_max(__builtin_bit_cast(us2, sat), __builtin_bit_cast(us2, packed_hi & 0x7fff7fffu));
+  const us2 key = __builtin_bit_cast(us2, packed_hi & 0x7fff7fffu) + us2{0x03ff, 0x03ff};
+  const ss2 m = __builtin_elementwise_max(__builtin_bit_cast(ss2, sat), __builtin_bit_cast(ss2, key));
   return __builtin_bit_cast(unsigned, m);
 }
-// operands known to be >= 0 (ReLU outputs): signed 16-bit max, -0.0 (0x8000) sorts below everything (1 VALU op)
+// operands known to be >= 0 and never NaN (ReLU outputs: fmaxf(NaN, 0) = 0): the raw pattern as a signed 16-bit number,
+// -0.0 (0x8000) sorts below everything (1 VALU op); saturated / inf = 0x7BFF / 0x7C00
 __device__ __forceinline__ unsigned sat_acc_nonneg(unsigned sat, unsigned packed_hi) {
   const ss2 m = __builtin_elementwise_max(__builtin_bit_cast(ss2, sat), __builtin_bit_cast(ss2, packed_hi));
   return __builtin_bit_cast(unsigned, m);
 }
+template <bool NONNEG = false>
 __device__ __forceinline__ void range_report(unsigned sat, unsigned* word) {
-  if (word && ((sat & 0xffffu) >= 0x7bffu || (sat >> 16) >= 0x7bffu)) *reinterpret_cast<volatile unsigned*>(word) = 1u;
+  constexpr int lim = NONNEG ? 0x7bff : 0x7ffe;
+  const int lo = (short)(sat & 0xffffu), hi = (short)(sat >> 16);
+  if (word && (lo >= lim || hi >= lim)) *reinterpret_cast<volatile unsigned*>(word) = 1u;
 }
 
 // Two fp32 values -> (packed hi halves, packed lo halves) with lo = v - float(hi).  One v_cvt_pkrtz per pair:

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void k_dvis_fused(
       }
     }
   }
-  if constexpr (H3) range_report(sat, range_word);
+  if constexpr (H3) range_report<true>(sat, range_word);
   // drain the weight ring (the LDS-DMA variant still has chunks in flight that target this workgroup's LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

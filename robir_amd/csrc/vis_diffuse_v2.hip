@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     }
     V2_T(4)
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   // drain the ring (copies still target this workgroup's LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
