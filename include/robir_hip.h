@@ -163,6 +163,18 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
 int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
+ *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
+ *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point
+ *             they belong to (balanced over the CUs for any n; the tile count is read from device memory: no host sync);
+ *   reduce    one workgroup per point: SG-weighted mean per lobe in the fixed sample order.
+ * Per pair the instruction sequence is that of rb_dvis_fused_v2: vis_out is bit-identical.  Caller-provided scratch (device):
+ *   pair_j[n*L*nsamp] u16, pair_vis[n*L*nsamp] f32, tile_info[n*L*nsamp/16][2] i32, point_info[n][2] i32, counters[2] u64.
+ * L*nsamp must be a multiple of 16. */
+int rb_dvis_stream(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                   const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                   unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
+                   int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Profiling aid: with RB_V2_TIMED=1 in the environment rb_dvis_fused_v2 runs an instrumented build that accumulates
  * shader-clock totals of wave 0 per phase (prologue, ring start, row gather, hidden layers, head, final reduction);
  * this call copies the six totals to out8[0..5] and clears them.  Returns non-zero on a HIP error. */

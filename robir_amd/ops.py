@@ -199,24 +199,48 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
     return dirs, wdir, wsum
 
 
-DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
+DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream", "f16x3-v2": "k_dvis_v2",
+                     "f16x3": "k_dvis_fused<H3>"}
+
+
+DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
+DVIS_STREAM_MAX_POINTS = 8192     # "f16x3-auto": launches up to this many surface points take the streaming family
 
 
 def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,
                precision="fp32"):
     """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain) or 'f16x3' (split-precision, ~2^-22 relative)."""
     normals = _f32(normals)
+    if precision == "f16x3-auto":
+        # same arithmetic, bit-identical results: the streaming family balances small launches (a single 1024-pixel chunk) over
+        # the CUs; at whole-view sizes the one-point-per-workgroup kernel is as fast and needs no scratch
+        precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
     h3 = precision.startswith("f16x3")
     assert h3 or precision == "fp32", precision
     # "f16x3-v2" (default of sg_render) = second-generation kernel: two tiles per wave, one workgroup per CU, head on
     # the matrix pipe (csrc/vis_diffuse_v2.hip);
     # "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA;
     # "f16x3-regstage" = same with global->VGPR->LDS staging; "f16x3-nt2" = two tiles per wave, one workgroup per CU
-    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7}[precision]
+    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
         assert chunk_id.dtype == torch.int32
+    if precision == "f16x3-v3":
+        # streaming form: global tile list + persistent grid (csrc/vis_diffuse_v3.hip); scratch sized for the worst case
+        # (every direction front-facing) so that nothing has to be read back to the host
+        LS = L * nsamp
+        dev = normals.device
+        pair_j = torch.empty(n * LS, dtype=torch.int16, device=dev)
+        pair_vis = torch.empty(n * LS, dtype=torch.float32, device=dev)
+        tile_info = torch.empty(n * LS // 16, 2, dtype=torch.int32, device=dev)
+        point_info = torch.empty(n, 2, dtype=torch.int32, device=dev)
+        counters = torch.empty(2, dtype=torch.int64, device=dev)
+        call("rb_dvis_stream", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+             ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(split["h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
+             c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
+        return out
     if precision == "f16x3-v2":
         call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),

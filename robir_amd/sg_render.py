@@ -21,11 +21,13 @@ from .nets import VisNetwork
 
 TINY_NUMBER = 1e-6
 # Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
-# chain); "f16x3-v2" (default) / "f16x3" = split-precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22
-# relative error, measured parity identical to "fp32": tests/test_sg_gpu.py runs all of them) in the second- / first-
-# generation kernel; "f16x3-nt2*", "f16x3-regstage" = register-blocking / staging variants of the first generation.
+# chain); "f16x3-auto" (default) = split precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative
+# error, measured parity identical to "fp32": tests/test_sg_gpu.py runs all of them, tests/test_precision_gpu.py anchors
+# both on float64) with the kernel generation picked by launch size: "f16x3-v3" (global tile list + persistent grid) for
+# small launches, "f16x3-v2" (one point per workgroup) for whole views -- bit-identical results; "f16x3" = first
+# generation; "f16x3-nt2*", "f16x3-regstage" = its register-blocking / staging variants.
 import os as _os
-VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3-v2")
+VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3-auto")
 
 
 # ----------------------------------------------------------------------------------------- small public helpers

@@ -79,6 +79,29 @@ def bad_frac(a, b, tol):
     return float((torch.nan_to_num(e, nan=float("inf")) > tol).double().mean())
 
 
+_CAPS = None
+
+
+def bounded(name, a, b, tol, frac):
+    """The repo's two-part bound for chained / end-to-end comparisons: at most `frac` of the entries beyond `tol`, and NO
+    entry beyond the cap recorded for `name` in tests/golden/measured_caps.json (= twice the maximum measured on an MI355X,
+    written by tools/update_caps.py from gpurun_out/test_metrics.jsonl; DESIGN.md 'Parity': the outliers are rays on a hit-mask
+    or cull threshold -- bounded, never arbitrary).  A name without a recorded cap fails: every comparison has a max bound."""
+    global _CAPS
+    import json
+    if _CAPS is None:
+        path = os.path.join(GOLD, "measured_caps.json")
+        _CAPS = json.load(open(path)) if os.path.exists(path) else {}
+    f, m = bad_frac(a, b, tol), rel_err(a, b)
+    cap = _CAPS.get(name)
+    record_metric("bounded/" + name, tol=tol, frac=f, max=m, frac_limit=frac, cap=cap if cap is not None else -1.0)
+    assert f <= frac, (name, "fraction beyond", tol, "is", f, "limit", frac)
+    if os.environ.get("ROBIR_RECORD_CAPS") == "1":
+        return
+    assert cap is not None, f"no cap recorded for {name}: run the GPU tests with ROBIR_RECORD_CAPS=1, then tools/update_caps.py"
+    assert m <= cap, (name, "max", m, "cap", cap)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False))
 

@@ -176,13 +176,14 @@ def test_visibility_point_without_front_facing_directions(dev, oracle_sd):
     nrm = torch.nn.functional.normalize(torch.rand(6, 3, generator=g) - 0.5, dim=-1)
     nrm[2] = 0.0
     u = torch.rand(2, 128, 32, generator=g)
-    for prec in ("f16x3-v2", "f16x3", "fp32"):
+    old_default = sg_render.VIS_PRECISION
+    for prec in ("f16x3-v3", "f16x3-v2", "f16x3", "fp32"):
         sg_render.VIS_PRECISION = prec
         try:
             v = sg_render._diffuse_vis_core(pts.to(dev), nrm.to(dev), m.visibility_network, lgt.to(dev), u[0].to(dev),
                                             u[1].to(dev), 1.0, False, None, 1, None).cpu()
         finally:
-            sg_render.VIS_PRECISION = "f16x3-v2"
+            sg_render.VIS_PRECISION = old_default
         assert float(v[2].abs().max()) == 0.0, prec
         lobe = lgt[:, :3] / (lgt[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
         ref = osg.diffuse_visibility(pts, nrm, lambda p, d: on.vis_logits(oracle_sd, p, d), lobe, lgt[:, 3:4].abs(), u[0], u[1]).t()

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, bad_frac, load_golden
+from conftest import rel_err, bad_frac, load_golden, bounded
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -78,7 +78,7 @@ def test_primary_cast_vs_reference_golden(dev, dev_octree):
         rh, rt = torch.from_numpy(g["hit"][i]), torch.from_numpy(g["t"][i])
         assert int((hit[sl].cpu() != rh).sum()) <= 2
         both = hit[sl].cpu() & rh
-        assert bad_frac(t[sl].cpu()[both], rt[both], TOL) <= 0.005
+        bounded("cast_primary_vs_reference_golden/t_c%d" % c, t[sl].cpu()[both], rt[both], TOL, 0.005)
         ref_m = list(g["sched_m_c%d" % c])
         assert [int(v) for v in sched[i, :len(ref_m), 1]] == ref_m
 

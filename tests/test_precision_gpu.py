@@ -66,7 +66,7 @@ def test_chained_error_budget(monkeypatch, seed, variance, sharp):
     draws = {k: torch.from_numpy(v) for k, v in synth.pbr_draws(seed + 40, n_hit, chunk_id=9).items()}
     dd = {k: v.to(dev) for k, v in draws.items()}
     outs = {}
-    for mode, vis in (("fp32", "fp32"), ("f16x3", "f16x3-v2")):
+    for mode, vis in (("fp32", "fp32"), ("f16x3", "f16x3-auto")):
         monkeypatch.setenv("ROBIR_MLP_PRECISION", mode)
         monkeypatch.setattr(sg_render, "VIS_PRECISION", vis)
         outs[mode] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in
@@ -175,13 +175,13 @@ def test_activation_range_sentinel(monkeypatch):
         return logits, vis, ref_logits, ref_vis
 
     s_ok = scale_for(1.0e3)                                          # hidden activations up to ~1e3
-    logits, vis, ref_logits, ref_vis = run(s_ok, "f16x3", "f16x3-v2")
+    logits, vis, ref_logits, ref_vis = run(s_ok, "f16x3", "f16x3-auto")
     ops.range_check(sync=True)                                       # nothing to report
     e1, e2 = rel_err(logits, ref_logits), rel_err(vis, ref_vis)
     record_metric("range_sentinel/act_1e3", scale=s_ok, logits=e1, light_vis=e2)
     assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
     s_bad = scale_for(2.0e5)                                         # beyond the f16 range of the hi halves
-    run(s_bad, "f16x3", "f16x3-v2")
+    run(s_bad, "f16x3", "f16x3-auto")
     with pytest.raises(_lib.RobirHipError, match="overflowed its activation range") as ei:
         ops.range_check(sync=True)
     assert "light-visibility" in str(ei.value) and "rb_vis_mlp_h3" in str(ei.value)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, bad_frac, load_golden
+from conftest import rel_err, bad_frac, load_golden, bounded
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -44,8 +44,8 @@ def test_matches_reference_golden(dev, implicit, tag):
     assert int((hit != gh).sum()) <= 1
     both = (hit & gh).numpy()
     assert bad_frac(dist[both], g["dist"][both], TOL) <= 0.005 and rel_err(dist[both], g["dist"][both]) <= 1e-3
-    assert bad_frac(x[both], g["points"][both], TOL) <= 0.005
-    assert bad_frac(dist[~both], g["dist"][~both], 1e-2) <= 0.05
+    bounded("raytracing_%s/points" % tag, x[both], g["points"][both], TOL, 0.005)
+    bounded("raytracing_%s/miss_dist" % tag, dist[~both], g["dist"][~both], 1e-2, 0.05)
 
 
 def test_matches_oracle_other_view_and_mask(dev, implicit, oracle_sd):
@@ -69,7 +69,7 @@ def test_matches_oracle_other_view_and_mask(dev, implicit, oracle_sd):
     both = hit & ho
     assert int(both.sum()) > 100
     assert bad_frac(dist[both], do[both], TOL) <= 0.005 and rel_err(dist[both], do[both]) <= 1e-3
-    assert bad_frac(x[both], xo[both], TOL) <= 0.005
+    bounded("raytracing_oracle_r08/points", x[both], xo[both], TOL, 0.005)
     # per-ray origins give the same result as one shared camera centre
     x2, hit2, dist2 = tr(implicit.sdf_only, cam.to(dev).expand(dirs.shape[0], 3).contiguous(), obj.to(dev), dirs[:, None, :])
     assert bool((hit2.cpu() == hit).all()) and float((dist2.cpu() - dist).abs().max()) == 0.0
@@ -103,7 +103,7 @@ def test_idr_network_with_ray_tracer(dev):
     hit, gh = a["network_object_mask"].cpu(), torch.from_numpy(g["hit"])
     assert int((hit != gh).sum()) <= 1
     both = (hit & gh).numpy()
-    assert bad_frac(a["points"].cpu()[both], g["points"][both], TOL) <= 0.005
+    bounded("raytracing_in_renderer/points", a["points"].cpu()[both], g["points"][both], TOL, 0.005)
     n_hit = int(hit.sum())
     dr = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(5, n_hit, chunk_id=1, nsamp_diffuse=8).items()}
     inp["hdr_shift"] = torch.zeros(1024, 1, device=dev)

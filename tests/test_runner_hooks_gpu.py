@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, rel_err, bad_frac, record_metric
+from conftest import ROOT, rel_err, bad_frac, record_metric, bounded
 
 pytestmark = pytest.mark.gpu
 
@@ -251,5 +251,5 @@ def test_runner_plot_loop_replay(dev, model, overlay_model_pkg):
     torch.manual_seed(104)
     nat = model(s, trainstage="Material", lin_diff=False, fun_spec=False, train_spec=True)
     sl = slice(4 * 1024, 5 * 1024)
-    assert bad_frac(merged["vis_shadow"][sl].cpu(), nat["vis_shadow"].cpu(), 1e-5) <= 0.01
-    assert bad_frac(merged["sg_rgb"][sl].cpu(), tm.hdr2ldr(nat["sg_rgb"]).cpu(), 1e-5) <= 0.01
+    bounded("runner_loop_replay/vis_shadow", merged["vis_shadow"][sl].cpu(), nat["vis_shadow"].cpu(), 1e-5, 0.01)
+    bounded("runner_loop_replay/sg_rgb", merged["sg_rgb"][sl].cpu(), tm.hdr2ldr(nat["sg_rgb"]).cpu(), 1e-5, 0.01)

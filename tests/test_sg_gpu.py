@@ -23,7 +23,7 @@ def vis_net(dev, synth_weights):
     return v.to(dev).eval()
 
 
-@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2", "f16x3-v2"])
+@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2", "f16x3-v2", "f16x3-v3"])
 def precision(request):
     from robir_amd import sg_render
     old = sg_render.VIS_PRECISION
@@ -204,3 +204,37 @@ def test_envmap_sg_grid_and_lookup(dev):
     ref = F.grid_sample(env.permute(2, 0, 1)[None], q, align_corners=True).squeeze().permute(1, 0)
     out = sg_render.render_envmap(env.to(dev), d.to(dev)).cpu()
     assert rel_err(out, ref) <= 1e-4
+
+
+def test_streaming_kernel_equals_one_point_per_workgroup_kernel(dev, vis_net):
+    """The third-generation family (global tile list + persistent grid, csrc/vis_diffuse_v3.hip) puts every (point, direction)
+    pair through the instruction sequence of k_dvis_v2: bit-identical visibilities -- for any number of persistent workgroups
+    (1, a prime, one per CU, more than there are rounds), for points without a single front-facing direction, for a single
+    point, across several chunks with their own direction tables."""
+    from robir_amd import ops, sg_render, synth
+    g = torch.Generator().manual_seed(12)
+    lgt = torch.from_numpy(synth.synth_light_sgs(0, 128)).to(dev)
+    for n, C in ((1, 1), (5, 1), (403, 3)):
+        pts = ((torch.rand(n, 3, generator=g) - 0.5) * 0.5).to(dev)
+        nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+        if n > 3:
+            nrm[3] = 0.0                                    # no front-facing direction at all
+        nrm = nrm.to(dev)
+        cid = (torch.arange(n) * C // n).to(torch.int32).to(dev) if C > 1 else None
+        u = torch.rand(2, C, 128, 32, generator=g).to(dev)
+        outs = {}
+        old_p, old_w = sg_render.VIS_PRECISION, ops.DVIS_STREAM_WORKGROUPS
+        try:
+            for prec, wgs in (("f16x3-v2", 0), ("f16x3-v3", 0), ("f16x3-v3", 1), ("f16x3-v3", 7), ("f16x3-v3", 4096)):
+                sg_render.VIS_PRECISION, ops.DVIS_STREAM_WORKGROUPS = prec, wgs
+                stats = {}
+                outs[(prec, wgs)] = (sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, C, stats),
+                                     int(stats["diffuse_vis_evals"]))
+        finally:
+            sg_render.VIS_PRECISION, ops.DVIS_STREAM_WORKGROUPS = old_p, old_w
+        ref, evals = outs[("f16x3-v2", 0)]
+        assert evals > 0 and bool(torch.isfinite(ref).all())
+        for k, (v, e) in outs.items():
+            assert e == evals, (n, k)
+            assert torch.equal(v, ref), (n, k, float((v - ref).abs().max()))
+        ops.range_check(sync=True)

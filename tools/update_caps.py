@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""tests/golden/measured_caps.json from gpurun_out/test_metrics.jsonl: cap = 2 x the maximum the GPU tests measured for every
+`bounded(...)` comparison (floored at the comparison's own tolerance), i.e. "measured max x 2" instead of an unbounded
+outlier allowance.  Run the GPU tests with ROBIR_RECORD_CAPS=1 first (records without asserting the caps)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "test_metrics.jsonl")
+caps, meas = {}, {}
+for line in open(src):
+    d = json.loads(line)
+    if d["name"].startswith("bounded/"):
+        n = d["name"][len("bounded/"):]
+        meas[n] = max(meas.get(n, 0.0), d["max"])
+        caps[n] = max(2.0 * meas[n], d["tol"])
+out = {k: float("%.3g" % v) for k, v in sorted(caps.items())}
+json.dump(out, open(os.path.join(ROOT, "tests", "golden", "measured_caps.json"), "w"), indent=0, sort_keys=True)
+for k in sorted(out):
+    print(f"{k:70s} measured {meas[k]:.3g}  cap {out[k]:.3g}")
