@@ -175,6 +175,34 @@ int rb_dvis_stream(const float* normals, const int* chunk_id, long n, const floa
                    const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                    unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
                    int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* ------------------------------------------------------------------------------------------------------------
+ * Traced light visibility -- OctreeVisModel (model/octree_tracing.py:63-85) as the VisModel of get_diffuse_visibility
+ * (model/sg_render.py:111-195), the mode `trace_vis` switches on (training/train_pbr.py:409-410): csrc/octree_vis.hip.
+ * rb_dvis_octree: same inputs / vis_out[n,L] as rb_dvis_fused_v2 with points[n,3] instead of the MLP rows and the octree
+ *   tables of rb_octree_cast_*; the surviving (point, direction) pairs of each chunk, in the reference's order, are traced in
+ *   lock-step batches of `batch_pairs` (reference: 2 000 000, sg_render.py:158) with max_iter (32) -- per batch the step size
+ *   (0.01 beyond 100 000 rays, else 0.005) and the per-iteration fine-march count follow utils/octree.py:542-549.
+ *   chunk_id must be ascending (points of a chunk contiguous).  No host synchronisation.  Scratch (device, caller-provided):
+ *   pcount[n] i32, prank[n] i32, chunk_tab[4*n_chunks+4] i64, group_tab[2*max_groups] i64, counters[34*max_groups] i32,
+ *   pair_p[cap] i32, pair_j[cap] u16, t_st[cap] f32, leaf_st[cap] i32, act_st[cap] u8, grp[cap] i32 (cap = n*L*nsamp),
+ *   point_span[2n] i64, layout[2] i64 (out: layout[0] = pairs traced).  max_groups >= sum over chunks of
+ *   ceil(pairs / batch_pairs) (<= n_chunks * ceil(points per chunk * L*nsamp / batch_pairs)).
+ * rb_octree_cast_grouped: the grouped lock-step secondary cast for explicit rays: group g = rays group_start[g] ..
+ *   group_start[g+1]-1 (device array of G+1 offsets) advances on its own schedule, exactly as if each group were a
+ *   separate rb_octree_cast_* call with max_iter.  Outputs as OctreeTracing.forward.  Scratch: gsize[G] i64, grp[R] i32,
+ *   t_st[R] f32, leaf_st[R] i32, act_st[R] u8, counters[34*G] i32.
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_dvis_octree(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
+                   const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
+                   const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
+                   int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
+                   unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
+                   long* layout, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+int rb_octree_cast_grouped(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                           const int* res, const float* origins, const float* dirs, long R, const long* group_start, int G,
+                           int max_iter, float clamp_dt, long* gsize, int* grp, float* t_st, int* leaf_st,
+                           unsigned char* act_st, int* counters, float* x_out, unsigned char* hit_out, float* t_out,
+                           rb_stream_t stream);
 /* Profiling aid: with RB_V2_TIMED=1 in the environment rb_dvis_fused_v2 runs an instrumented build that accumulates
  * shader-clock totals of wave 0 per phase (prologue, ring start, row gather, hidden layers, head, final reduction);
  * this call copies the six totals to out8[0..5] and clears them.  Returns non-zero on a HIP error. */

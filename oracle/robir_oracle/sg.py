@@ -62,7 +62,7 @@ def _run_vis(vis_fn, p, d, batch):
 
 
 def diffuse_visibility(points, normals, vis_fn, lobes, lambdas, u_theta, u_phi, thr=1.0, argmax_vis=False,
-                       return_dirs=False):
+                       return_dirs=False, batch=2000000):
     """get_diffuse_visibility (sg_render.py:111-195).  points/normals [n,3]; lobes [L,3]; lambdas [L,1];
     u_theta/u_phi [L,nsamp] uniform draws.  -> vis [L,n]."""
     L, nsamp = u_theta.shape
@@ -76,7 +76,7 @@ def diffuse_visibility(points, normals, vis_fn, lobes, lambdas, u_theta, u_phi, 
     flat = dirs.reshape(-1, 3)
     front = ((normals.unsqueeze(1) * flat.unsqueeze(0)).sum(-1)) > TINY
     pi_, di_ = front.nonzero(as_tuple=True)
-    logits = _run_vis(vis_fn, points[pi_], flat[di_], 2000000)
+    logits = _run_vis(vis_fn, points[pi_], flat[di_], batch)          # sg_render.py:158: batch_size = 2000000
     pv = logits.argmax(-1).float() if argmax_vis else torch.softmax(logits, -1)[..., 1]
     vis = torch.zeros(n, L * nsamp)
     vis[front] = pv

@@ -186,7 +186,10 @@ class OctreeTracing(nn.Module):
 
 
 class OctreeVisModel(nn.Module):
-    """octree_tracing.py:63-85: [is_hit, ~is_hit] as float 'logits'."""
+    """octree_tracing.py:63-85: traced visibility as a VisModel -- [is_hit, ~is_hit] as float 'logits' of ONE lock-step
+    secondary cast of the rays it is given.  robir_amd.sg_render recognises this class: the light-SG visibility then runs the
+    fused cull + grouped cast of csrc/octree_vis.hip (no (point, direction) pairs materialised, any number of chunks per call,
+    the reference's 2 M-pair batches), the BRDF-lobe visibility the grouped cast per chunk (`forward_groups`)."""
 
     def __init__(self, ray_tracer):
         super().__init__()
@@ -196,4 +199,13 @@ class OctreeVisModel(nn.Module):
     def forward(self, points, view_dirs):
         with torch.no_grad():
             _, is_hit = self.ray_tracer.sdf_octree.cast(points, view_dirs, return_is_hit=True)
+            return torch.stack([is_hit, ~is_hit], dim=-1).float()
+
+    def forward_groups(self, points, view_dirs, group_start):
+        """The same for rays partitioned into independent lock-step groups (one per chunk of a multi-chunk render): equals
+        calling forward() once per group."""
+        with torch.no_grad():
+            tree = self.ray_tracer.sdf_octree
+            _, is_hit, _ = ops.octree_cast_grouped(tree.tables, points.float().contiguous(), view_dirs.float().contiguous(),
+                                                   group_start, tree.max_iter)
             return torch.stack([is_hit, ~is_hit], dim=-1).float()

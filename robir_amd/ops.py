@@ -367,6 +367,58 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
     return x, hit.bool(), t_out, counters
 
 
+def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsamp, argmax_vis=False, eval_count=None,
+                batch_pairs=2000000, max_iter=32, max_points_per_chunk=1024):
+    """Traced light visibility (OctreeVisModel as the VisModel, csrc/octree_vis.hip) -> vis [n, L].  chunk_id ascending."""
+    points, normals = _f32(points), _f32(normals)
+    n = points.shape[0]
+    dev = points.device
+    LS = L * nsamp
+    out = torch.empty(n, L, dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    cap = n * LS
+    per_chunk = n if chunk_id is None else max_points_per_chunk
+    max_groups = n_chunks * ((per_chunk * LS + batch_pairs - 1) // batch_pairs) + 1
+    i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
+    i64 = lambda m: torch.empty(m, dtype=torch.int64, device=dev)
+    pcount, prank, counters = i32(n), i32(n), i32(34 * max_groups)
+    chunk_tab, group_tab, point_span, layout = i64(4 * n_chunks + 4), i64(2 * max_groups), i64(2 * n), i64(2)
+    pair_p, leaf_st, grp = i32(cap), i32(cap), i32(cap)
+    pair_j = torch.empty(cap, dtype=torch.int16, device=dev)
+    t_st = torch.empty(cap, dtype=torch.float32, device=dev)
+    act_st = torch.empty(cap, dtype=torch.uint8, device=dev)
+    call("rb_dvis_octree", *T.args(), ptr(points), ptr(normals), ptr(chunk_id), c_long(n), c_int(n_chunks), ptr(dirs), ptr(wdir),
+         ptr(wsum), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_long(batch_pairs), c_int(max_iter), ptr(pcount),
+         ptr(prank), ptr(chunk_tab), ptr(group_tab), c_int(max_groups), ptr(counters), ptr(pair_p), ptr(pair_j), ptr(t_st),
+         ptr(leaf_st), ptr(act_st), ptr(grp), ptr(point_span), ptr(layout), ptr(out), ptr(eval_count), stream_ptr())
+    return out
+
+
+def octree_cast_grouped(T, origins, dirs, group_start, max_iter=32):
+    """Secondary lock-step cast of explicit rays in independent groups (group g = rays group_start[g]:group_start[g+1], a device
+    int64 tensor of G+1 ascending offsets): what the reference computes calling the tracer once per group."""
+    origins, dirs = _f32(origins), _f32(dirs)
+    R = dirs.shape[0]
+    dev = dirs.device
+    G = group_start.numel() - 1
+    assert group_start.dtype == torch.int64 and G >= 1
+    x = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    hit = torch.empty(R, dtype=torch.uint8, device=dev)
+    t = torch.empty(R, dtype=torch.float32, device=dev)
+    if R == 0:
+        return x, hit.bool(), t
+    gsize = torch.empty(G, dtype=torch.int64, device=dev)
+    grp, leaf_st = (torch.empty(R, dtype=torch.int32, device=dev) for _ in range(2))
+    t_st = torch.empty(R, dtype=torch.float32, device=dev)
+    act_st = torch.empty(R, dtype=torch.uint8, device=dev)
+    counters = torch.empty(34 * G, dtype=torch.int32, device=dev)
+    call("rb_octree_cast_grouped", *T.args(), ptr(origins), ptr(dirs), c_long(R), ptr(group_start.contiguous()), c_int(G),
+         c_int(max_iter), c_float(T.clamp_dt), ptr(gsize), ptr(grp), ptr(t_st), ptr(leaf_st), ptr(act_st), ptr(counters), ptr(x),
+         ptr(hit), ptr(t), stream_ptr())
+    return x, hit.bool(), t
+
+
 def camera_rays(pose, K, uv):
     """pose [4,4], K [3,3] host-side tensors/arrays; uv [N,2] device."""
     import numpy as np

@@ -18,8 +18,10 @@ import torch
 
 from . import ops
 from .nets import VisNetwork
+from .octree_tracing import OctreeVisModel
 
 TINY_NUMBER = 1e-6
+OCTREE_VIS_BATCH = 2000000      # pairs per VisModel call of the reference (sg_render.py:158): one lock-step cast each
 # Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
 # chain); "f16x3-auto" (default) = split precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative
 # error, measured parity identical to "fp32": tests/test_sg_gpu.py runs all of them, tests/test_precision_gpu.py anchors
@@ -131,6 +133,15 @@ def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis,
             cnt = stats.setdefault("diffuse_vis_evals", torch.zeros(1, dtype=torch.int64, device=dev))
         return ops.dvis_fused(normals.float().contiguous(), cid, A, Bd, dirs, wdir, wsum, sp, L, nsamp, argmax_vis, cnt,
                               precision=VIS_PRECISION)
+    if isinstance(VisModel, OctreeVisModel):
+        # traced visibility (trace_vis, train_pbr.py:409-410): fused cull + lock-step secondary cast in the reference's
+        # 2 M-pair batches per chunk, no pairs materialised (csrc/octree_vis.hip)
+        cnt = None
+        if stats is not None:
+            cnt = stats.setdefault("diffuse_vis_evals", torch.zeros(1, dtype=torch.int64, device=dev))
+        tree = VisModel.ray_tracer.sdf_octree
+        return ops.dvis_octree(tree.tables, points.float().contiguous(), normals.float().contiguous(), cid, C, dirs, wdir, wsum,
+                               L, nsamp, argmax_vis, cnt, batch_pairs=OCTREE_VIS_BATCH, max_iter=tree.max_iter)
     return _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis)
 
 
@@ -145,8 +156,9 @@ def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L,
     front = (normals.unsqueeze(1) * dd).sum(-1) > TINY_NUMBER
     pi_, di_ = front.nonzero(as_tuple=True)
     logits = torch.zeros(pi_.shape[0], 2, device=points.device)
-    for s in range(0, pi_.shape[0], 2000000):
-        logits[s:s + 2000000] = VisModel(points[pi_[s:s + 2000000]], dd[pi_[s:s + 2000000], di_[s:s + 2000000]])
+    for s in range(0, pi_.shape[0], OCTREE_VIS_BATCH):          # sg_render.py:158: batches of 2 000 000 pairs
+        e = s + OCTREE_VIS_BATCH
+        logits[s:e] = VisModel(points[pi_[s:e]], dd[pi_[s:e], di_[s:e]])
     pv = logits.argmax(-1).float() if argmax_vis else torch.softmax(logits, -1)[..., 1]
     vis = torch.zeros(n, LS, device=points.device)
     vis[front] = pv
@@ -160,6 +172,11 @@ def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p,
     dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
     if isinstance(VisModel, VisNetwork):
         logits = VisModel.logits_from_features(ops.feat_vis(points.float().contiguous(), dirs, rep=nsamp))
+    elif isinstance(VisModel, OctreeVisModel) and cid is not None and C > 1:
+        # several chunks in one call: each chunk's n_c * nsamp rays are their own lock-step batch, as in the reference's
+        # per-chunk calls (group boundaries from the ascending chunk ids, computed on the device)
+        gs = torch.searchsorted(cid.long(), torch.arange(C + 1, device=cid.device)) * nsamp
+        logits = VisModel.forward_groups(points.unsqueeze(1).expand(-1, nsamp, 3).reshape(-1, 3), dirs, gs).contiguous()
     else:
         logits = VisModel(points.unsqueeze(1).expand(-1, nsamp, 3).reshape(-1, 3), dirs).float().contiguous()
     return ops.spec_vis_reduce(logits, front, wts, n, nsamp, inv, argmax_vis, testing)

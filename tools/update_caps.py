@@ -7,7 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "test_metrics.jsonl")
+src = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(ROOT, "gpurun_out", "test_metrics.jsonl")
 caps, meas = {}, {}
 for line in open(src):
     d = json.loads(line)
@@ -15,7 +15,10 @@ for line in open(src):
         n = d["name"][len("bounded/"):]
         meas[n] = max(meas.get(n, 0.0), d["max"])
         caps[n] = max(2.0 * meas[n], d["tol"])
-out = {k: float("%.3g" % v) for k, v in sorted(caps.items())}
-json.dump(out, open(os.path.join(ROOT, "tests", "golden", "measured_caps.json"), "w"), indent=0, sort_keys=True)
-for k in sorted(out):
+dst = os.path.join(ROOT, "tests", "golden", "measured_caps.json")
+old = json.load(open(dst)) if os.path.exists(dst) and "--fresh" not in sys.argv else {}
+old.update(caps)                      # comparisons not re-measured in this run keep their recorded cap
+out = {k: float("%.3g" % v) for k, v in sorted(old.items())}
+json.dump(out, open(dst, "w"), indent=0, sort_keys=True)
+for k in sorted(meas):
     print(f"{k:70s} measured {meas[k]:.3g}  cap {out[k]:.3g}")
