@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--vis-precision", default="f16x3-auto", choices=["fp32", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
+    ap.add_argument("--vis", default="mlp", choices=["mlp", "octree"],
+                    help="light / BRDF-lobe visibility model: the visibility MLP (default, the reference's default) or traced "
+                         "visibility = OctreeVisModel(octree_ray_tracer), the reference's `trace_vis` switch "
+                         "(training/train_pbr.py:409-410): the MLP's 98 %% of the PBR FLOPs become octree gathers")
     return ap.parse_args()
 
 
@@ -174,7 +178,12 @@ def main():
     build_s = time.time() - t0
 
     timer = KernelTimer()
-    ops.dvis_fused = timer.wrap(ops.dvis_fused)
+    if args.vis == "octree":
+        from robir_amd.octree_tracing import OctreeVisModel
+        model.visibility_network = OctreeVisModel(model.octree_ray_tracer)
+        ops.dvis_octree = timer.wrap(ops.dvis_octree)
+    else:
+        ops.dvis_fused = timer.wrap(ops.dvis_fused)
     uv, _, K = synth.synth_camera(H, W)
     pose = view_pose(0)                                  # every rank works on the SAME view: the N = 1 workload
     uv_d, pose_d, K_d = torch.from_numpy(uv).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
@@ -235,6 +244,22 @@ def main():
         weak = {"value": world * H * W * 2 / wdt, "unit": "rays/s", "steps": 2, "ms_per_step": wdt / 2 * 1e3,
                 "note": "one whole view per GPU (views differ in cost: hit fraction 0.65 .. 0.53)"}
 
+    octree_line = None
+    if args.vis == "octree":
+        lay = [int(v) for v in ops.LAST_OCTREE_VIS_LAYOUT.cpu()]
+        pairs, fetches, ray_steps = lay[0], lay[2], lay[3]
+        # algorithmic bytes of one traced-visibility launch: the 32-byte octree records its lock-step iterations read, plus the
+        # per-pair state written once and read once (pair 6 B, t 4, leaf 4, active 1, group 4) and the active flag re-read by
+        # every one of the 33 iterations
+        bytes_launch = 32.0 * fetches + pairs * (2 * 19.0 + 33.0)
+        octree_line = {"bound": "hbm", "kernel": "k_ovis_iter x33 + cull / fill / reduce (traced light visibility)",
+                       "achieved": bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                       "traffic": None, "launches": k_n, "avg_launch_ms": k_ms, "pairs_per_launch": pairs,
+                       "octree_records_read_per_ray": fetches / max(pairs, 1), "iterations_per_ray": ray_steps / max(pairs, 1),
+                       "gathered_bytes_per_ray": 32.0 * fetches / max(pairs, 1),
+                       "note": "gathers are dependent 32-byte reads of a 29 MB table (L2 / MALL resident): the bound is "
+                               "latency x occupancy, not HBM bandwidth; frac is against the HBM peak as the metric asks"}
+        octree_line["frac"] = octree_line["achieved"] / 8000.0
     if rank == 0:
         h3 = precision.startswith("f16x3")
         # peak of the pipe the dominant kernel runs on, per ALGORITHMIC flop: exact mode = dense f32-input MFMA;
@@ -265,11 +290,14 @@ def main():
                        "hit_fraction": round(hit_frac, 4), "octree_build_s": round(build_s, 2),
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B,
                        "parallelism": f"chunk-shard x{world} of one view + all-gather"},
-            "roofline": roofline,
+            "roofline": roofline if octree_line is None else octree_line,
         }
+        if args.vis == "octree":
+            line["metric"] = "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), traced visibility (trace_vis)"
+            line["config"]["visibility"] = "OctreeVisModel (secondary lock-step octree cast, max_iter 32, 2 M-pair batches)"
         if weak is not None:
             line["weak_views"] = weak
-    if world == 1 and precision != "fp32" and not args.no_exact:
+    if world == 1 and precision != "fp32" and not args.no_exact and args.vis == "mlp":
         # Second first-class figure: the same view with EVERY MLP on the exact f32-input MFMA (v_mfma_f32_16x16x4_f32),
         # timed over its own loop -- the rate at the reference's own precision -- and how far the default image is from it
         # under identical random draws.

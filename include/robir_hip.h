@@ -185,7 +185,7 @@ int rb_dvis_stream(const float* normals, const int* chunk_id, long n, const floa
  *   chunk_id must be ascending (points of a chunk contiguous).  No host synchronisation.  Scratch (device, caller-provided):
  *   pcount[n] i32, prank[n] i32, chunk_tab[4*n_chunks+4] i64, group_tab[2*max_groups] i64, counters[34*max_groups] i32,
  *   pair_p[cap] i32, pair_j[cap] u16, t_st[cap] f32, leaf_st[cap] i32, act_st[cap] u8, grp[cap] i32 (cap = n*L*nsamp),
- *   point_span[2n] i64, layout[2] i64 (out: layout[0] = pairs traced).  max_groups >= sum over chunks of
+ *   point_span[2n] i64, layout[4] i64 (out: [0] pairs traced, [2] 32-byte octree records read, [3] ray-iterations).  max_groups >= sum over chunks of
  *   ceil(pairs / batch_pairs) (<= n_chunks * ceil(points per chunk * L*nsamp / batch_pairs)).
  * rb_octree_cast_grouped: the grouped lock-step secondary cast for explicit rays: group g = rays group_start[g] ..
  *   group_start[g+1]-1 (device array of G+1 offsets) advances on its own schedule, exactly as if each group were a

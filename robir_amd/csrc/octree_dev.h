@@ -53,10 +53,12 @@ __device__ __forceinline__ int child_of(const f4& a, const f4& b, int fc, const 
 }
 // Octree.query for a point known to be strictly inside the root (octree.py:231-262); also returns the leaf's cached SDF.
 // Both halves of a node are fetched together: one memory latency per level.
-__device__ __forceinline__ int descend(const Oct& T, const float x[3], float& leaf_sdf) {
+// nfetch (optional): running count of 32-byte node records read -- the tracer's algorithmic memory traffic
+__device__ __forceinline__ int descend(const Oct& T, const float x[3], float& leaf_sdf, int* nfetch = nullptr) {
   int ptr = base_cell(T, x);
   while (true) {
     const f4 a = T.node[2 * (long)ptr], b = T.node[2 * (long)ptr + 1];
+    if (nfetch) *nfetch += 1;
     const int fc = __float_as_int(a[3]);
     if (fc < 0) {
       leaf_sdf = b[3];
@@ -122,9 +124,10 @@ __device__ __forceinline__ RayState cast_init(const Oct& T, const float o[3], co
 
 // one lock-step iteration for one active ray (octree.py:528-573)
 __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const float d[3], RayState& s, int m,
-                                          double step) {
+                                          double step, int* nfetch = nullptr) {
   float pos[3] = {o[0] + s.t * d[0], o[1] + s.t * d[1], o[2] + s.t * d[2]};
   const f4 a = T.node[2 * (long)s.leaf], b = T.node[2 * (long)s.leaf + 1];
+  if (nfetch) *nfetch += 1;
   const float mn[3] = {a[0], a[1], a[2]}, sz[3] = {b[0], b[1], b[2]};
   float near;
   float far = slab(mn, sz, pos, d, near);
@@ -157,6 +160,7 @@ __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const 
           a[k] = T.node[2 * (long)ptr[k]];
           b[k] = T.node[2 * (long)ptr[k] + 1];
         }
+        if (nfetch) *nfetch += FB;
         any = false;
 #pragma unroll
         for (int k = 0; k < FB; ++k) {
@@ -184,7 +188,7 @@ __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const 
     s.active = false;
   } else {
     float sv;
-    s.leaf = descend(T, pos, sv);
+    s.leaf = descend(T, pos, sv, nfetch);
     s.active = !(sv <= 1e-4f);
   }
 }

@@ -27,10 +27,12 @@ namespace rb {
 constexpr int OV_MAX_DIRS = 4096;
 constexpr int OV_ITERS = 34;        // counters per group: iterations 0 .. max_iter + 1 (max_iter <= 32)
 
-struct OvisLayout {                 // device scalars written by k_ovis_layout
+struct OvisLayout {                 // device scalars written by k_ovis_layout / accumulated by k_ovis_iter
   long total_pairs;
   int total_groups;
   int pad;
+  unsigned long long node_fetches;  // 32-byte octree records read by the lock-step iterations (algorithmic gather traffic)
+  unsigned long long ray_steps;     // (ray, iteration) pairs advanced
 };
 
 // points of chunk c are the contiguous range [lower_bound(cid, c), lower_bound(cid, c + 1))  (cid ascending)
@@ -121,6 +123,8 @@ __global__ __launch_bounds__(256) void k_ovis_layout(int n_chunks, const long* _
     }
     lay->total_pairs = po;
     lay->total_groups = go < max_groups ? go : max_groups;
+    lay->node_fetches = 0ull;
+    lay->ray_steps = 0ull;
     if (eval_count) atomicAdd(eval_count, (unsigned long long)po);     // statistics: secondary rays traced
   }
   for (long i = threadIdx.x; i < (long)max_groups * OV_ITERS; i += 256) counters[i] = 0;
@@ -230,10 +234,12 @@ template <class Rays>
 __global__ __launch_bounds__(256) void k_ovis_iter(Oct T, Rays rays, const long* __restrict__ total_ptr, long total_fixed,
                                                     const long* __restrict__ gsize, const int* __restrict__ grp, int it,
                                                     float* __restrict__ t_st, int* __restrict__ leaf_st,
-                                                    unsigned char* __restrict__ act_st, int* __restrict__ counters) {
+                                                    unsigned char* __restrict__ act_st, int* __restrict__ counters,
+                                                    OvisLayout* __restrict__ stats) {
   const long total = total_ptr ? *total_ptr : total_fixed;
   const long stride = (long)gridDim.x * blockDim.x;
   const long rounds = (total + stride - 1) / stride;
+  int nfetch = 0, nstep = 0;
   for (long r = 0; r < rounds; ++r) {
     const long i = r * stride + blockIdx.x * (long)blockDim.x + threadIdx.x;
     bool act = false;
@@ -250,13 +256,24 @@ __global__ __launch_bounds__(256) void k_ovis_iter(Oct T, Rays rays, const long*
       s.t = t_st[i];
       s.leaf = leaf_st[i];
       s.active = true;
-      cast_step(T, o, d, s, multi_samp(R, n_act), R > 100000 ? 0.01 : 0.005);
+      cast_step(T, o, d, s, multi_samp(R, n_act), R > 100000 ? 0.01 : 0.005, &nfetch);
+      nstep += 1;
       t_st[i] = s.t;
       leaf_st[i] = s.leaf;
       act_st[i] = s.active;
       act = s.active;
     }
     count_active(act, g, counters, it + 1);
+  }
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) {
+      nfetch += __shfl_xor(nfetch, o);
+      nstep += __shfl_xor(nstep, o);
+    }
+    if ((threadIdx.x & 63) == 0 && nstep) {
+      atomicAdd(&stats->node_fetches, (unsigned long long)nfetch);
+      atomicAdd(&stats->ray_steps, (unsigned long long)nstep);
+    }
   }
 }
 
@@ -392,7 +409,7 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
   const int grid = ovis_grid();
   for (int it = 0; it <= max_iter; ++it)      // the reference leaves its loop when it > max_iter: max_iter + 1 iterations
     hipLaunchKernelGGL(k_ovis_iter<PairRays>, dim3((unsigned)grid), dim3(256), 0, s, T, rays, &lay->total_pairs, 0L, gsize, grp, it,
-                       t_st, leaf_st, act_st, counters);
+                       t_st, leaf_st, act_st, counters, lay);
   if (int rc = check_launch("k_ovis_iter")) return rc;
   hipLaunchKernelGGL(k_ovis_reduce, dim3((unsigned)n), dim3(256), 0, s, chunk_id, n, wdir, wsum, pair_j, leaf_st,
                      reinterpret_cast<const long2*>(point_span), L, nsamp, argmax_vis, vis_out);
@@ -422,7 +439,7 @@ int rb_octree_cast_grouped(const float* node, const float* nrm, long B, const fl
   const int grid = (int)(blocks < ovis_grid() ? blocks : ovis_grid());
   for (int it = 0; it <= max_iter; ++it)
     hipLaunchKernelGGL(k_ovis_iter<ExplicitRays>, dim3((unsigned)grid), dim3(256), 0, s, T, rays, (const long*)nullptr, R, gsize,
-                       grp, it, t_st, leaf_st, act_st, counters);
+                       grp, it, t_st, leaf_st, act_st, counters, (OvisLayout*)nullptr);
   if (int rc = check_launch("k_ovis_iter")) return rc;
   hipLaunchKernelGGL(k_cast_grouped_finish, grid1d(R, 256), dim3(256), 0, s, T, rays, R, clamp_dt, t_st, leaf_st, x_out, hit_out,
                      t_out);

@@ -367,6 +367,9 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
     return x, hit.bool(), t_out, counters
 
 
+LAST_OCTREE_VIS_LAYOUT = None
+
+
 def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsamp, argmax_vis=False, eval_count=None,
                 batch_pairs=2000000, max_iter=32, max_points_per_chunk=1024):
     """Traced light visibility (OctreeVisModel as the VisModel, csrc/octree_vis.hip) -> vis [n, L].  chunk_id ascending."""
@@ -383,7 +386,7 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
     i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
     i64 = lambda m: torch.empty(m, dtype=torch.int64, device=dev)
     pcount, prank, counters = i32(n), i32(n), i32(34 * max_groups)
-    chunk_tab, group_tab, point_span, layout = i64(4 * n_chunks + 4), i64(2 * max_groups), i64(2 * n), i64(2)
+    chunk_tab, group_tab, point_span, layout = i64(4 * n_chunks + 4), i64(2 * max_groups), i64(2 * n), i64(4)
     pair_p, leaf_st, grp = i32(cap), i32(cap), i32(cap)
     pair_j = torch.empty(cap, dtype=torch.int16, device=dev)
     t_st = torch.empty(cap, dtype=torch.float32, device=dev)
@@ -392,6 +395,8 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
          ptr(wsum), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_long(batch_pairs), c_int(max_iter), ptr(pcount),
          ptr(prank), ptr(chunk_tab), ptr(group_tab), c_int(max_groups), ptr(counters), ptr(pair_p), ptr(pair_j), ptr(t_st),
          ptr(leaf_st), ptr(act_st), ptr(grp), ptr(point_span), ptr(layout), ptr(out), ptr(eval_count), stream_ptr())
+    global LAST_OCTREE_VIS_LAYOUT
+    LAST_OCTREE_VIS_LAYOUT = layout      # device tensor [pairs, groups, node records read, ray-iterations] of the last call
     return out
 
 
