@@ -93,6 +93,11 @@ int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_strea
  * 288 (skip layer: [208 | 64 | 16 zero slots]), 256 x4 and one scale 2^scale_log2. */
 int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
                   float* out0, float* grad, rb_stream_t stream);
+/* Second generation of rb_sdf_mlp_h3 (csrc/sdf_ring.hip): same arguments, packed weights and results (to fp32 rounding); the net
+ * is one cyclic chunk stream through an LDS-DMA ring, activations and hi/lo splits run between the MFMAs, workgroups are
+ * persistent (n_workgroups <= 0: one per compute unit). */
+int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
+                    float* out0, float* grad, int n_workgroups, rb_stream_t stream);
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).

@@ -101,12 +101,20 @@ def sdf_mlp(X, M, blob, mode, out_scale=1.0, grad_scale=1.0):
     return out0, grad
 
 
+import os as _os
+SDF_KERNEL = _os.environ.get("ROBIR_SDF_KERNEL", "ring")     # "ring" | "v1" (first-generation k_sdf_mlp_h3)
+
+
 def sdf_mlp_h3(X, M, blob, mode, scale_log2, out_scale=1.0, grad_scale=1.0):
     full = mode in (1, 3)
     out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=X.device)
     grad = torch.empty(M, 3, dtype=torch.float32, device=X.device) if mode >= 2 else None
-    call("rb_sdf_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(mode), c_int(scale_log2), c_float(out_scale),
-         c_float(grad_scale), ptr(out0), ptr(grad), stream_ptr())
+    if SDF_KERNEL == "ring":        # second generation: weight ring + activations between the MFMAs (csrc/sdf_ring.hip)
+        call("rb_sdf_mlp_ring", ptr(X), c_long(M), ptr(blob), c_int(mode), c_int(scale_log2), c_float(out_scale),
+             c_float(grad_scale), ptr(out0), ptr(grad), c_int(0), stream_ptr())
+    else:
+        call("rb_sdf_mlp_h3", ptr(X), c_long(M), ptr(blob), c_int(mode), c_int(scale_log2), c_float(out_scale),
+             c_float(grad_scale), ptr(out0), ptr(grad), stream_ptr())
     return out0, grad
 
 

@@ -99,11 +99,14 @@ def test_sdf_mlp(dev, pts_dirs, synth_weights, oracle_sd, mode):
         assert rel_err(grad.cpu(), nets.implicit_gradient(oracle_sd, pts)) <= TOL
 
 
+@pytest.mark.parametrize("kernel", ["ring", "v1"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-def test_sdf_mlp_split_precision(dev, pts_dirs, synth_weights, oracle_sd, mode):
-    """f16x3 form of the SDF kernels: same tolerance against the oracle, and fp32-rounding-level distance from the exact path."""
+def test_sdf_mlp_split_precision(dev, pts_dirs, synth_weights, oracle_sd, mode, kernel, monkeypatch):
+    """f16x3 form of the SDF kernels (second generation = weight ring, first generation = phase-alternating): same tolerance
+    against the oracle, and fp32-rounding-level distance from the exact path."""
     from robir_amd import ops, packing
     from robir_oracle import nets
+    monkeypatch.setattr(ops, "SDF_KERNEL", kernel)
     pts, _ = pts_dirs
     full = mode in (1, 3)
     X = ops.feat_pe10(pts.to(dev), scale=2.0, jvp=mode >= 2)
@@ -116,6 +119,33 @@ def test_sdf_mlp_split_precision(dev, pts_dirs, synth_weights, oracle_sd, mode):
     if mode >= 2:
         assert rel_err(grad.cpu(), nets.implicit_gradient(oracle_sd, pts)) <= TOL
         assert rel_err(grad.cpu(), exg.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_sdf_ring_kernel_many_rounds_and_ragged_sizes(dev, synth_weights, mode, monkeypatch):
+    """The ring kernel's workgroups are persistent: with more rounds of 128 rows than compute units every workgroup runs
+    several rounds on a ring that never drains (the 4-slot ring rotates by two slots per round), and the last round is ragged.
+    Against the first-generation kernel (same arithmetic) and the exact f32-MFMA kernel, for sizes around the tile / round /
+    grid boundaries."""
+    from robir_amd import ops, packing
+    full = mode in (1, 3)
+    g = torch.Generator().manual_seed(7)
+    h3 = packing.pack_sdf_h3(synth_weights, dev, full=full)
+    ex = packing.pack_sdf(synth_weights, dev, full=full)
+    for n in (1, 5, 31, 33, 127, 129, 40000 if mode >= 2 else 150001):
+        pts = ((torch.rand(n, 3, generator=g) - 0.5) * 1.6).to(dev)
+        X = ops.feat_pe10(pts, scale=2.0, jvp=mode >= 2)
+        monkeypatch.setattr(ops, "SDF_KERNEL", "ring")
+        a0, ag = ops.sdf_mlp_h3(X, n, h3, mode, packing.H3_SCALE_LOG2, out_scale=0.5, grad_scale=1.0)
+        monkeypatch.setattr(ops, "SDF_KERNEL", "v1")
+        b0, bg = ops.sdf_mlp_h3(X, n, h3, mode, packing.H3_SCALE_LOG2, out_scale=0.5, grad_scale=1.0)
+        e0, eg = ops.sdf_mlp(X, n, ex, mode, out_scale=0.5, grad_scale=1.0)
+        assert bool(torch.isfinite(a0).all())
+        assert rel_err(a0.cpu(), b0.cpu()) <= 2e-6, (n, rel_err(a0.cpu(), b0.cpu()))
+        assert rel_err(a0.cpu(), e0.cpu()) <= 1e-5, (n, rel_err(a0.cpu(), e0.cpu()))
+        if mode >= 2:
+            assert rel_err(ag.cpu(), bg.cpu()) <= 2e-6 and rel_err(ag.cpu(), eg.cpu()) <= 1e-5, n
+    ops.range_check(sync=True)
 
 
 def test_sdf_golden(dev, synth_weights):
