@@ -506,7 +506,15 @@ class NeuSModel(nn.Module):
         return 2.0
 
     def inv_s(self):
-        return float(torch.exp(self.deviation_network.variance.detach() * 10.0).clip(1e-6, 1e6))
+        """exp(10 * variance) clipped to [1e-6, 1e6] as a host float.  Reading it is a device synchronisation, and borrow_color
+        needs it for every 8192-point batch: cached on the parameter itself (same object, storage and version -- a real
+        nn.Parameter, not a temporary)."""
+        v = self.deviation_network.variance
+        key = (v.data_ptr(), v._version, v.device)
+        if getattr(self, "_inv_s_key", None) != key:
+            self._inv_s_val = float(torch.exp(v.detach() * 10.0).clip(1e-6, 1e6))
+            self._inv_s_key = key
+        return self._inv_s_val
 
     def forward(self, pnts, dirs, **kwargs):
         shape = list(pnts.shape[:-1]) + [-1]

@@ -217,7 +217,7 @@ class IDRNetwork(nn.Module):
                                      "vis_shadow", "random_xi_roughness", "random_xi_diffuse_albedo")}
         out1 = {k: ones1() for k in ("metallic", "random_xi_metallic", "acc", "final_t")}
         bg = ones3()
-        gerr = torch.tensor(0.0, device=dev)
+        gerr = torch.zeros((), device=dev)          # (torch.tensor(0.0, device=...) is a blocking host-to-device copy)
         if self.envmap_material_network.envmap is not None:
             bg = sg_render.render_envmap(self.envmap_material_network.envmap, dirs)
         if n > 0:
@@ -313,7 +313,7 @@ class CESRHook:
         Xp = ops.feat_pe10(points.float().contiguous())
         logits = self.shadow_net.eval_point_labels(Xp, 128)
         diffuse_vis = ops.softmax2(logits, 1)
-        normal_new = ops.normalize3(ops.cesr_net(Xp, Xp.shape[0], 0, self.normal_net.packed()), 1e-4, 1)
+        normal_new = ops.normalize3(self.normal_net._cesr(Xp, Xp.shape[0], 0), 1e-4, 1)
         albedo = mat["sg_diffuse_albedo"]
         ret = sg_render.render_with_all_sg(points=points, normal=normal_new if self.cur_iter > 1000 else mat["sg_normal_map"],
                                            viewdirs=vd, lgtSGs=mat["sg_lgtSGs"], indir_integral=ops.abs_scale(indir_integral, 2 * np.pi, take_abs=False),

@@ -227,7 +227,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
     shared = lgtSGs.dim() == 2 or (lgtSGs.stride(0) == 0)
     lgt_first = (lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]).float().contiguous()
     light_vis = None
-    supervise = torch.tensor(0.0, device=dev)
+    supervise = torch.zeros((), device=dev)
     if comp_vis:
         nsamp = 32 if diffuse_vis is None else 8          # sg_render.py:389
         u_t = draws.get("dvis_theta")
