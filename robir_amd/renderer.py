@@ -243,9 +243,13 @@ class IDRNetwork(nn.Module):
         return ret
 
     # ------------------------------------------------------------------ secondary rays
-    def trace_radiance(self, input, nsamp=16, test_dir=None, draws=None):
+    def trace_radiance(self, input, nsamp=16, test_dir=None, draws=None, chunk=None):
         """implicit_differentiable_renderer.py:566-650.  draws: (u1, u2) uniform [n*nsamp] replacing the two
-        torch.rand calls of spherical_uniform."""
+        torch.rand calls of spherical_uniform.
+        chunk: `input` holds several consecutive lock-step chunks of `chunk` pixels (the output of render_chunks): the
+        secondary rays of each chunk are then their own lock-step batch (grouped cast), exactly what the reference computes
+        calling trace_radiance once per 1024-pixel chunk (training/train_visibility.py); without it the call is ONE batch, like
+        one reference call."""
         forward_only_guard(self)
         if test_dir is not None:
             raise NotImplementedError("test_dir (debug option) is not built")
@@ -270,8 +274,19 @@ class IDRNetwork(nn.Module):
             d, back, cosw, origins = ops.sphere_dirs(u1.to(dev), u2.to(dev), nr, o, nsamp)
             sdirs = d.reshape(n, nsamp, 3)
             with torch.no_grad():
-                sec_x, sec_hit, _ = self.octree_ray_tracer(sdf=None, cam_loc=origins, object_mask=None,
-                                                           ray_directions=sdirs)
+                if chunk is not None and N > chunk:
+                    nc = (N + chunk - 1) // chunk
+                    per = torch.zeros(nc * chunk, dtype=torch.int64, device=dev)
+                    per[:N] = mask.reshape(-1).long()
+                    gs = torch.zeros(nc + 1, dtype=torch.int64, device=dev)
+                    gs[1:] = torch.cumsum(per.view(nc, chunk).sum(1), 0) * nsamp        # rays of chunk c: gs[c] .. gs[c+1]
+                    tree = self.octree_ray_tracer.sdf_octree
+                    ro = origins[:, None, :].expand(n, nsamp, 3).reshape(-1, 3).contiguous()
+                    sec_x, sec_hit, _ = ops.octree_cast_grouped(tree.tables, ro, sdirs.reshape(-1, 3).contiguous(), gs,
+                                                                tree.max_iter)
+                else:
+                    sec_x, sec_hit, _ = self.octree_ray_tracer(sdf=None, cam_loc=origins, object_mask=None,
+                                                               ray_directions=sdirs)
             rad = torch.zeros(n * nsamp, 3, device=dev)
             hidx = sec_hit.nonzero()[:, 0]
             if hidx.numel() > 0:

@@ -68,7 +68,7 @@ def config3(model):
     def illum():
         o = model.render_chunks(uv_d, pose_d, K_d, hdr, chunk=1024, trainstage="Illum")
         o["hdr_shift"] = hdr
-        return model.trace_radiance(o, nsamp=8)
+        return model.trace_radiance(o, nsamp=8, chunk=1024)      # every chunk its own lock-step batch, like the reference
 
     t = timed(illum, reps=2)
     print(f"config 3: 800x800 Illum forward + trace_radiance(nsamp=8): {t:.3f} s = {N / t:.3g} primary rays/s")
