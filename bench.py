@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 VIS_MACS_PER_EVAL = 229376          # 126*256 + 3*256*256 + 256*2
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
-TRAFFIC_B_PER_PAIR = 30.0          # profiles/r01_dvis_f16x3_pmc.md: 28-31 B per pair at 16 and 128 chunks per launch
+TRAFFIC_B_PER_PAIR = 24.0          # profiles/r02_dvis_pmc.md: (2 x FETCH_SIZE + WRITE_SIZE) / pairs of k_dvis_v2 at 32 chunks per launch (r01: 28-31)
 H = W = 800
 CHUNK = 1024
 

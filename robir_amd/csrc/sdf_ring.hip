@@ -112,9 +112,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
   const u4* ring_u = reinterpret_cast<const u4*>(ring) + lane;   // slot 0 (prologue)
   u4 wreg[18];
   unsigned sat = 0u;
-  unsigned xh[2][9][4], xl[2][9][4];   // operands of the current layer (K <= 288: nine k-blocks of 32)
-  unsigned yh[2][9][4], yl[2][9][4];   // ... of the next layer
-  unsigned sh[2][2][4], sl[2][2][4];   // the 64 input features / sqrt(2), lifted: skip operands of layer 4
+  // operand registers are 128-bit tuples (one MFMA B operand each): declared as vectors so that the register allocator keeps a
+  // k-block's four registers contiguous -- as scalars it rebuilt every tuple with accumulator-file copies (1.35 per MFMA)
+  u4 xh[2][9], xl[2][9];               // operands of the current layer (K <= 288: nine k-blocks of 32)
+  u4 yh[2][9], yl[2][9];               // ... of the next layer
+  u4 sh[2][2], sl[2][2];               // the 64 input features / sqrt(2), lifted: skip operands of layer 4
   f4 fraw[2][4];                       // input features of the NEXT round (prefetched)
   long rrow[2];                        // this lane's row in each tile of the current round
 
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     h8 a[2], b[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
-      b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
+      a[t] = __builtin_bit_cast(h8, xh[t][kb]);
+      b[t] = __builtin_bit_cast(h8, xl[t][kb]);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -198,8 +200,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      split_pair_mix(v[2 * q], v[2 * q + 1], yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
-      sat = sat_acc(sat, yh[t][jb >> 1][(jb & 1) * 2 + q]);
+      unsigned hi, lo;
+      split_pair_mix(v[2 * q], v[2 * q + 1], hi, lo);
+      yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
+      yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
+      sat = sat_acc(sat, hi);
     }
   };
   // piece (tile, register pair) of hidden chunk jb -> next layer's k-block jb/2, registers 2*(jb&1)+q
@@ -208,7 +213,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     if constexpr (JVP) {
       if (q == 0) jvp_stage_a(acc, t); else jvp_stage_b(jb, t, sa);
     } else {
-      act_pair(acc.a[t][2 * q], acc.a[t][2 * q + 1], sa, yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
+      unsigned hi, lo;
+      act_pair(acc.a[t][2 * q], acc.a[t][2 * q + 1], sa, hi, lo);
+      yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
+      yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
     }
   };
   // piece of output chunk jb: stores
@@ -317,11 +325,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
 #pragma unroll
       for (int kb = 0; kb < 9; ++kb)
         if (kb < nkb) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            xh[t][kb][q] = yh[t][kb][q];
-            xl[t][kb][q] = yl[t][kb][q];
-          }
+          xh[t][kb] = yh[t][kb];
+          xl[t][kb] = yl[t][kb];
         }
   };
   // rows of the copies of the first two chunks of the stream: in the distance-only modes the output layer is a single chunk,
@@ -357,10 +362,14 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
         const f4 v = fraw[t][kb];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          split_pair_mix(v[2 * q] * asc, v[2 * q + 1] * asc, xh[t][kb / 2][(kb & 1) * 2 + q], xl[t][kb / 2][(kb & 1) * 2 + q]);
-          sat = sat_acc(sat, xh[t][kb / 2][(kb & 1) * 2 + q]);
-          split_pair_mix(v[2 * q] * inv_sqrt2 * asc, v[2 * q + 1] * inv_sqrt2 * asc, sh[t][kb / 2][(kb & 1) * 2 + q],
-                         sl[t][kb / 2][(kb & 1) * 2 + q]);
+          unsigned hi, lo;
+          split_pair_mix(v[2 * q] * asc, v[2 * q + 1] * asc, hi, lo);
+          xh[t][kb / 2][(kb & 1) * 2 + q] = hi;
+          xl[t][kb / 2][(kb & 1) * 2 + q] = lo;
+          sat = sat_acc(sat, hi);
+          split_pair_mix(v[2 * q] * inv_sqrt2 * asc, v[2 * q + 1] * inv_sqrt2 * asc, hi, lo);
+          sh[t][kb / 2][(kb & 1) * 2 + q] = hi;
+          sl[t][kb / 2][(kb & 1) * 2 + q] = lo;
         }
       }
     // layer 0 (K = 64; its first two chunks were copied with P_HEAD rows): followed by layer 1

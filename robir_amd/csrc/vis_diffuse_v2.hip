@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
 
   V2_T(1)
   unsigned sat = 0u;                   // range sentinel: running max of the hi halves (all >= 0 here: ReLU outputs)
-  unsigned xh[2][8][4], xl[2][8][4];   // B operands of the current layer (packed hi / lo halves)
-  unsigned yh[2][8][4], yl[2][8][4];   // ... of the next layer, filled chunk by chunk
+  // 128-bit tuples (one MFMA B operand each), declared as vectors so that a k-block's four registers stay contiguous
+  u4 xh[2][8], xl[2][8];   // B operands of the current layer (packed hi / lo halves)
+  u4 yh[2][8], yl[2][8];   // ... of the next layer, filled chunk by chunk
 
   auto mfma_kb = [&](int kb, V2Acc& acc, const u4 (&wsrc)[16]) {
     const h8 wh = __builtin_bit_cast(h8, wsrc[kb * 2]);
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
     h8 a[2], b[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
-      b[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
+      a[t] = __builtin_bit_cast(h8, xh[t][kb]);
+      b[t] = __builtin_bit_cast(h8, xl[t][kb]);
     }
     // same product order as H3Ring::chunk (hi*lo, hi*hi, lo*hi; corrections share an accumulator).  The three MFMAs of
     // a tile are issued back to back: consecutive MFMAs on ONE accumulator hide up to two filler instructions each for
@@ -167,8 +168,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
       r1 += acc.a[t][1][2 * q + 1];
     }
     const float v0 = fmaxf(r0 * w_unscale, 0.f), v1 = fmaxf(r1 * w_unscale, 0.f);
-    v2_split_pair(v0, v1, yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
-    sat = sat_acc_nonneg(sat, yh[t][jb >> 1][(jb & 1) * 2 + q]);
+    unsigned hi, lo;
+    v2_split_pair(v0, v1, hi, lo);
+    yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
+    yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
+    sat = sat_acc_nonneg(sat, hi);
   };
   auto epilogue = [&](const V2Acc& acc, int jb) {
 #pragma unroll
@@ -202,9 +206,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
         const f4 av = a_row[kb * 4 + g];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          v2_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f),
-                        xh[t][kb / 2][(kb & 1) * 2 + q], xl[t][kb / 2][(kb & 1) * 2 + q]);
-          sat = sat_acc_nonneg(sat, xh[t][kb / 2][(kb & 1) * 2 + q]);
+          unsigned hi, lo;
+          v2_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f), hi, lo);
+          xh[t][kb / 2][(kb & 1) * 2 + q] = hi;
+          xl[t][kb / 2][(kb & 1) * 2 + q] = lo;
+          sat = sat_acc_nonneg(sat, hi);
         }
       }
     }
@@ -263,11 +269,10 @@ __global__ __launch_bounds__(256, 1) void k_dvis_v2(
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            xh[t][kb][q] = yh[t][kb][q];
-            xl[t][kb][q] = yl[t][kb][q];
-          }
+        {
+          xh[t][kb] = yh[t][kb];
+          xl[t][kb] = yl[t][kb];
+        }
     }
     V2_T(3)
     // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias (fetched by the last chunk of layer 2) and

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(256, 1) void k_dvis3_stream(
   };
 
   unsigned sat = 0u;                   // range sentinel: running max of the hi halves (all >= 0 here: ReLU outputs)
-  unsigned xh[2][8][4], xl[2][8][4];   // B operands of the current layer (packed hi / lo halves)
-  unsigned yh[2][8][4], yl[2][8][4];   // ... of the next layer, filled chunk by chunk
+  // 128-bit tuples (one MFMA B operand each), declared as vectors so that a k-block's four registers stay contiguous
+  u4 xh[2][8], xl[2][8];   // B operands of the current layer (packed hi / lo halves)
+  u4 yh[2][8], yl[2][8];   // ... of the next layer, filled chunk by chunk
 
   auto mfma_kb = [&](int kb, V3Acc& acc, const u4 (&wsrc)[16]) {
     const h8 wh = __builtin_bit_cast(h8, wsrc[kb * 2]);
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256, 1) void k_dvis3_stream(
     h8 a[2], bb[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      a[t] = __builtin_bit_cast(h8, u4{xh[t][kb][0], xh[t][kb][1], xh[t][kb][2], xh[t][kb][3]});
-      bb[t] = __builtin_bit_cast(h8, u4{xl[t][kb][0], xl[t][kb][1], xl[t][kb][2], xl[t][kb][3]});
+      a[t] = __builtin_bit_cast(h8, xh[t][kb]);
+      bb[t] = __builtin_bit_cast(h8, xl[t][kb]);
     }
     // product order hi*lo, hi*hi, lo*hi into ONE accumulator per tile, the three MFMAs of a tile back to back (see v2)
 #pragma unroll
@@ -190,8 +191,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis3_stream(
   auto epilogue_piece = [&](const V3Acc& acc, int jb, int piece) {
     const int t = piece >> 1, q = piece & 1;
     const float v0 = fmaxf(acc.a[t][2 * q] * w_unscale, 0.f), v1 = fmaxf(acc.a[t][2 * q + 1] * w_unscale, 0.f);
-    v3_split_pair(v0, v1, yh[t][jb >> 1][(jb & 1) * 2 + q], yl[t][jb >> 1][(jb & 1) * 2 + q]);
-    if constexpr (SENT) sat = sat_acc_nonneg(sat, yh[t][jb >> 1][(jb & 1) * 2 + q]);
+    unsigned hi, lo;
+    v3_split_pair(v0, v1, hi, lo);
+    yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
+    yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
+    if constexpr (SENT) sat = sat_acc_nonneg(sat, hi);
   };
   auto epilogue = [&](const V3Acc& acc, int jb) {
 #pragma unroll
@@ -256,9 +260,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis3_stream(
         const f4 av = arow[t * 64 + kb * 4 + g];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          v3_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f),
-                        xh[t][kb / 2][(kb & 1) * 2 + q], xl[t][kb / 2][(kb & 1) * 2 + q]);
-          if constexpr (SENT) sat = sat_acc_nonneg(sat, xh[t][kb / 2][(kb & 1) * 2 + q]);
+          unsigned hi, lo;
+          v3_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f), hi, lo);
+          xh[t][kb / 2][(kb & 1) * 2 + q] = hi;
+          xl[t][kb / 2][(kb & 1) * 2 + q] = lo;
+          if constexpr (SENT) sat = sat_acc_nonneg(sat, hi);
         }
       }
     }
@@ -313,11 +319,10 @@ __global__ __launch_bounds__(256, 1) void k_dvis3_stream(
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            xh[t][kb][q] = yh[t][kb][q];
-            xl[t][kb][q] = yl[t][kb][q];
-          }
+        {
+          xh[t][kb] = yh[t][kb];
+          xl[t][kb] = yl[t][kb];
+        }
     }
     // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias, wreg the next round's chunk 0 fragments
     {
