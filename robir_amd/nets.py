@@ -56,6 +56,43 @@ def forward_only_guard(module):
                                "torch.no_grad(), or freeze the parameters (training stays on the reference's modules)")
 
 
+# ----------------------------------------------------------------------------------------- small-batch concurrency
+# A single 1024-pixel chunk gives the 512-wide nets ~660 rows = 11 workgroups per launch: each launch is one workgroup's
+# latency (0.12 ms) on a machine with 256 CUs, and a chunk runs five of them back to back.  Independent nets of one forward
+# are therefore issued on side streams when the batch is small (joined before anything consumes them).  Whole-view batches
+# fill the GPU by themselves and stay on the caller's stream.
+import os as _os
+SIDE_STREAMS = _os.environ.get("ROBIR_SIDE_STREAMS", "1") != "0"
+SIDE_STREAM_MAX_ROWS = 8192
+_SIDE_POOL = {}
+
+
+def run_concurrently(thunks, rows):
+    """[t() for t in thunks]; for small batches on a GPU each thunk after the first runs on its own side stream.  Safe without
+    record_stream bookkeeping: a side section starts only after an event recorded on the caller's stream (everything enqueued
+    before -- including the consumers of tensors a previous side section allocated -- precedes it), and the caller's stream
+    waits for every side stream before this function returns."""
+    if len(thunks) < 2 or not SIDE_STREAMS or rows > SIDE_STREAM_MAX_ROWS or not torch.cuda.is_available():
+        return [t() for t in thunks]
+    cur = torch.cuda.current_stream()
+    pool = _SIDE_POOL.get(cur.device)
+    if pool is None:
+        pool = _SIDE_POOL[cur.device] = [torch.cuda.Stream(device=cur.device) for _ in range(3)]
+    ev = cur.record_event()
+    outs = [None] * len(thunks)
+    used = []
+    for i in range(1, len(thunks)):
+        st = pool[(i - 1) % len(pool)]
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            outs[i] = thunks[i]()
+        used.append(st)
+    outs[0] = thunks[0]()
+    for st in used:
+        cur.wait_stream(st)
+    return outs
+
+
 def _require_dims(name, got, want):
     if list(got) != list(want):
         raise NotImplementedError(f"{name}: the HIP kernels are built for dims {want}, got {list(got)}")
@@ -189,6 +226,13 @@ class SparseAE(nn.Module):
             lat, _ = ops.ae_latent(self._encode(X), self._var(dev), self._latent_act_code())
         return ops.ae_decode(lat, dec, self.out_dim, sig_out), ops.ae_decode(lat2, dec, self.out_dim, sig_out)
 
+    def run_pass(self, X):
+        """One encode -> latent activation -> decode pass on features X [n,64] (no latent noise)."""
+        forward_only_guard(self)
+        enc, dec = self._blobs()
+        lat, _ = ops.ae_latent(self._encode(X), self._var(X.device), self._latent_act_code())
+        return ops.ae_decode(lat, dec, self.out_dim, self.out_act is not None)
+
     def forward(self, values, noise=None):
         """values [n,in_dim] already-embedded inputs (as the reference passes them)."""
         n = values.shape[0]
@@ -234,19 +278,24 @@ class IndirctIllumNetwork(nn.Module):
         blob = self._packed.get("lobe", self.lobe_layer, lambda sd: packing.pack_illum(
             {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
         X = ops.feat_pe10(points.float().contiguous(), extra=hdr_shift.float().contiguous() if self.use_hdr else None)
-        if mlp_precision() == "f16x3":
-            blob3 = self._packed.get("lobe_h3", self.lobe_layer, lambda sd: packing.pack_illum_h3(
-                {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
-            sgs = ops.illum_decode(ops.wide_mlp_h3(X, blob3, False, packing.H3_SCALE_LOG2))
-        else:
-            sgs = ops.illum_decode(ops.illum_mlp(X, blob))
         if noise is None:
             noise = torch.randn(n, 64, device=dev)
         elif noise.shape[1] < 64:                # no_hdr: the reference draws randn_like of the 63 embedded columns
             noise = torch.nn.functional.pad(noise, (0, 64 - noise.shape[1]))
-        Xn = ops.axpy(X, noise.float().contiguous(), 0.02)
-        _, second = self.integral_layer.run(X, X_noisy=Xn, need_first=False)
-        return sgs, ops.abs_scale(second, 1.0)
+        noise = noise.float().contiguous()
+
+        def lobes():
+            if mlp_precision() == "f16x3":
+                blob3 = self._packed.get("lobe_h3", self.lobe_layer, lambda sd: packing.pack_illum_h3(
+                    {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
+                return ops.illum_decode(ops.wide_mlp_h3(X, blob3, False, packing.H3_SCALE_LOG2))
+            return ops.illum_decode(ops.illum_mlp(X, blob))
+
+        def integral():       # only the perturbed pass is used (implicit_differentiable_renderer.py:220)
+            return ops.abs_scale(self.integral_layer.run_pass(ops.axpy(X, noise, 0.02)), 1.0)
+
+        sgs, integ = run_concurrently([lobes, integral], n)      # two independent nets
+        return sgs, integ
 
 
 # ----------------------------------------------------------------------------------------- materials + light
@@ -290,17 +339,25 @@ class EnvmapMaterialNetwork(nn.Module):
         n, dev = points.shape[0], points.device
         pts = points.float().contiguous()
         nz_n = noise.get("normal")
-        if train_norm is False or train_spec:
+        want_spec = train_norm is False or train_spec
+        nz_s = None
+        if want_spec:
             nz_s = noise.get("spec")
             if nz_s is None:
                 nz_s = torch.randn(n, 32, device=dev)
-            brdf, brdf_r = self.spec_brdf_encoder_layer.run(ops.feat_pe10(pts), noise=nz_s.float().contiguous())
+            nz_s = nz_s.float().contiguous()
         if nz_n is None:
             nz_n = torch.randn(n, 60, device=dev)
-        nm, nm_r = self.normal_decoder_layer.run(ops.feat_ipe(pts, 1e-5),
-                                                 X_noisy=ops.feat_ipe(pts, 1e-5, nz_n.float().contiguous(), 0.02))
-        normal_map = ops.normalize3(nm, 1e-4, 1)
-        random_xi_normal = ops.normalize3(nm_r, 1e-4, 1)
+        nz_n = nz_n.float().contiguous()
+        # the spec auto-encoder and the two passes of the normal auto-encoder (clean / perturbed input) are independent
+        thunks = [lambda: ops.normalize3(self.normal_decoder_layer.run_pass(ops.feat_ipe(pts, 1e-5)), 1e-4, 1),
+                  lambda: ops.normalize3(self.normal_decoder_layer.run_pass(ops.feat_ipe(pts, 1e-5, nz_n, 0.02)), 1e-4, 1)]
+        if want_spec:
+            thunks.append(lambda: self.spec_brdf_encoder_layer.run(ops.feat_pe10(pts), noise=nz_s))
+        res = run_concurrently(thunks, n)
+        normal_map, random_xi_normal = res[0], res[1]
+        if want_spec:
+            brdf, brdf_r = res[2]
         if train_norm:
             return {"sg_normal_map": normal_map, "random_xi_normal": random_xi_normal}
         lgtSGs = self.restrict_lobes_upper(self.lgtSGs) if self.upper_hemi else self.lgtSGs

@@ -245,3 +245,30 @@ def test_illum_network_without_hdr_input(dev, precision, monkeypatch):
     ref_sgs, ref_int = onets.indirect_illum(sd, pts, None, noise)
     assert rel_err(sgs.cpu(), ref_sgs) <= TOL
     assert rel_err(integ.cpu(), ref_int) <= TOL
+
+
+def test_side_streams_give_identical_results(dev, synth_weights, monkeypatch):
+    """Small batches issue the independent 512-wide nets of one forward on side streams (nets.run_concurrently); the results are
+    those of the sequential order, bit for bit, over repeated calls that recycle the side streams' allocations."""
+    from robir_amd import nets as hnets, renderer
+    m = renderer.build_synthetic_model(dev, build_octrees=False)
+    g = torch.Generator().manual_seed(3)
+    outs = {}
+    for mode in (True, False, True):
+        monkeypatch.setattr(hnets, "SIDE_STREAMS", mode)
+        acc = []
+        for rep in range(6):
+            n = 700 - 37 * rep
+            pts = ((torch.rand(n, 3, generator=torch.Generator().manual_seed(rep)) - 0.5) * 0.5).to(dev)
+            hdr = torch.full((n, 1), 0.5, device=dev)
+            nz = {"spec": torch.randn(n, 32, generator=torch.Generator().manual_seed(10 + rep)).to(dev),
+                  "normal": torch.randn(n, 60, generator=torch.Generator().manual_seed(20 + rep)).to(dev)}
+            ill = torch.randn(n, 64, generator=torch.Generator().manual_seed(30 + rep)).to(dev)
+            sgs, integ = m.indirect_illum_network(pts, hdr, noise=ill)
+            mat = m.envmap_material_network(pts, train_spec=True, noise=nz)
+            acc.append(torch.cat([sgs.reshape(n, -1), integ, mat["sg_normal_map"], mat["random_xi_normal"], mat["sg_diffuse_albedo"],
+                                  mat["sg_roughness"], mat["random_xi_roughness"]], -1).cpu())
+        outs.setdefault(mode, []).append(acc)
+    a, b, c = outs[True][0], outs[False][0], outs[True][1]
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
