@@ -350,6 +350,10 @@ int rb_neus_mid_z(const float* z, long R, int n, float sample_dist, float* zmid,
 /* z / rays_d / sample_dist / cos_anneal: NULL z = stage-2 alpha from the neighbouring mid-point SDFs (model/sdf_render.py:
  * 206-218); z[R,n] (section starts) + rays_d[R,3] = stage-1 alpha, SDF extrapolated half a section along the ray with the
  * annealed cosine (neus/volume_render/sdf_render.py:172-190) -- for rendering directly from stage-1 checkpoints. */
+/* Stage-2 weights from the mid-point SDFs alone (same expressions as rb_neus_finish: bit-identical weights); keep[j] = weights[j]
+ * != 0, *count += kept.  Callers that do not need the eikonal term skip gradient + colour where the weight is exactly zero. */
+int rb_neus_weights(const float* sdf, const float* pts, long R, int n, float inv_s, float radius, float* weights,
+                    unsigned char* keep, unsigned long long* count, rb_stream_t stream);
 int rb_neus_finish(const float* sdf, long sdf_stride, const float* color, const float* grad, const float* pts,
                    const float* zmid, const float* near, const float* far, long R, int n, float inv_s, float radius,
                    int white, const float* z, const float* rays_d, float sample_dist, float cos_anneal, float* rgb,

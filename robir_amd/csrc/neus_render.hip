@@ -130,6 +130,41 @@ __global__ void k_mid_z(const float* __restrict__ z, long R, int n, float sample
   zmid[j] = z[j] + dz * 0.5f;
 }
 
+// Stage-2 weights of render_core from the mid-point SDFs alone (sdf_render.py:203-237: alpha from consecutive SDFs, inside-sphere
+// mask, transmittance product) -- the SAME expressions k_neus_finish evaluates, so `weights` and `keep` (w != 0) are bit-identical
+// to what the full pass produces.  Lets the caller skip gradient + colour for samples whose weight is exactly zero: behind the
+// first few opaque samples the transmittance underflows to 0 (trained sharpness: inv_s in the hundreds), and 0 * colour adds
+// nothing to any output.  keep[j] = 1 if weights[j] != 0; count += number kept.
+__global__ void k_neus_weights(const float* __restrict__ sdf, const float* __restrict__ pts, long R, int n, float inv_s,
+                               float radius, float* __restrict__ weights, unsigned char* __restrict__ keep,
+                               unsigned long long* __restrict__ count) {
+  const long r = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  int kept = 0;
+  if (r < R) {
+    float T = 1.f;
+    for (int k = 0; k < n; ++k) {
+      const long j = r * n + k;
+      const float s0 = sdf[j];
+      const float s1 = sdf[k + 1 < n ? j + 1 : j];
+      const float c0 = sigmoidf_(s0 * inv_s), c1 = sigmoidf_(s1 * inv_s);
+      float a = ((c0 - c1) + 1e-5f) / (c0 + 1e-5f);
+      a = fminf(fmaxf(a, 0.f), 1.f);
+      const float px = pts[3 * j], py = pts[3 * j + 1], pz = pts[3 * j + 2];
+      const float pn = sqrtf(px * px + py * py + pz * pz);
+      a = a * (pn < radius ? 1.f : 0.f);
+      const float w = a * T;
+      T = T * (1.f - a + 1e-7f);
+      weights[j] = w;
+      const bool k1 = w != 0.f;        // NaN weights are kept (they must reach the outputs like in the reference)
+      keep[j] = k1 ? 1 : 0;
+      kept += k1 ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(count, (unsigned long long)kept);
+}
+
 // render_core compositing + render_neus epilogue (sdf_render.py:203-260, 354-374).
 // sdf: column 0 of an [M, sdf_stride] matrix.  gerr[2] += (sum relax*(|g|-1)^2, sum relax).
 __global__ void k_neus_finish(const float* __restrict__ sdf, long sdf_stride, const float* __restrict__ color,
@@ -309,6 +344,15 @@ int rb_neus_mid_z(const float* z, long R, int n, float sample_dist, float* zmid,
   RB_REQUIRE(z && zmid, "null pointer");
   hipLaunchKernelGGL(k_mid_z, grid1d(R * n, 256), dim3(256), 0, (hipStream_t)stream, z, R, n, sample_dist, zmid);
   return check_launch("k_mid_z");
+}
+
+int rb_neus_weights(const float* sdf, const float* pts, long R, int n, float inv_s, float radius, float* weights,
+                    unsigned char* keep, unsigned long long* count, rb_stream_t stream) {
+  if (R <= 0) return 0;
+  RB_REQUIRE(sdf && pts && weights && keep && count, "null pointer");
+  hipLaunchKernelGGL(k_neus_weights, grid1d(R, 128), dim3(128), 0, (hipStream_t)stream, sdf, pts, R, n, inv_s, radius, weights,
+                     keep, count);
+  return check_launch("k_neus_weights");
 }
 
 int rb_neus_finish(const float* sdf, long sdf_stride, const float* color, const float* grad, const float* pts,

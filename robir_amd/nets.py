@@ -565,13 +565,17 @@ class NeuSModel(nn.Module):
     def inv_s(self):
         """exp(10 * variance) clipped to [1e-6, 1e6] as a host float.  Reading it is a device synchronisation, and borrow_color
         needs it for every 8192-point batch: cached on the parameter itself (same object, storage and version -- a real
-        nn.Parameter, not a temporary)."""
+        nn.Parameter, not a temporary).  Optimizer steps, load_state_dict and any in-place op on the parameter bump its version;
+        a write through `variance.data` does not (autograd's escape hatch) -- call refresh_inv_s() after one."""
         v = self.deviation_network.variance
         key = (v.data_ptr(), v._version, v.device)
         if getattr(self, "_inv_s_key", None) != key:
             self._inv_s_val = float(torch.exp(v.detach() * 10.0).clip(1e-6, 1e6))
             self._inv_s_key = key
         return self._inv_s_val
+
+    def refresh_inv_s(self):
+        self._inv_s_key = None
 
     def forward(self, pnts, dirs, **kwargs):
         shape = list(pnts.shape[:-1]) + [-1]

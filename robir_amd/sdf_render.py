@@ -22,10 +22,16 @@ def _f(t):
 
 
 def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
-                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, stage1_alpha=False):
+                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, stage1_alpha=False, need_grad_error=True):
     """model/sdf_render.py:263-374 (stage 2; `cos_anneal_ratio` is ignored there).  stage1_alpha=True renders with the
     stage-1 render_core instead (neus/volume_render/sdf_render.py:172-190: alpha from the cos-annealed half-section
-    extrapolation of the SDF), i.e. what NeuS stage-1 checkpoints were trained against; see render_neus_stage1."""
+    extrapolation of the SDF), i.e. what NeuS stage-1 checkpoints were trained against; see render_neus_stage1.
+
+    need_grad_error=False (stage 2 only): the caller does not use the eikonal term `grad_error` (no stage-2 caller of the
+    reference does, model/sdf_render.py:376-420).  The weights are then computed first from an SDF-only pass, and gradient +
+    colour are evaluated only for samples whose weight is not exactly zero -- rgb / dist / acc / grad / weights are bit-identical
+    (0 * colour adds nothing), `grad_error` is NaN.  Pays off for trained sharpness (inv_s in the hundreds: the transmittance
+    underflows to 0 a few samples behind the surface); costs one sync to size the compacted batch."""
     if n_outside != 0 or lindisp or not (is_eval or perturb == 0):
         raise NotImplementedError("HIP render_neus: n_outside=0, lindisp=False, is_eval=True (deterministic sampling)")
     o, d = _f(rays.origins), _f(rays.directions)
@@ -68,17 +74,40 @@ def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64
     zmid = torch.empty(R, n, device=dev)
     call("rb_neus_mid_z", ptr(z), c_long(R), c_int(n), c_float(sample_dist), ptr(zmid), S())
     pts, dirs = points(zmid, want_dirs=True)
-    out, grad = net.eval_points(pts, full=True, grad=True)               # [M,257], [M,3]
-    col = model.color_network(pts, grad, dirs, out[:, 1:])
+    pruned = not need_grad_error and not stage1_alpha
+    if pruned:
+        sdf_mid = net.eval_points(pts, full=False)[0]                    # [M]: the value the full pass would produce, bit for bit
+        w0 = torch.empty(R, n, device=dev)
+        keep = torch.empty(R * n, dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        call("rb_neus_weights", ptr(sdf_mid), ptr(pts), c_long(R), c_int(n), c_float(model.inv_s()), c_float(radius), ptr(w0),
+             ptr(keep), ptr(cnt), S())
+        idx = keep.nonzero()[:, 0]                                       # (the one host sync of this path)
+        out = torch.zeros(R * n, 1, device=dev)
+        out[:, 0] = sdf_mid
+        grad = torch.zeros(R * n, 3, device=dev)
+        col = torch.zeros(R * n, 3, device=dev)
+        if idx.numel() > 0:
+            pk, dk = pts[idx].contiguous(), dirs[idx].contiguous()
+            ok, gk = net.eval_points(pk, full=True, grad=True)
+            grad[idx] = gk
+            col[idx] = model.color_network(pk, gk, dk, ok[:, 1:])
+        sdf_stride = 1
+    else:
+        out, grad = net.eval_points(pts, full=True, grad=True)           # [M,257], [M,3]
+        col = model.color_network(pts, grad, dirs, out[:, 1:])
+        sdf_stride = 257
     rgb, dist, acc = torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
     nrm, w = torch.empty(R, 3, device=dev), torch.empty(R, n, device=dev)
     gerr = torch.zeros(2, device=dev)
     z = z.contiguous()
-    call("rb_neus_finish", ptr(out), c_long(257), ptr(col), ptr(grad), ptr(pts), ptr(zmid), ptr(near), ptr(far), c_long(R),
+    call("rb_neus_finish", ptr(out), c_long(sdf_stride), ptr(col), ptr(grad), ptr(pts), ptr(zmid), ptr(near), ptr(far), c_long(R),
          c_int(n), c_float(model.inv_s()), c_float(radius), c_int(1 if white_bkgd else 0),
          ptr(z if stage1_alpha else None), ptr(d if stage1_alpha else None), c_float(sample_dist),
          c_float(float(cos_anneal_ratio)), ptr(rgb), ptr(dist), ptr(acc), ptr(nrm), ptr(w), ptr(gerr), S())
     ge = gerr[0] / (gerr[1] + 1e-5)
+    if pruned:
+        ge = torch.full((), float("nan"), device=dev)        # not evaluated on the skipped samples
     if stage1_alpha:        # the stage-1 function's own result dict (neus/volume_render/sdf_render.py:358-365)
         return {"rgb": rgb, "dist": dist, "acc": acc, "sim_or_grad": ge, "weights": w, "means": zmid}
     return {"rgb": rgb, "dist": dist, "acc": acc, "grad_error": ge, "grad": nrm, "weights": w}

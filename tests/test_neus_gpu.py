@@ -114,3 +114,30 @@ def test_render_neus_second_weight_set(dev):
     out = sdf_render.render_neus(rays, m, 1.0, is_eval=True)
     for k, tol in (("rgb", 2e-4), ("dist", 2e-4), ("acc", 4e-4), ("grad", 4e-4)):
         bounded("render_neus_second_ckpt/" + k, out[k].cpu(), ref[k], tol, 0.01)
+
+
+@pytest.mark.parametrize("variance", [0.3, 0.6])
+def test_render_neus_zero_weight_pruning_is_exact(dev, synth_weights, variance):
+    """need_grad_error=False: weights first (SDF-only pass), gradient + colour only where the weight is not exactly zero.  Every
+    output except the eikonal term is bit-identical to the full evaluation -- also the SDF the weights come from (the
+    distance-only kernel mode and the full forward-mode one produce the same value row)."""
+    from robir_amd import sdf_render, synth
+    from robir_oracle import renderer as orend
+    model = _neus(dev, synth_weights, variance)
+    uv, pose, K = synth.synth_camera(64, 64)
+    dirs, cam = orend.camera_rays(torch.from_numpy(uv)[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
+    R = 3000
+    ro = (cam.expand(R, 3) * 2.0).contiguous().to(dev)
+    rd = dirs[0, 500:500 + R].contiguous().to(dev)
+    near, far = torch.full((R, 1), 0.8, device=dev), torch.full((R, 1), 2.8, device=dev)
+    rays = sdf_render.Rays(ro, rd, rd, None, None, near, far)
+    full = sdf_render.render_neus(rays, model, 1.0, is_eval=True)
+    fast = sdf_render.render_neus(rays, model, 1.0, is_eval=True, need_grad_error=False)
+    for k in ("rgb", "dist", "acc", "grad", "weights"):
+        assert torch.equal(full[k], fast[k]), (k, float((full[k] - fast[k]).abs().max()))
+    assert bool(torch.isnan(fast["grad_error"])) and bool(torch.isfinite(full["grad_error"]))
+    kept = float((fast["weights"] != 0).float().mean())
+    from conftest import record_metric
+    record_metric("render_neus_pruning/variance_%g" % variance, kept_fraction=kept)
+    if variance >= 0.6:
+        assert kept < 0.9          # trained-like sharpness: the transmittance underflows behind the surface

@@ -57,6 +57,22 @@ def config2(model):
     # 112 SDF evaluations for the sampling + 128 x (SDF+features, gradient, colour) = 0.59 GFLOP per ray
     print(f"config 2: render_neus 400x400, 128 samples/ray: {t:.3f} s = {R / t:.3g} rays/s = {0.59e9 * R / t / 1e12:.0f} "
           "algorithmic TFLOP/s")
+    if os.environ.get("RB_CONFIG_REPS") == "1":
+        return                       # profiling run: the default path only
+    # the same without the (unused in stage 2) eikonal term: gradient + colour only where the weight is non-zero -- identical
+    # rgb / dist / acc / grad / weights.  Depends on the sharpness of the SDF: the untrained init (variance 0.3, inv_s 20)
+    # keeps every sample, a trained-like sharpness (variance 0.6, inv_s 403) drops the samples behind the surface
+    var = neus.deviation_network.variance
+    old = float(var)
+    for v in (old, 0.6):
+        var.fill_(v)
+        o = sdf_render.render_neus(rays, neus, 1.0, is_eval=True, need_grad_error=False)
+        kept = float((o["weights"] != 0).float().mean())
+        t0 = timed(lambda: sdf_render.render_neus(rays, neus, 1.0, is_eval=True), reps=2)
+        t1 = timed(lambda: sdf_render.render_neus(rays, neus, 1.0, is_eval=True, need_grad_error=False), reps=2)
+        print(f"config 2 (variance {v:g}, inv_s {neus.inv_s():.0f}): full {t0:.3f} s = {R / t0:.3g} rays/s; without grad_error "
+              f"{t1:.3f} s = {R / t1:.3g} rays/s ({100 * kept:.0f} % of the samples carry weight)")
+    var.fill_(old)
 
 
 def config3(model):
