@@ -1,0 +1,325 @@
+"""Deferred chunk forwards: the unchanged runners' loop at the batched rate.
+
+The reference's evaluation loops (training/train_pbr.py:248-281, training/train_cesr.py:310-350, scripts/relight.py:42-58) cut a
+view into 1024-pixel chunks (utils/general.py:27-38), call `model(s, trainstage=...)` once per chunk, keep a few detached /
+tone-mapped fields of every result and only look at the numbers after utils.merge_output (utils/general.py:55-69).  One
+1024-ray call cannot fill 256 CUs (4 ms of dependent launches), the same chunks as ONE pass of
+IDRNetwork.render_chunks run at the bench rate.  With `model.deferred_chunks = N` (env ROBIR_DEFER_CHUNKS) an eval-mode
+`forward()` therefore only RECORDS its chunk and returns placeholders:
+
+  * ChunkQueue     the recorded chunks of one pass (same stage / flags / camera / hook), copied into staging buffers;
+  * ChunkOutputs   the dict `forward()` returns; its values are DeferredTensors created on first access;
+  * DeferredTensor a tensor without storage that knows its shape, dtype and device.  torch functions applied to it are recorded
+                   too (output shapes come from running the function on meta tensors), so `a + b`, `x[..., 0:1]`, `.expand`,
+                   `.reshape`, `torch.cat`, `hdr2ldr` ... stay placeholders; anything that needs the numbers (`.cpu()`,
+                   `.item()`, `.numpy()`, `bool()`, printing, an in-place write, a kernel of this library taking its address)
+                   first runs the queue it descends from -- as one render_chunks-shaped pass -- and then the recorded functions.
+
+What a recorded pass computes is exactly IDRNetwork._render on the concatenated chunks, i.e. what render_chunks returns for them
+(every chunk keeps its own lock-step trace, its own sample tables and its own specular minimum).  Differences from immediate
+execution, all stated in INTEGRATION.md: random numbers are drawn when the pass runs, starting from the generator state at the
+time of its first recorded chunk; weights must not change while chunks are pending (checked: RuntimeError); train(), eval(),
+load_light() and flush() run what is pending.
+"""
+import os
+import weakref
+
+import torch
+
+DEFAULT_CHUNKS = int(os.environ.get("ROBIR_DEFER_CHUNKS", "0") or 0)
+_NO_TF = torch._C.DisableTorchFunctionSubclass
+_LIVE = weakref.WeakSet()            # queues with recorded chunks that have not run
+
+# need the numbers (or write into them): run what is pending, then call the function on ordinary tensors
+_FORCE = frozenset((
+    "cpu", "cuda", "to", "numpy", "item", "tolist", "data_ptr", "is_contiguous", "storage", "untyped_storage", "copy_", "set_",
+    "record_stream", "backward", "pin_memory", "share_memory_", "__bool__", "__float__", "__int__", "__index__", "__complex__",
+    "__repr__", "__str__", "__format__", "__reduce_ex__", "__reduce__", "__deepcopy__", "__array__", "__array_wrap__",
+    "__setitem__", "__contains__", "__dlpack__", "__dlpack_device__", "__cuda_array_interface__", "__iter__", "__hash__",
+    "equal", "allclose", "is_nonzero", "nonzero", "unique", "masked_select"))
+_NOT_INPLACE = frozenset(("__index__", "__int__", "__invert__", "__iter__", "__init__", "__init_subclass__"))
+
+
+def _inplace(name):
+    if name.startswith("__"):
+        return name.startswith("__i") and name not in _NOT_INPLACE
+    return name.endswith("_")
+
+
+class DeferredTensor(torch.Tensor):
+    @staticmethod
+    def __new__(cls, meta, device, thunk):
+        t = torch.Tensor._make_wrapper_subclass(cls, meta.shape, dtype=meta.dtype, device=device)
+        t._rb_meta, t._rb_thunk, t._rb_value = meta, thunk, None
+        return t
+
+    def __init__(self, *a, **k):
+        pass
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__":                      # .shape .dtype .device .ndim .is_cuda .requires_grad ...: the wrapper knows
+            with _NO_TF():
+                return func(*args, **kwargs)
+        if name == "detach" and len(args) == 1:    # results carry no graph
+            return args[0]
+        if name == "__hash__":
+            return id(args[0])
+        if name in _FORCE or _inplace(name) or kwargs.get("out") is not None:
+            return func(*_plain(args), **_plain(kwargs))
+        try:
+            with _NO_TF():
+                mout = func(*_meta(args), **_meta(kwargs))
+        except Exception:                          # data-dependent output, or no meta kernel: compute now
+            return func(*_plain(args), **_plain(kwargs))
+        dev = _device_of(args) or _device_of(tuple(kwargs.values()))
+        if isinstance(mout, torch.Tensor):
+            return DeferredTensor(mout, dev, lambda: func(*_plain(args), **_plain(kwargs)))
+        if isinstance(mout, (tuple, list)) and mout and all(isinstance(m, torch.Tensor) for m in mout):
+            cell = []
+
+            def whole():
+                if not cell:
+                    cell.append(func(*_plain(args), **_plain(kwargs)))
+                return cell[0]
+            outs = [DeferredTensor(m, dev, (lambda i: (lambda: whole()[i]))(i)) for i, m in enumerate(mout)]
+            try:
+                return type(mout)(outs)
+            except TypeError:
+                return tuple(outs)
+        return mout                                # shape arithmetic (sizes, bools, ints): no numbers involved
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # reached only by calls that bypass __torch_function__ (C++ callers): compute on ordinary tensors
+        return func(*_plain(args), **_plain(kwargs or {}))
+
+
+def is_deferred(x):
+    return type(x) is DeferredTensor
+
+
+def materialize(t):
+    """The ordinary tensor behind a placeholder (runs the recorded pass / functions on first use)."""
+    v = t._rb_value
+    if v is None:
+        v = t._rb_thunk()
+        if is_deferred(v):
+            v = materialize(v)
+        t._rb_value, t._rb_thunk = v, None
+    return v
+
+
+def plain(x):
+    return materialize(x) if type(x) is DeferredTensor else x
+
+
+def _plain(x):
+    if type(x) is DeferredTensor:
+        return materialize(x)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_plain(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    return x
+
+
+def _meta(x):
+    if type(x) is DeferredTensor:
+        return x._rb_meta
+    if isinstance(x, torch.Tensor):
+        return torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device="meta")
+    if isinstance(x, (list, tuple)):
+        return type(x)(_meta(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _meta(v) for k, v in x.items()}
+    return x
+
+
+def _device_of(xs):
+    for x in xs:
+        if type(x) is DeferredTensor:
+            with _NO_TF():
+                return x.device
+        if isinstance(x, (list, tuple)):
+            d = _device_of(x)
+            if d is not None:
+                return d
+    return None
+
+
+def lazy_like(x, fn):
+    """Placeholder with x's shape (float32) for fn(ordinary tensor of x) -- for element-wise kernels of this library."""
+    with _NO_TF():
+        shape, dev = tuple(x.shape), x.device
+    return DeferredTensor(torch.empty(shape, dtype=torch.float32, device="meta"), dev, lambda: fn(materialize(x)))
+
+
+def flush_all():
+    """Run every recorded pass (called before anything that changes what a pass would compute)."""
+    for q in list(_LIVE):
+        q.flush()
+
+
+# per-ray trailing shapes of what IDRNetwork._shade returns (renderer.py); checked against the real result when a pass has run
+_F3 = ("points", "ray_dirs", "bg_rgb", "sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb",
+       "indir_specular_rgb", "normals", "diffuse_albedo", "roughness", "normal_map", "vis_shadow", "random_xi_roughness",
+       "random_xi_diffuse_albedo")
+_F1 = ("sdf_output", "metallic", "random_xi_metallic", "acc", "final_t")
+_B0 = ("network_object_mask", "surface_mask")
+
+
+def output_spec(trainstage, n_indirect_sgs, has_hdr):
+    """name -> (trailing shape, dtype) of the per-ray outputs; None for the pass-wide scalar."""
+    if trainstage == "Illum":
+        spec = {"points": ((3,), torch.float32), "sdf_output": ((1,), torch.float32), "ray_dirs": ((3,), torch.float32),
+                "network_object_mask": ((), torch.bool), "indirect_sgs": ((n_indirect_sgs, 7), torch.float32),
+                "indir_integral": ((3,), torch.float32), "normals": ((3,), torch.float32)}
+    else:
+        spec = {k: ((3,), torch.float32) for k in _F3}
+        spec.update({k: ((1,), torch.float32) for k in _F1})
+        spec.update({k: ((), torch.bool) for k in _B0})
+        spec["gradient_error"] = None
+    return spec
+
+
+class ChunkQueue:
+    def __init__(self, model, sig, spec, chunk, limit, pose, K, has_hdr, device, render_args):
+        self.model = weakref.ref(model)
+        self.sig, self.spec, self.chunk, self.limit = sig, spec, chunk, limit
+        self.pose, self.K = pose.clone(), K.clone()
+        self.render_args = render_args
+        cap = chunk * limit
+        self.uv = torch.empty(cap, 2, device=device)
+        self.mask = torch.empty(cap, dtype=torch.bool, device=device)
+        self.hdr = torch.empty(cap, 1, device=device) if has_hdr else None
+        self.rays, self.slots, self.closed = 0, [], False
+        self.result = None
+        self.running = False
+        self.versions = _versions(model)
+        gen = torch.cuda.default_generators[device.index or 0] if device.type == "cuda" else torch.default_generator
+        self.gen, self.gen_state = gen, gen.get_state()
+        _LIVE.add(self)
+
+    def add(self, uv, mask, hdr):
+        n = uv.shape[0]
+        a = self.rays
+        self.uv[a:a + n].copy_(uv)
+        self.mask[a:a + n].copy_(mask)
+        if self.hdr is not None:
+            self.hdr[a:a + n].copy_(hdr)
+        self.slots.append((a, n))
+        self.rays = a + n
+        if n < self.chunk or len(self.slots) == self.limit:
+            self.closed = True                     # a short chunk can only be the last one of a pass
+        return len(self.slots) - 1
+
+    def flush(self):
+        if self.result is not None or self.running:
+            return
+        model = self.model()
+        _LIVE.discard(self)
+        if model is None:
+            raise RuntimeError("deferred chunks outlived their model")
+        if model.__dict__.get("_pending") is self:
+            model._pending = None
+        if _versions(model) != self.versions:
+            raise RuntimeError("model parameters changed while chunk forwards were pending (deferred_chunks > 0): call "
+                               "model.flush() before modifying weights")
+        self.running = True
+        try:
+            now = self.gen.get_state()
+            untouched = torch.equal(now, self.gen_state)
+            self.gen.set_state(self.gen_state)       # draw as if the pass had run when its first chunk was recorded
+            n = self.rays
+            hdr = self.hdr[:n] if self.hdr is not None else None
+            self.result = model._render(self.uv[:n], self.pose, self.K, self.mask[:n], hdr, self.chunk, *self.render_args)
+            if not untouched:                      # somebody re-seeded / drew in between: leave their stream alone
+                self.gen.set_state(now)
+        finally:
+            self.running = False
+        self.uv = self.mask = self.hdr = None
+        keys = set(self.result) - {"object_mask", "hdr_shift"}
+        if keys != set(self.spec):
+            raise RuntimeError(f"deferred pass returned {sorted(keys ^ set(self.spec))} unexpectedly")
+
+    def get(self, slot, name):
+        self.flush()
+        v = self.result[name]
+        if self.spec[name] is None:
+            return v
+        a, n = self.slots[slot]
+        return v[a:a + n]
+
+
+def _versions(model):
+    return tuple(p._version for p in model.parameters())
+
+
+class ChunkOutputs(dict):
+    """What a recorded forward() returns: placeholders made on first access (the runners read 6-10 of the 25 fields)."""
+
+    def __init__(self, queue, slot, n, device, given):
+        super().__init__(given)
+        self._q, self._slot, self._n, self._dev = queue, slot, n, device
+
+    def __missing__(self, k):
+        q = self._q
+        if k not in q.spec:
+            raise KeyError(k)
+        s = q.spec[k]
+        meta = (torch.empty((), device="meta") if s is None
+                else torch.empty((self._n,) + s[0], dtype=s[1], device="meta"))
+        slot = self._slot
+        t = DeferredTensor(meta, self._dev, lambda: q.get(slot, k))
+        self[k] = t
+        return t
+
+    def _fill(self):
+        for k in self._q.spec:
+            if not dict.__contains__(self, k):
+                self.__missing__(k)
+
+    def get(self, k, default=None):
+        if dict.__contains__(self, k) or k in self._q.spec:
+            return self[k]
+        return default
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or k in self._q.spec
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None

@@ -382,6 +382,8 @@ class EnvmapMaterialNetwork(nn.Module):
     def load_light(self, path):
         """sg_envmap_material.py:257-268: `<path>/sg_128.npy` light SGs + `<path>.exr` background map (read by robir_amd.exr:
         the reference goes through imageio)."""
+        from . import deferred
+        deferred.flush_all()               # recorded chunk forwards were meant for the light that is loaded now
         sg = torch.from_numpy(np.load(os.path.join(path, "sg_128.npy"))).to(self.lgtSGs.data.device)
         self.lgtSGs.data = sg
         from .exr import read_exr
@@ -711,11 +713,19 @@ class ACESToneMapping(nn.Module):
 
     def _apply_tm(self, x, raw_shift, mode):
         shape = x.shape
-        xs = x.detach().float().reshape(-1, 3).contiguous()
-        sh = self.make_shift(raw_shift).reshape(-1).to(xs.device)
-        if sh.numel() != 1 and sh.numel() != xs.shape[0]:
-            sh = sh.expand(xs.shape[0]) if sh.numel() == 1 else sh.reshape(-1)
-        return ops.tonemap(xs, sh.contiguous(), mode + 16 * self._curve).reshape(shape)
+        rows = x.numel() // 3
+        sh = self.make_shift(raw_shift).reshape(-1).to(x.device)
+        if sh.numel() != 1 and sh.numel() != rows:
+            sh = sh.expand(rows) if sh.numel() == 1 else sh.reshape(-1)
+        sh = sh.contiguous()
+        from . import deferred
+
+        def run(v):
+            xs = v.detach().float().reshape(-1, 3).contiguous()
+            return ops.tonemap(xs, sh, mode + 16 * self._curve).reshape(shape)
+        if deferred.is_deferred(x):        # a recorded chunk forward (deferred.py): tone-map when its pass has run
+            return deferred.lazy_like(x, run)
+        return run(x)
 
     def hdr2ldr(self, x, raw_shift=None):
         return self._apply_tm(x, raw_shift, 0)

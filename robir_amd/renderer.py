@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, sg_render
+from . import deferred, ops, sg_render
 from .nets import (ImplicitNetworkMy, IndirctIllumNetwork, VisNetwork, EnvmapMaterialNetwork, GammaCorrect,
                    forward_only_guard)
 from .octree_tracing import OctreeTracing
@@ -108,13 +108,59 @@ class IDRNetwork(nn.Module):
         # the same outputs as the runner's split_input(n_pixels=1024) loop at the batched rate.
         chunk = getattr(self, "lockstep_chunk", None)
         chunk = N if not chunk or N <= chunk else int(chunk)
+        limit = self.__dict__.get("deferred_chunks", deferred.DEFAULT_CHUNKS)
+        if (limit and not self.training and chunk == N and N <= 1024 and self.use_octree and draws is None and stats is None
+                and input.get("albedo_ratio") is None):
+            return self._record_chunk(input, N, int(limit), trainstage, fun_spec, lin_diff)
+        self.flush()
         return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), chunk,
                             trainstage, fun_spec, lin_diff, draws, stats, input.get("albedo_ratio"))
+
+    # ------------------------------------------------------------------ deferred chunk forwards (robir_amd/deferred.py)
+    def _record_chunk(self, input, N, limit, trainstage, fun_spec, lin_diff):
+        uv, pose, K, hdr = input["uv"][0], input["pose"][0], input["intrinsics"][0], input.get("hdr_shift")
+        mask = input["object_mask"].reshape(-1)
+        hook = self.get_sg_render
+        q = self.__dict__.get("_pending")
+        if q is not None:
+            psrc, ksrc = q.sig[-2:]
+            same = (not q.closed and N <= q.chunk and q.sig[:6] == (trainstage, fun_spec, lin_diff, hdr is None, uv.device, hook)
+                    and (psrc == (id(input["pose"]), input["pose"]._version) or torch.equal(pose, q.pose))
+                    and (ksrc == (id(input["intrinsics"]), input["intrinsics"]._version) or torch.equal(K, q.K)))
+            if not same:
+                q.flush()
+                q = None
+        if q is None:
+            sig = (trainstage, fun_spec, lin_diff, hdr is None, uv.device, hook, (id(input["pose"]), input["pose"]._version),
+                   (id(input["intrinsics"]), input["intrinsics"]._version))
+            spec = deferred.output_spec(trainstage, self.indirect_illum_network.num_lgt_sgs, hdr is not None)
+            q = deferred.ChunkQueue(self, sig, spec, N, limit, pose, K, hdr is not None, uv.device,
+                                    (trainstage, fun_spec, lin_diff, None, None, None))
+            self.__dict__["_pending"] = q
+        slot = q.add(uv, mask, hdr)
+        given = {"object_mask": mask}
+        if hdr is not None:
+            given["hdr_shift"] = hdr
+        out = deferred.ChunkOutputs(q, slot, N, uv.device, given)
+        if q.closed:                       # full (or ended by a short chunk): run it now, the next chunk starts a new pass
+            q.flush()
+        return out
+
+    def flush(self):
+        """Run the recorded chunk forwards, if any (deferred_chunks > 0)."""
+        q = self.__dict__.get("_pending")
+        if q is not None:
+            q.flush()
+
+    def train(self, mode=True):
+        deferred.flush_all()
+        return super().train(mode)
 
     def render_chunks(self, uv, pose, K, hdr_shift, chunk=1024, trainstage="Material", draws=None, stats=None):
         """uv [N,2] for any number of consecutive `chunk`-pixel chunks (chunk <= 1024); pose [4,4], K [3,3];
         hdr_shift [N,1].  draws: dict as synth.pbr_draws but with 'dvis_*' stacked [C,L,32]."""
         forward_only_guard(self)
+        self.flush()
         N = uv.shape[0]
         mask = torch.ones(N, dtype=torch.bool, device=uv.device)
         return self._render(uv, pose, K, mask, hdr_shift, chunk, trainstage, False, False, draws, stats, None)
@@ -226,10 +272,15 @@ class IDRNetwork(nn.Module):
             if (getattr(self.get_sg_render, "__func__", None) is IDRNetwork.get_sg_render
                     or getattr(self.get_sg_render, "robir_native", False)):
                 kw = dict(draws=draws, chunk_id=cid, n_chunks=n_chunks, stats=stats)   # our own hooks understand these
-            r = self.get_sg_render(hp, view, sgs_h if hdr_shift is not None else indirect_sgs[idx],
-                                   albedo_ratio=albedo_ratio, fun_spec=fun_spec, lin_diff=lin_diff, train_spec=True,
-                                   indir_integral=int_h if hdr_shift is not None else indirect_integral[idx],
-                                   tex_uv=None, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
+            elif n_chunks > 1:        # a runner's own hook: render_with_all_sg learns the chunk partition from the context
+                sg_render._BATCH_CTX = (cid, n_chunks, n)
+            try:
+                r = self.get_sg_render(hp, view, sgs_h if hdr_shift is not None else indirect_sgs[idx],
+                                       albedo_ratio=albedo_ratio, fun_spec=fun_spec, lin_diff=lin_diff, train_spec=True,
+                                       indir_integral=int_h if hdr_shift is not None else indirect_integral[idx],
+                                       tex_uv=None, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
+            finally:
+                sg_render._BATCH_CTX = None
             for k in out3:
                 v = r[k]
                 out3[k][idx] = v.expand(-1, 3) if v.shape[-1] == 1 else v

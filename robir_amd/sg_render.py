@@ -92,7 +92,15 @@ def _rand(shape, device):
     return torch.rand(*shape, device=device)
 
 
-def _chunks(chunk_id, n_chunks):
+# The partition of the points at hand into lock-step chunks, for callers that cannot say (a runner's own get_sg_render calls
+# render_with_all_sg with the reference's arguments): set by IDRNetwork._shade around the hook call when it passes the hit
+# points of several chunks at once, so that every chunk keeps its own sample tables and specular minimum.
+_BATCH_CTX = None
+
+
+def _chunks(chunk_id, n_chunks, n=None):
+    if chunk_id is None and _BATCH_CTX is not None and n == _BATCH_CTX[2]:
+        return _BATCH_CTX[0], _BATCH_CTX[1]
     return (None, 1) if chunk_id is None else (chunk_id, int(n_chunks))
 
 
@@ -104,7 +112,7 @@ def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, 
     dev = points.device
     L = lgtSGLobes.shape[0]
     n = points.shape[0]
-    cid, C = _chunks(chunk_id, n_chunks)
+    cid, C = _chunks(chunk_id, n_chunks, n)
     lgt = torch.zeros(L, 7, device=dev)
     lgt[:, :3] = lgtSGLobes
     lgt[:, 3:4] = lgtSGLambdas
@@ -217,7 +225,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
         raise NotImplementedError("multi-view shading is not on the hot path")
     dev = points.device
     n = points.shape[0]
-    cid, C = _chunks(chunk_id, n_chunks)
+    cid, C = _chunks(chunk_id, n_chunks, n)
     draws = draws or {}
     pts = points.float().contiguous()
     nrm = normal.float().contiguous()

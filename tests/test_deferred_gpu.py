@@ -1,0 +1,208 @@
+"""Deferred chunk forwards on the GPU (robir_amd/deferred.py): the reference runners' per-chunk evaluation loop, unchanged, at
+the batched rate -- utils.general.split_input(n_pixels=1024) -> model(s, trainstage='Material') per chunk -> the loop's own
+detach / tone-map / add -> utils.general.merge_output (training/train_pbr.py:248-281, utils/general.py:27-38,55-69) -- and
+bit-equal to IDRNetwork.render_chunks on the same chunks."""
+import time
+import types
+
+import pytest
+import torch
+
+from conftest import record_metric
+from test_runner_hooks_gpu import make_pbr_runner_hook, overlay_model_pkg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from robir_amd import renderer
+    return renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+
+
+@pytest.fixture()
+def deferring(model):
+    model.deferred_chunks = 1024
+    yield model
+    model.flush()
+    model.__dict__.pop("deferred_chunks", None)
+    model.__dict__.pop("get_sg_render", None)
+
+
+def _same(a, b):
+    """Bit-for-bit (rays parallel to an axis carry NaN points in both)."""
+    a, b = a.cpu().contiguous().reshape(-1), b.cpu().contiguous().reshape(-1)
+    return a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+def _view(dev, h, w):
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(h, w)
+    total = h * w
+    mi = {"uv": torch.from_numpy(uv).to(dev)[None], "pose": torch.from_numpy(pose).to(dev)[None],
+          "intrinsics": torch.from_numpy(K).to(dev)[None], "object_mask": torch.ones(1, total, dtype=torch.bool, device=dev)}
+    return mi, total
+
+
+def split_input(model_input, total_pixels, n_pixels=1024):          # utils/general.py:27-38
+    split = []
+    for indx in torch.split(torch.arange(total_pixels, device=model_input["uv"].device), n_pixels, dim=0):
+        data = model_input.copy()
+        data["uv"] = torch.index_select(model_input["uv"], 1, indx)
+        data["object_mask"] = torch.index_select(model_input["object_mask"], 1, indx)
+        split.append(data)
+    return split
+
+
+def merge_output(res, total_pixels, batch_size=1):                   # utils/general.py:55-69
+    out = {}
+    for entry in res[0]:
+        if len(res[0][entry].shape) == 1:
+            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, 1) for r in res], 1).reshape(batch_size * total_pixels)
+        else:
+            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, r[entry].shape[-1]) for r in res],
+                                   1).reshape(batch_size * total_pixels, -1)
+    return out
+
+
+def plot_loop(model, split, total):
+    """The body of PBRTrainRunner.plot_to_disk's loop, train_pbr.py:259-281."""
+    res = []
+    for s in split:
+        s["hdr_shift"] = model.gamma.hdr_shift.as_input().expand(s["uv"].shape[1], 1)
+        out = model(s, trainstage="Material", lin_diff=False, fun_spec=False, train_spec=True)
+        indir_rgb = out["indir_rgb"]
+        roughness = out["roughness"][..., 0:1]
+        diffuse_albedo = out["diffuse_albedo"]
+        sg_rgb = out["sg_rgb"]
+        pred_rgb = sg_rgb + indir_rgb
+        sg_rgb = model.gamma.hdr_shift.hdr2ldr(sg_rgb)
+        indir_rgb = model.gamma.hdr_shift.hdr2ldr(indir_rgb)
+        pred_rgb = model.gamma.hdr_shift.hdr2ldr(pred_rgb)
+        res.append({"roughness": roughness.detach().expand(diffuse_albedo.shape), "diffuse_albedo": diffuse_albedo.detach(),
+                    "indir_rgb": indir_rgb.detach(), "sg_rgb": sg_rgb.detach(), "pred_rgb": pred_rgb.detach(),
+                    "vis_shadow": out["vis_shadow"].detach(), "mask": out["network_object_mask"].detach()})
+    return merge_output(res, total)
+
+
+def _batched(model, mi, total, seed):
+    tm = model.gamma.hdr_shift
+    torch.manual_seed(seed)
+    o = model.render_chunks(mi["uv"][0], mi["pose"][0], mi["intrinsics"][0], tm.as_input().expand(total, 1).contiguous(),
+                            chunk=1024, trainstage="Material")
+    return {"roughness": o["roughness"][..., 0:1].expand(total, 3), "diffuse_albedo": o["diffuse_albedo"],
+            "indir_rgb": tm.hdr2ldr(o["indir_rgb"]), "sg_rgb": tm.hdr2ldr(o["sg_rgb"]),
+            "pred_rgb": tm.hdr2ldr(o["sg_rgb"] + o["indir_rgb"]), "vis_shadow": o["vis_shadow"], "mask": o["network_object_mask"]}
+
+
+@pytest.mark.parametrize("hook", ["native", "runner"])
+def test_runner_loop_800x800_deferred_is_render_chunks(dev, deferring, overlay_model_pkg, hook):
+    from robir_amd import deferred
+    model = deferring
+    mi, total = _view(dev, 800, 800)
+    if hook == "runner":                         # the hook the unchanged runner installs (train_pbr.py:413)
+        model.get_sg_render = make_pbr_runner_hook(types.SimpleNamespace(model=model, train_spec=True, no_normal=False,
+                                                                         is_training=False))
+    want = _batched(model, mi, total, 5)
+    best = 1e9
+    for rep in range(3):
+        split = split_input(mi, total)
+        torch.cuda.synchronize()
+        torch.manual_seed(5)
+        t0 = time.time()
+        merged = plot_loop(model, split, total)
+        assert all(deferred.is_deferred(v) for v in merged.values())      # nothing has run yet
+        got = {k: v.cpu() for k, v in merged.items()}                     # the plotting code reads the numbers
+        torch.cuda.synchronize()
+        best = min(best, time.time() - t0)
+    for k in want:
+        assert torch.equal(got[k], want[k].cpu()), k
+    rate = total / best
+    record_metric(f"deferred/runner_loop_800x800/{hook}_hook", rays_per_s=rate, seconds=best)
+    assert rate >= 5.0e5, rate
+    assert model.__dict__.get("_pending") is None
+
+
+def test_deferred_single_chunk_equals_immediate_forward(dev, deferring):
+    model = deferring
+    mi, total = _view(dev, 64, 64)
+    s = split_input(mi, total)[1]
+    s["hdr_shift"] = torch.full((1024, 1), 0.5, device=dev)
+    torch.manual_seed(3)
+    lazy = model(s, trainstage="Material")
+    model.flush()
+    model.deferred_chunks = 0
+    torch.manual_seed(3)
+    now = model(s, trainstage="Material")
+    assert set(lazy) == set(now)
+    for k in now:
+        assert _same(lazy[k], now[k]), k
+
+
+def test_short_last_chunk_stage_change_and_limit(dev, deferring):
+    from robir_amd import deferred
+    model = deferring
+    mi, total = _view(dev, 100, 100)             # 9 full chunks + 784 rays
+    split = split_input(mi, total)
+    assert split[-1]["uv"].shape[1] == 784
+    hdr = lambda s: torch.full((s["uv"].shape[1], 1), 0.5, device=dev)
+    torch.manual_seed(9)
+    outs = []
+    for s in split:
+        s["hdr_shift"] = hdr(s)
+        outs.append(model(s, trainstage="Material"))
+    assert model.__dict__.get("_pending") is None        # the short chunk closed the pass and ran it
+    albedo = torch.cat([o["diffuse_albedo"] for o in outs]).cpu()
+    torch.manual_seed(9)
+    ref = model.render_chunks(mi["uv"][0], mi["pose"][0], mi["intrinsics"][0], torch.full((total, 1), 0.5, device=dev))
+    assert torch.equal(albedo, ref["diffuse_albedo"].cpu())
+    assert torch.equal(torch.cat([o["sg_rgb"] for o in outs]).cpu(), ref["sg_rgb"].cpu())
+    # a different stage starts its own pass and runs the pending one first; so does reaching the limit
+    model.deferred_chunks = 4
+    a = model(split[0], trainstage="Material")
+    q0 = model._pending
+    b = model(split[1], trainstage="Illum")
+    assert q0.result is not None and model._pending is not q0 and "indirect_sgs" in b and "sg_rgb" not in b
+    assert b["indirect_sgs"].shape == (1024, model.indirect_illum_network.num_lgt_sgs, 7)
+    tr = model.trace_radiance(b, nsamp=4)                 # reads the placeholders through this library's kernels
+    assert tr["trace_radiance"].shape == (1024, 4, 3) and bool(torch.isfinite(tr["gt_integral"]).all())
+    model.flush()
+    many = [model(s, trainstage="Material") for s in split[:9]]
+    assert [o._q for o in many].count(many[0]._q) == 4 and many[8]._q is model._pending and many[4]._q.result is not None
+    assert torch.equal(torch.cat([o["diffuse_albedo"] for o in many]).cpu(), ref["diffuse_albedo"][:9 * 1024].cpu())
+    assert torch.equal(a["network_object_mask"].cpu(), ref["network_object_mask"][:1024].cpu())
+    assert not deferred._LIVE or all(q.result is None for q in deferred._LIVE)
+
+
+def test_pending_chunks_and_changed_weights(dev, deferring):
+    model = deferring
+    mi, total = _view(dev, 64, 64)
+    split = split_input(mi, total)
+    for s in split:
+        s["hdr_shift"] = torch.full((1024, 1), 0.5, device=dev)
+    out = model(split[0], trainstage="Material")
+    p = model.envmap_material_network.lgtSGs
+    keep = p.detach().clone()
+    p.mul_(1.0)                                  # an in-place update of a parameter while a chunk is pending
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        out["sg_rgb"].cpu()
+    p.copy_(keep)
+    out = model(split[0], trainstage="Material")
+    model.train()                                # train() / eval() run what is pending
+    assert out._q.result is not None
+    model.eval()
+    out = model(split[1], trainstage="Material")
+    q = out._q
+    torch.manual_seed(77)                        # re-seeding in between does not change what the recorded pass draws ...
+    v1 = out["vis_shadow"].cpu()
+    assert q.result is not None
+    torch.manual_seed(77)
+    w1 = torch.rand(4, device=dev)               # ... and the pass does not consume the new stream
+    torch.manual_seed(77)
+    assert torch.equal(torch.rand(4, device=dev), w1)
+    assert bool(torch.isfinite(v1).all())
