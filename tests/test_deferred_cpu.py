@@ -59,6 +59,13 @@ def test_recorded_functions_run_once_when_numbers_are_needed():
     assert len(calls) == 2
     mixed = torch.ones(4, 3) + a                 # ordinary tensor first: still recorded
     assert is_deferred(mixed) and torch.equal(materialize(mixed), v + 1)
+    # arithmetic: same-shape float32 / Python numbers take the shortcut, broadcasting and type promotion the meta tensors
+    for r, want in ((a * 2.0, v * 2), (1.0 - a, 1 - v), (a / torch.full((4, 3), 2.0), v / 2), (a + torch.ones(3), v + 1),
+                    (a + torch.ones(4, 3, dtype=torch.float64), v.double() + 1), (torch.maximum(a, b), 2 * v),
+                    (a * torch.tensor(3.0), v * 3), (a > 4.0, v > 4)):
+        assert is_deferred(r) and r.shape == want.shape and r.dtype == want.dtype
+        got = materialize(r)
+        assert got.dtype == want.dtype and torch.equal(got, want)
 
 
 def test_what_forces_the_numbers():
