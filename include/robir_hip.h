@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 2
+#define RB_ABI_VERSION 3
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -98,6 +98,20 @@ int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_l
  * persistent (n_workgroups <= 0: one per compute unit). */
 int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
                     float* out0, float* grad, int n_workgroups, rb_stream_t stream);
+/* All 257 outputs and the input gradient of the signed distance in REVERSE mode (csrc/sdf_back.hip; model/neus_model.py:440-452
+ * is autograd too): one value pass (rb_sdf_mlp_ring's kernel, which also stores sigmoid(100 z) of every hidden pre-activation)
+ * and one row vector per point back through the transposed layers -- twice the matrix work of the values instead of the four
+ * times of the forward-mode rows of mode 3; same results to fp32 rounding.
+ *   X [M,64] rb_feat_pe10 rows (value rows only);  Wp as rb_sdf_mlp_ring;  out0 [M,257], grad [M,3] as mode 3;
+ *   Wb   the transposed layers packed by rb_pack_layer_h3 in the order W7^T, W6^T, W5^T, W4^T (320 x 256: rows 0..192 the
+ *        columns of layer 3's outputs, 208..270 those of the skip features, the rest zero), W3^T (256 x 224), W2^T, W1^T,
+ *        W0^T (64 x 256), followed by >= 2 KB of padding;  w8row [256] = row 0 of layer 8 (the distance output);
+ *   scratch  rb_sdf_value_grad_scratch_floats(M) floats (8.5 KB per point: the sigmoid blob and the feature gradients).
+ * Callers bound the scratch by evaluating large M in slabs. */
+long rb_sdf_value_grad_scratch_floats(long M);
+int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
+                      float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
+                      rb_stream_t stream);
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).

@@ -42,7 +42,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.rb_last_error.restype = ctypes.c_char_p
         _lib.rb_packed_layer_floats.restype = ctypes.c_long
-        if _lib.rb_abi_version() != 2:
+        _lib.rb_sdf_value_grad_scratch_floats.restype = ctypes.c_long
+        if _lib.rb_abi_version() != 3:
             raise RobirHipError("librobir_hip.so ABI version mismatch")
     return _lib
 

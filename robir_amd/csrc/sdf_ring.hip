@@ -57,11 +57,24 @@ __device__ __forceinline__ void sr_dma16(const f4* gbase_uniform, unsigned lane_
 __device__ __forceinline__ void sr_wait(int allowed) {      // counted wait; `allowed` folds to a constant after unrolling
   if (allowed <= 1) {
     asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  } else if (allowed <= 3) {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   } else if (allowed <= 4) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
+  } else if (allowed <= 5) {
     asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  } else if (allowed <= 6) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   }
+}
+// 16 B per lane to uniform base + lane offset (scalar base: no per-store 64-bit vector address, which the compiler would
+// otherwise precompute for every store of a layer and spill)
+__device__ __forceinline__ void sr_store16(const f4* base_uniform, unsigned lane_byte_off, f4 v) {
+  // a store of more than 64 bits reads its data registers late: a VALU write to them needs wait states in between
+  // (cdna ISA, manually inserted wait states) -- the compiler adds them for its own stores, not after inline assembly
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(lane_byte_off), "v"(v), "s"(base_uniform) : "memory");
 }
 __device__ __forceinline__ float sr_quad0(float v) {        // value of lane (lane & ~3) of the quad: DPP quad_perm [0,0,0,0]
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x00, 0xf, 0xf, true));
@@ -72,13 +85,18 @@ struct SrAcc {
 };
 
 // MODE: bit 0 = all 257 outputs (else the signed distance only), bit 1 = forward-mode input gradient (rows 4m + {0,1,2,3} =
-// value + three tangent columns of point m), as rb_sdf_mlp_h3.
+// value + three tangent columns of point m), as rb_sdf_mlp_h3; bit 2 (with bit 0, without bit 1) = also store sigmoid(100 z) of
+// every hidden pre-activation for the reverse-mode gradient pass (sdf_back.hip): `sig` [rounds][125 chunks][2 tiles][256 lanes]
+// float4 -- lane-local, in the order the epilogue produces it, 16 B per lane and chunk.
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X, long MR, const f4* __restrict__ Wp, float us,
                                                       float out_scale, float grad_scale, float* __restrict__ out0,
-                                                      float* __restrict__ grad, unsigned* __restrict__ range_word) {
-  constexpr bool JVP = MODE >= 2;
+                                                      float* __restrict__ grad, unsigned* __restrict__ range_word,
+                                                      f4* __restrict__ sig) {
+  constexpr bool JVP = (MODE & 2) != 0;
   constexpr bool FULL = (MODE & 1) != 0;
+  constexpr bool STORE = (MODE & 4) != 0;
+  static_assert(!STORE || (FULL && !JVP), "sigmoid store: value rows, all outputs");
   constexpr int LAST = FULL ? 17 : 1;                 // chunks of the output layer (272 = 257 padded, or the sdf row's chunk)
   constexpr int NCHUNK = sr_cbase(8, LAST) + LAST;    // 142 / 126
   constexpr float AS = 64.0f, TS = 0.25f;             // operand lifts of value rows / tangent rows (powers of two)
@@ -150,10 +168,18 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
   };
   // activation of two pre-activations of tile t -> lifted operand pair (softplus on value rows, z' * sigmoid(100 z) on
   // tangent rows with z taken from the quad's value lane), `sa` = output scale x operand lift
-  auto act_pair = [&](float r0, float r1, float sa, unsigned& hi, unsigned& lo) {
+  f4 sstage = {0.f, 0.f, 0.f, 0.f};   // STORE: the four sigmoids of a (chunk, tile) on their way to `sig`
+  f4* sig_round = sig;                // ... of the current round
+  auto act_pair = [&](float r0, float r1, float sa, unsigned& hi, unsigned& lo, int q = 0) {
     const float z0 = r0 * zs, z1 = r1 * zs;
     float v0, v1;
-    if constexpr (JVP) {
+    if constexpr (STORE) {
+      float s0, s1;
+      v0 = softplus100<false>(z0, &s0);
+      v1 = softplus100<false>(z1, &s1);
+      sstage[2 * q] = s0;
+      sstage[2 * q + 1] = s1;
+    } else if constexpr (JVP) {
       float s0, s1;
       const float p0 = softplus100<false>(sr_quad0(z0), &s0), p1 = softplus100<false>(sr_quad0(z1), &s1);
       v0 = is_val ? p0 : z0 * s0;
@@ -208,15 +234,22 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     }
   };
   // piece (tile, register pair) of hidden chunk jb -> next layer's k-block jb/2, registers 2*(jb&1)+q
-  auto hidden_piece = [&](const SrAcc& acc, int jb, int piece, float sa) {
+  auto hidden_piece = [&](const SrAcc& acc, int jb, int piece, float sa, int cb) {
     const int t = piece >> 1, q = piece & 1;
     if constexpr (JVP) {
       if (q == 0) jvp_stage_a(acc, t); else jvp_stage_b(jb, t, sa);
     } else {
       unsigned hi, lo;
-      act_pair(acc.a[t][2 * q], acc.a[t][2 * q + 1], sa, hi, lo);
+      act_pair(acc.a[t][2 * q], acc.a[t][2 * q + 1], sa, hi, lo, q);
       yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
       yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
+      if constexpr (STORE) {
+        if (q == 1) {
+          const f4* base = sig_round;
+          asm volatile("" : "+s"(base));            // one scalar add per store, not 32 precomputed addresses per layer
+          sr_store16(base + ((cb + jb) * 2 + t) * 256, lane_off, sstage);
+        }
+      }
     }
   };
   // piece of output chunk jb: stores
@@ -276,7 +309,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
       acc.a[1] = bias;
       // chunk jb+1 must have landed; only the copy of chunk jb+2 (issued during chunk jb-1) may still be in flight.  Anything
       // else younger (feature prefetch, output stores) is not credited: waiting for it too is safe, and rare
-      sr_wait(jb + 2 < NCH ? P : (jb + 2 == NCH ? PF0 : PF1));
+      // (STORE: the two sigmoid stores of the previous iteration's epilogue are younger than its copy as well -- vmcnt counts
+      // stores.  Not credited where they are not certain: the first two chunks of layer 0 follow the output layer, whose
+      // stores depend on the row count)
+      sr_wait((jb + 2 < NCH ? P : (jb + 2 == NCH ? PF0 : PF1)) + (STORE && EPI != 2 && (jb >= 2 || K != 64) ? 2 : 0));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int KBn = (jb + 1 < NCH ? K : KF) / 32;             // next chunk: its fragments roll into wreg
@@ -295,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
 #pragma unroll
           for (int pc = 0; pc < 4; ++pc)
             if ((pc * KB) / 4 == kb) {
-              if constexpr (EPI == 2) output_piece(prev, jb - 1, pc); else hidden_piece(prev, jb - 1, pc, sa);
+              if constexpr (EPI == 2) output_piece(prev, jb - 1, pc); else hidden_piece(prev, jb - 1, pc, sa, cb);
             }
         }
 #pragma unroll
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     }
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) {
-      if constexpr (EPI == 2) output_piece(prev, NCH - 1, pc); else hidden_piece(prev, NCH - 1, pc, sa);
+      if constexpr (EPI == 2) output_piece(prev, NCH - 1, pc); else hidden_piece(prev, NCH - 1, pc, sa, cb);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -354,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
   for (; round < nrounds; round += gridDim.x) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) rrow[t] = round * 128 + wave * 32 + t * 16 + (lane & 15);
+    if constexpr (STORE) sig_round = sig + round * (125L * 2 * 256);
     // ---- input features -> operands of layer 0 and the skip operands of layer 4
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -485,10 +522,20 @@ extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
   switch (mode) {
-    case 0: hipLaunchKernelGGL(k_sdf_ring<0>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw); break;
-    case 1: hipLaunchKernelGGL(k_sdf_ring<1>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw); break;
-    case 2: hipLaunchKernelGGL(k_sdf_ring<2>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw); break;
-    default: hipLaunchKernelGGL(k_sdf_ring<3>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw); break;
+    case 0: hipLaunchKernelGGL(k_sdf_ring<0>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
+    case 1: hipLaunchKernelGGL(k_sdf_ring<1>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
+    case 2: hipLaunchKernelGGL(k_sdf_ring<2>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
+    default: hipLaunchKernelGGL(k_sdf_ring<3>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
   }
   return check_launch("k_sdf_ring");
 }
+
+namespace rb {
+// forward half of the reverse-mode gradient (sdf_back.hip): all outputs of M points + the sigmoid blob
+int launch_sdf_ring_store(const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
+                          hipStream_t s) {
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
+  hipLaunchKernelGGL(k_sdf_ring<5>, dim3(grid), dim3(256), 0, s, X, M, W, us, out_scale, 0.0f, out0, nullptr, rw, sig);
+  return check_launch("k_sdf_ring<5>");
+}
+}  // namespace rb

@@ -440,6 +440,10 @@ class SDFNetwork(nn.Module):
         return self._packed.get("full_h3" if full else "sdf_h3", self,
                                 lambda sd: packing.pack_sdf_h3(self._sd(sd), _dev(self), full=full))
 
+    def packed_back_h3(self):
+        assert self.kind == "neus"
+        return self._packed.get("back_h3", self, lambda sd: packing.pack_sdf_back_h3(self._sd(sd), _dev(self)))
+
     def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False, precise=False):
         """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
         precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
@@ -449,6 +453,11 @@ class SDFNetwork(nn.Module):
         M = x.shape[0]
         assert not (precise and full)
         mode = (1 if full else 0) + (2 if grad else 0) + (4 if precise else 0)
+        if (mode == 3 and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_GRAD == "reverse"
+                and M >= ops.SDF_GRAD_MIN_POINTS):
+            # values once + one row vector back through the transposed layers, instead of three tangent rows per point
+            return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
+                                      out_scale)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
         if not precise and mlp_precision() == "f16x3":
             return ops.sdf_mlp_h3(X, M, self.packed_h3(full), mode, packing.H3_SCALE_LOG2, out_scale, out_scale * in_scale)

@@ -118,6 +118,31 @@ def sdf_mlp_h3(X, M, blob, mode, scale_log2, out_scale=1.0, grad_scale=1.0):
     return out0, grad
 
 
+SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)
+SDF_GRAD_MIN_POINTS = 4096        # below this a launch is latency-bound and the two-kernel reverse form does not pay
+SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB of scratch per point)
+_sdf_grad_scratch = {}
+
+
+def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
+    """All 257 outputs + d sdf / dx by the reverse-mode pass: x [M,3] -> out [M,257], grad [M,3]."""
+    wb, w8 = back
+    out0 = torch.empty(M, 257, dtype=torch.float32, device=x.device)
+    grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    slab = min(M, SDF_GRAD_SLAB)
+    need = int(_lib.lib().rb_sdf_value_grad_scratch_floats(c_long(slab)))
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    scratch = _sdf_grad_scratch.get(key)
+    if scratch is None or scratch.numel() < need:
+        scratch = _sdf_grad_scratch[key] = torch.empty(need, dtype=torch.float32, device=x.device)
+    for a in range(0, M, slab):
+        n = min(slab, M - a)
+        X = feat_pe10(x[a:a + n], scale=in_scale)
+        call("rb_sdf_value_grad", ptr(X), c_long(n), ptr(blob), ptr(wb), ptr(w8), c_int(scale_log2), c_float(out_scale),
+             c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), c_int(0), stream_ptr())
+    return out0, grad
+
+
 def color_mlp(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 3, dtype=torch.float32, device=X.device)

@@ -148,6 +148,101 @@ def test_sdf_ring_kernel_many_rounds_and_ragged_sizes(dev, synth_weights, mode, 
     ops.range_check(sync=True)
 
 
+def _trained_like(synth_weights, seed):
+    """The geometric initialisation zeroes the positional-encoding columns of layer 0 and of the skip connection (layer 4)
+    and keeps every hidden weight matrix near-diagonal in distribution: a gradient path that only a trained net exercises --
+    the Jacobian of the encoding, the skip connection's share -- needs weights away from it."""
+    from robir_amd.packing import SDF
+    g = np.random.Generator(np.random.PCG64(seed))
+    sd = dict(synth_weights)
+    for l, cols, amp in ((0, slice(3, 63), 0.08), (4, slice(193, 256), 0.05)):
+        w = np.array(sd[SDF + "lin%d.weight_v" % l], dtype=np.float32, copy=True)
+        damp = 1.0 / (1.0 + np.arange(w[:, cols].shape[1]) // 6)          # high frequencies weaker, like trained nets
+        w[:, cols] += (amp * g.standard_normal(w[:, cols].shape) * damp[None, :]).astype(np.float32)
+        sd[SDF + "lin%d.weight_v" % l] = w
+    for l in (1, 2, 3, 5, 6, 7):
+        w = np.array(sd[SDF + "lin%d.weight_v" % l], dtype=np.float32, copy=True)
+        sd[SDF + "lin%d.weight_v" % l] = w + (0.02 * g.standard_normal(w.shape)).astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("weights", ["init", "trained_like"])
+def test_sdf_value_grad_reverse_mode(dev, pts_dirs, synth_weights, weights, monkeypatch):
+    """rb_sdf_value_grad (values once + one row vector back through the transposed layers) against the forward-mode rows of
+    mode 3, the exact f32-MFMA kernel and the oracle's autograd -- with the synthetic initialisation and with weights that
+    make the encoding's Jacobian and the skip connection carry gradient."""
+    from robir_amd import ops, packing
+    from robir_oracle import nets
+    sd = synth_weights if weights == "init" else _trained_like(synth_weights, 5)
+    osd = nets.as_torch(sd)
+    pts, _ = pts_dirs
+    x = pts.to(dev)
+    M = x.shape[0]
+    h3 = packing.pack_sdf_h3(sd, dev, full=True)
+    back = packing.pack_sdf_back_h3(sd, dev)
+    out, grad = ops.sdf_value_grad(x, M, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+    X4 = ops.feat_pe10(x, scale=2.0, jvp=True)
+    f0, fg = ops.sdf_mlp_h3(X4, M, h3, 3, packing.H3_SCALE_LOG2, out_scale=0.5, grad_scale=1.0)
+    e0, eg = ops.sdf_mlp(X4, M, packing.pack_sdf(sd, dev, full=True), 3, out_scale=0.5, grad_scale=1.0)
+    ops.range_check(sync=True)
+    assert torch.equal(out, f0)                                   # the value pass is the same kernel arithmetic
+    ref_g = nets.implicit_gradient(osd, pts)
+    assert float(ref_g.abs().max()) > 0.5
+    if weights == "trained_like":                                 # the encoding's columns do carry gradient now
+        w0 = torch.from_numpy(sd[packing.SDF + "lin0.weight_v"])
+        assert float(w0[:, 3:].abs().max()) > 0.05
+    for name, other, tol in (("forward-mode", fg, 2e-5), ("exact fp32", eg, 2e-5)):
+        assert rel_err(grad.cpu(), other.cpu()) <= tol, (name, rel_err(grad.cpu(), other.cpu()))
+    assert rel_err(grad.cpu(), ref_g) <= TOL
+    assert rel_err(out.cpu(), nets.implicit_forward(osd, pts)) <= TOL
+
+
+def test_sdf_value_grad_sizes_slabs_and_repeatability(dev, synth_weights, monkeypatch):
+    """Persistent workgroups over many rounds, ragged last rounds, several slabs through one scratch buffer; and bit-identical
+    results run after run (the sigmoid rows reach the backward kernel by LDS-DMA whose arrival is detected from the data:
+    a row consumed before it landed would show up here as a difference between runs)."""
+    from robir_amd import ops, packing
+    sd = _trained_like(synth_weights, 6)
+    h3 = packing.pack_sdf_h3(sd, dev, full=True)
+    back = packing.pack_sdf_back_h3(sd, dev)
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 127, 129, 4097, 33000, 300001):
+        x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.7).to(dev)
+        out, grad = ops.sdf_value_grad(x, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+        f0, fg = ops.sdf_mlp_h3(ops.feat_pe10(x, scale=2.0, jvp=True), n, h3, 3, packing.H3_SCALE_LOG2, out_scale=0.5,
+                                grad_scale=1.0)
+        assert torch.equal(out, f0), n
+        assert bool(torch.isfinite(grad).all()) and rel_err(grad.cpu(), fg.cpu()) <= 2e-5, (n, rel_err(grad.cpu(), fg.cpu()))
+    monkeypatch.setattr(ops, "SDF_GRAD_SLAB", 70000)              # 300001 points -> five slabs, the last one ragged
+    o2, g2 = ops.sdf_value_grad(x, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+    assert torch.equal(o2, out) and torch.equal(g2, grad)
+    monkeypatch.setattr(ops, "SDF_GRAD_SLAB", 1 << 20)
+    for _ in range(4):
+        o3, g3 = ops.sdf_value_grad(x, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+        assert torch.equal(o3, out) and torch.equal(g3, grad)
+    ops.range_check(sync=True)
+
+
+def test_eval_points_picks_the_reverse_mode_for_large_batches(dev, synth_weights, monkeypatch):
+    from robir_amd import nets, ops, synth
+    model = nets.NeuSModel()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
+    net = model.to(dev).eval().sdf_network
+    g = torch.Generator().manual_seed(3)
+    x = ((torch.rand(20000, 3, generator=g) - 0.5) * 1.6).to(dev)
+    calls = []
+    real = ops.sdf_value_grad
+    monkeypatch.setattr(ops, "sdf_value_grad", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    o_r, g_r = net.eval_points(x, 2.0, 0.5, full=True, grad=True)
+    assert calls == [1]
+    net.eval_points(x[:1000], 2.0, 0.5, full=True, grad=True)    # small batches keep the forward-mode rows
+    net.eval_points(x, 2.0, 0.5, full=False, grad=True)          # so does the distance-only form
+    assert calls == [1]
+    monkeypatch.setattr(ops, "SDF_GRAD", "forward")
+    o_f, g_f = net.eval_points(x, 2.0, 0.5, full=True, grad=True)
+    assert calls == [1] and torch.equal(o_r, o_f) and rel_err(g_r.cpu(), g_f.cpu()) <= 2e-5
+
+
 def test_sdf_golden(dev, synth_weights):
     from robir_amd import ops, packing
     g = load_golden("nets")
