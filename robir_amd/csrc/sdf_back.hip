@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
   auto hidden_piece = [&](const SbAcc& acc, int jb, int piece, float sa, int first) {
     const int t = piece >> 1, q = piece & 1;
     if (q == 0) {
-      volatile f4* slot = &sstg[(first + jb) & (SB_SS - 1)][t][tid];
+      // (an LDS-space pointer: through a generic one the re-read would be a FLAT load, which counts in vmcnt too and makes the
+      // compiler drain the whole copy queue at every check)
+      typedef volatile __attribute__((address_space(3))) f4 lds_f4;
+      lds_f4* slot = (lds_f4*)&sstg[(first + jb) & (SB_SS - 1)][t][tid];
       f4 s = *slot;
       while (__builtin_amdgcn_ballot_w64(!(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])) >= 0.0f)) != 0ull) {
 #ifdef SB_DEBUG
