@@ -309,10 +309,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
       acc.a[1] = bias;
       // chunk jb+1 must have landed; only the copy of chunk jb+2 (issued during chunk jb-1) may still be in flight.  Anything
       // else younger (feature prefetch, output stores) is not credited: waiting for it too is safe, and rare
-      // (STORE: the two sigmoid stores of the previous iteration's epilogue are younger than its copy as well -- vmcnt counts
-      // stores.  Not credited where they are not certain: the first two chunks of layer 0 follow the output layer, whose
-      // stores depend on the row count)
-      sr_wait((jb + 2 < NCH ? P : (jb + 2 == NCH ? PF0 : PF1)) + (STORE && EPI != 2 && (jb >= 2 || K != 64) ? 2 : 0));
+      // (STORE: the sigmoid stores of the previous iteration's epilogue sit in that window too.  They are not credited: LDS-DMA
+      // rows and stores do not retire in order with each other (sdf_back.hip), and a store that retired early must not stand
+      // in for a row -- at worst this waits for two rows more than necessary)
+      sr_wait(jb + 2 < NCH ? P : (jb + 2 == NCH ? PF0 : PF1));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int KBn = (jb + 1 < NCH ? K : KF) / 32;             // next chunk: its fragments roll into wreg
