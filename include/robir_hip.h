@@ -119,6 +119,12 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);
 /* Split-precision (f16x3) form: Wp = the five layers packed by rb_pack_layer_h3 (first layer k_pad 320, same permutation). */
 int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
+/* The same net reading its 304 input columns from two places: 0..255 = feat[i*feat_stride + 0..255] * feat_scale (the SDF net's
+ * output rows; 4-byte alignment suffices), 256..303 = tail[i*48 + 0..47] written by rb_feat_color_tail ([x*x_scale | PE4(view) |
+ * normal | 0 x15]) -- no assembled [M,304] rows.  Results equal rb_feat_color + rb_color_mlp_h3 bit for bit. */
+int rb_feat_color_tail(const float* x, float x_scale, const float* view, const float* normal, long M, float* tail, rb_stream_t stream);
+int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, const float* tail, long M, const float* Wp,
+                        int scale_log2, float* rgb, rb_stream_t stream);
 /* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
  * Wp packed [64->512, 512->512 x3, 512->144]. */
 /* Split-precision (f16x3) form of rb_illum_mlp (encoder = 0, raw[M,144]) and rb_ae_encode (encoder = 1, raw_latent[M,32]):

@@ -252,6 +252,27 @@ __global__ void k_feat_color(const float* __restrict__ x, float x_scale, const f
   }
 }
 
+// T[M,48] = columns 256..303 of the row above: [x*x_scale (3) | PE4(view) (27) | normal (3) | 0 x15] (rb_color_mlp_h3_two)
+__global__ void k_feat_color_tail(const float* __restrict__ x, float x_scale, const float* __restrict__ view,
+                                  const float* __restrict__ normal, long M, float* __restrict__ T) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  float row[48];
+  float v[3] = {view[3 * i], view[3 * i + 1], view[3 * i + 2]};
+  row[0] = x[3 * i] * x_scale;
+  row[1] = x[3 * i + 1] * x_scale;
+  row[2] = x[3 * i + 2] * x_scale;
+  write_pe<4>(v, row + 3);
+  row[30] = normal[3 * i];
+  row[31] = normal[3 * i + 1];
+  row[32] = normal[3 * i + 2];
+#pragma unroll
+  for (int k = 33; k < 48; ++k) row[k] = 0.f;
+  f4* dst = reinterpret_cast<f4*>(T + i * 48);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) dst[k] = f4{row[4 * k], row[4 * k + 1], row[4 * k + 2], row[4 * k + 3]};
+}
+
 // =====================================================================================================
 // Kernels.  All: 256 threads (4 waves), 1 wave per SIMD, rows_per_block = 64*NT.
 // =====================================================================================================
@@ -754,6 +775,13 @@ int rb_feat_color(const float* x, float x_scale, const float* view, const float*
   hipLaunchKernelGGL(k_feat_color, dim3((unsigned)(M < RB_MAX_BLOCKS ? M : RB_MAX_BLOCKS)), dim3(256), 0, (hipStream_t)stream, x, x_scale, view, normal, feat,
                      feat_stride, feat_scale, M, X);
   return check_launch("k_feat_color");
+}
+
+int rb_feat_color_tail(const float* x, float x_scale, const float* view, const float* normal, long M, float* T, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && view && normal && T, "null pointer");
+  hipLaunchKernelGGL(k_feat_color_tail, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_scale, view, normal, M, T);
+  return check_launch("k_feat_color_tail");
 }
 
 int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream) {

@@ -168,8 +168,14 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
 
 // Split-precision (f16x3) form of the colour network: Wp from rb_pack_layer_h3 with k_pad 320 (same column permutation),
 // 256 x3, 256; operands lifted by 2^4 before the hi/lo split.
-__global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                          float us, float* __restrict__ rgb, unsigned* __restrict__ range_word) {
+// TWO: the 304 input columns come from two places -- columns 0..255 straight from the SDF net's output rows (feat, any row stride,
+// 4-byte aligned: rows of 257 floats), columns 256..303 from a 48-float tail row [x | PE4(view) | normal | 0 x15] (rb_feat_color_tail)
+// -- instead of a 1.2 KB row that rb_feat_color first copies together (19 ms of config 2 were that copy).  Same values, same order.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool TWO>
+__global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict__ X, const float* __restrict__ feat, long feat_stride,
+                                                          float feat_scale, long M, const f4* __restrict__ Wp, float us,
+                                                          float* __restrict__ rgb, unsigned* __restrict__ range_word) {
   constexpr float AS = 16.0f;
   __shared__ f4 lds[2 * chunk_f4(320)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,8 +191,31 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict
   unsigned xh[2][8][4], xl[2][8][4];
   {
     float in0[2][76];
-    load_features<304>(X, row0, M, lane, in0[0]);
-    load_features<304>(X, row0 + 16, M, lane, in0[1]);
+    if constexpr (TWO) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const long row = row0 + 16 * t;
+        const bool ok = row < M;
+        const float* pf = feat + (ok ? row : 0) * feat_stride + g * 4;
+        const f4* pt = reinterpret_cast<const f4*>(X + (ok ? row : 0) * 48) + g;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+          const f4u v = ok ? *reinterpret_cast<const f4u*>(pf + kb * 16) : f4u{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in0[t][kb * 4 + r] = v[r] * feat_scale;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+          const f4 v = ok ? pt[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in0[t][64 + kb * 4 + r] = v[r];
+        }
+      }
+    } else {
+      load_features<304>(X, row0, M, lane, in0[0]);
+      load_features<304>(X, row0 + 16, M, lane, in0[1]);
+    }
     unsigned ih[2][10][4], il[2][10][4];
     split_operands<320, 76, 2>(in0, ih, il, AS);
     ws.prime<chunk_f4(320)>(w0);
@@ -383,9 +412,18 @@ int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_l
 int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && rgb, "null pointer");
-  hipLaunchKernelGGL(k_color_mlp_h3, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
+  hipLaunchKernelGGL(k_color_mlp_h3<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, nullptr, 0L, 1.0f, M, (const f4*)Wp,
                      ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
   return check_launch("k_color_mlp_h3");
+}
+
+int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, const float* tail, long M, const float* Wp,
+                        int scale_log2, float* rgb, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(feat && tail && Wp && rgb, "null pointer");
+  hipLaunchKernelGGL(k_color_mlp_h3<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, tail, feat, feat_stride, feat_scale, M,
+                     (const f4*)Wp, ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
+  return check_launch("k_color_mlp_h3<two>");
 }
 
 int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, rb_stream_t stream) {

@@ -526,6 +526,9 @@ class RenderingNetwork(nn.Module):
 
     def forward(self, points, normals, view_dirs, feature_vectors, x_scale=1.0, feat_scale=1.0):
         forward_only_guard(self)
+        if mlp_precision() == "f16x3":
+            return ops.color_mlp_h3_two(points, view_dirs, normals, feature_vectors, self.packed_h3(), packing.H3_SCALE_LOG2,
+                                        x_scale=x_scale, feat_scale=feat_scale)
         X = ops.feat_color(points.float().contiguous(), view_dirs.float().contiguous(), normals.float().contiguous(),
                            feature_vectors, x_scale=x_scale, feat_scale=feat_scale)
         if mlp_precision() == "f16x3":

@@ -71,6 +71,19 @@ def feat_color(x, view, normal, feat, x_scale=1.0, feat_scale=1.0):
     return X
 
 
+def color_mlp_h3_two(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_scale=1.0):
+    """feat_color + color_mlp_h3 without the assembled [M,304] rows: the 256 feature columns are read where they are."""
+    x, view, normal = _f32(x), _f32(view), _f32(normal)
+    assert feat.dtype == torch.float32 and feat.stride(-1) == 1
+    M = x.shape[0]
+    tail = torch.empty(M, 48, dtype=torch.float32, device=x.device)
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    call("rb_feat_color_tail", ptr(x), c_float(x_scale), ptr(view), ptr(normal), c_long(M), ptr(tail), stream_ptr())
+    call("rb_color_mlp_h3_two", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(tail), c_long(M),
+         ptr(blob), c_int(scale_log2), ptr(rgb), stream_ptr())
+    return rgb
+
+
 def vis_mlp(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 2, dtype=torch.float32, device=X.device)

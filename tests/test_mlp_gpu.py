@@ -264,6 +264,21 @@ def test_color_mlp(dev, synth_weights):
     assert rel_err(rgb, g["color"]) <= TOL
     rgb3 = ops.color_mlp_h3(X, packing.pack_color_h3(synth_weights, dev), packing.H3_SCALE_LOG2).cpu()
     assert rel_err(rgb3, g["color"]) <= TOL and rel_err(rgb3, rgb) <= 1e-5
+    # the form the renderer uses: no assembled [M,304] rows -- features read in place from the SDF net's 257-float rows
+    two = ops.color_mlp_h3_two(pts, dirs, nrm, feat[:, 1:], packing.pack_color_h3(synth_weights, dev), packing.H3_SCALE_LOG2,
+                               x_scale=2.0, feat_scale=2.0)
+    assert torch.equal(two.cpu(), rgb3)
+    gen = torch.Generator().manual_seed(4)
+    for n in (1, 127, 129, 70001):
+        p2 = ((torch.rand(n, 3, generator=gen) - 0.5) * 1.6).to(dev)
+        d2 = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+        n2 = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1).to(dev)
+        f2 = torch.randn(n, 257, generator=gen).to(dev) * 0.3
+        a = ops.color_mlp_h3(ops.feat_color(p2, d2, n2, f2[:, 1:], x_scale=2.0, feat_scale=2.0),
+                             packing.pack_color_h3(synth_weights, dev), packing.H3_SCALE_LOG2)
+        b = ops.color_mlp_h3_two(p2, d2, n2, f2[:, 1:], packing.pack_color_h3(synth_weights, dev), packing.H3_SCALE_LOG2,
+                                 x_scale=2.0, feat_scale=2.0)
+        assert torch.equal(a, b), n
 
 
 def test_illum_and_autoencoders(dev, synth_weights):
