@@ -233,6 +233,53 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
       sat = sat_acc(sat, hi);
     }
   };
+  // Value rows, staged: softplus is a chain of three transcendentals (exp -> rcp, log) whose latencies an in-order wave waits out
+  // when the chain sits in one gap between MFMAs.  Cut at the transcendentals and spread over three consecutive k-block gaps
+  // (six MFMAs between the stages), the same operations in the same order (results unchanged bit for bit) issue without the
+  // stalls: stage 1 pre-activation + exponential, stage 2 reciprocal + logarithm, stage 3 combine, lift, split, store.
+  float pz[4][2], pe[4][2], pr[4][2], pl[4][2], pcr[4][2];      // per piece (tile, register pair) and element
+  auto val_stage1 = [&](const SrAcc& acc, int piece) {
+    const int t = piece >> 1, q = piece & 1;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float z = acc.a[t][2 * q + e] * zs;
+      const float bz = 100.0f * z;
+      pz[piece][e] = z;
+      pe[piece][e] = __builtin_amdgcn_exp2f((bz > 20.0f ? 20.0f : bz) * 1.44269504088896340736f);
+    }
+  };
+  auto val_stage2 = [&](int piece) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float u = 1.0f + pe[piece][e];
+      pr[piece][e] = __builtin_amdgcn_rcpf(u);
+      pcr[piece][e] = pe[piece][e] - (u - 1.0f);
+      pl[piece][e] = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+    }
+  };
+  auto val_stage3 = [&](int jb, int piece, float sa, int cb) {
+    const int t = piece >> 1, q = piece & 1;
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float z = pz[piece][e], bz = 100.0f * z;
+      const float sp = (pl[piece][e] + pcr[piece][e] * pr[piece][e]) * 0.01f;
+      v[e] = bz > 20.0f ? z : sp;
+      if constexpr (STORE) sstage[2 * q + e] = bz > 20.0f ? 1.0f : pe[piece][e] * pr[piece][e];
+    }
+    unsigned hi, lo;
+    split_pair_mix(v[0] * sa, v[1] * sa, hi, lo);
+    sat = sat_acc(sat, hi);
+    yh[t][jb >> 1][(jb & 1) * 2 + q] = hi;
+    yl[t][jb >> 1][(jb & 1) * 2 + q] = lo;
+    if constexpr (STORE) {
+      if (q == 1) {
+        const f4* base = sig_round;
+        asm volatile("" : "+s"(base));
+        sr_store16(base + ((cb + jb) * 2 + t) * 256, lane_off, sstage);
+      }
+    }
+  };
   // piece (tile, register pair) of hidden chunk jb -> next layer's k-block jb/2, registers 2*(jb&1)+q
   auto hidden_piece = [&](const SrAcc& acc, int jb, int piece, float sa, int cb) {
     const int t = piece >> 1, q = piece & 1;
@@ -328,11 +375,30 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
           wreg[2 * kb + 1] = ring_n[(2 * kb + 1) * 64];
         }
         if (jb > 0) {
+          if constexpr (!JVP && EPI != 2 && KB >= 8) {
+            // staged value rows: piece pc starts in gap {0, 1, 3, 5}[pc] and takes three consecutive gaps
 #pragma unroll
-          for (int pc = 0; pc < 4; ++pc)
-            if ((pc * KB) / 4 == kb) {
-              if constexpr (EPI == 2) output_piece(prev, jb - 1, pc); else hidden_piece(prev, jb - 1, pc, sa, cb);
+            for (int pc = 0; pc < 4; ++pc) {
+              const int g0 = pc == 0 ? 0 : 2 * pc - 1;
+              if (g0 + 2 == kb) val_stage3(jb - 1, pc, sa, cb);
             }
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+              const int g0 = pc == 0 ? 0 : 2 * pc - 1;
+              if (g0 + 1 == kb) val_stage2(pc);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+              const int g0 = pc == 0 ? 0 : 2 * pc - 1;
+              if (g0 == kb) val_stage1(prev, pc);
+            }
+          } else {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc)
+              if ((pc * KB) / 4 == kb) {
+                if constexpr (EPI == 2) output_piece(prev, jb - 1, pc); else hidden_piece(prev, jb - 1, pc, sa, cb);
+              }
+          }
         }
 #pragma unroll
         for (int i = 0; i < 5; ++i)
