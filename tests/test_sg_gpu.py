@@ -72,6 +72,38 @@ def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd, precision):
         print(f"[{precision}] chunk {c}: max rel err vs oracle {rel_err(out[sl], ref):.3e}")
 
 
+@pytest.mark.parametrize("testing,inv,argmax_vis", [(False, False, False), (True, True, False), (False, False, True)])
+def test_specular_visibility_vs_oracle(dev, vis_net, oracle_sd, testing, inv, argmax_vis):
+    """get_specular_visibility on its own (sg_render.py:198-301; inside render_with_sg it only shows through sg_specular_rgb):
+    cone samples around the reflection direction, the front-facing cull, the lobe weights and the batch-global sharpness
+    minimum, against the oracle on the same draws -- rough and mirror-like points in one batch."""
+    from robir_amd import sg_render
+    from robir_oracle import nets as on, sg as osg
+    g = np.random.Generator(np.random.PCG64(15))
+    n, nsamp = 53, 24
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    view = torch.nn.functional.normalize(nrm + 0.8 * torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    rough = torch.from_numpy(np.exp(g.uniform(np.log(0.08), np.log(0.9), (n, 1))).astype(np.float32))
+    u = torch.from_numpy(g.random((2, n, nsamp), dtype=np.float32))
+    out = sg_render.get_specular_visibility(pts.to(dev), nrm.to(dev), view.to(dev), vis_net, None, None, nsamp=nsamp,
+                                            testing=testing, inv=inv, argmax_vis=argmax_vis, roughness=rough.to(dev),
+                                            draws=(u[0].to(dev), u[1].to(dev))).cpu()
+    # the warped BRDF lobe the reference passes in (sg_render.py:414-437)
+    vdl = (nrm * view).sum(-1, keepdim=True).clamp(min=0.0)
+    w_lobe = 2 * vdl * nrm - view
+    w_lobe = w_lobe / (w_lobe.norm(dim=-1, keepdim=True) + 1e-6)
+    w_lam = (2.0 / rough ** 4) / (4 * vdl + 1e-6)
+    ref = osg.specular_visibility(pts, nrm, view, lambda p, d: on.vis_logits(oracle_sd, p, d), w_lobe, w_lam, u[0], u[1],
+                                  testing=testing, inv=inv, argmax_vis=argmax_vis)
+    assert out.shape == ref.shape == (n,)
+    assert float(ref.std()) > 0.02                       # a batch where the samples matter
+    if argmax_vis:                                       # hard decisions: a logit pair within rounding of a tie may flip a sample
+        assert float(((out - ref).abs() > 1e-4).float().mean()) <= 0.05
+    else:
+        assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+
+
 def test_generic_vismodel_callable(dev, vis_net):
     """A VisModel that is not our VisNetwork goes through the generic (callable) path and must agree."""
     from robir_amd import sg_render, synth
