@@ -43,6 +43,9 @@ constexpr int SB_SLOT_F4 = 1024;          // 16 KB per ring slot (K <= 256: four
 constexpr int SB_NS = 4;                  // ring slots; a chunk is requested SB_NS - 1 iterations before its MFMAs
 constexpr int SB_SS = 8;                  // sigmoid staging sets; a chunk's rows are requested SB_SD iterations before its MFMAs
 constexpr int SB_SD = 6;
+#ifndef SB_FILL
+#define SB_FILL 6
+#endif
 constexpr int SB_D = SB_NS - 1;
 constexpr int SB_NCHUNK = 120;
 constexpr long SB_SIG_ROUND_F4 = 125L * 2 * 256;     // float4s of the sigmoid blob per round (sdf_ring.hip)
@@ -81,6 +84,9 @@ struct SbAcc {
 #ifdef SB_DEBUG
 __device__ unsigned long long g_sb_spins, g_sb_checks;
 #endif
+#ifdef SB_TRACE
+__device__ unsigned long long g_sb_trace[4][4096];     // [wave][event]: cycle stamps of workgroup 0
+#endif
 
 // gfeat [rounds * 128][2][64]: d(sdf_raw)/d(feature slot) -- [.][0] the skip connection's share (layer 4), [.][1] layer 0's
 __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restrict__ Wb, const float* __restrict__ w8row, float us,
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
   __shared__ f4 sstg[SB_SS][2][256];                  // 64 KB: sigmoids of chunks p .. p+7 (set = stream position & 7), two tiles
   constexpr f4 poison = {-1.f, -1.f, -1.f, -1.f};
   __shared__ f4 w8s[64];
+  __shared__ f4 junk[2][64];                          // target of the copies a sigmoid wave issues only to keep the loop body uniform
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long nrounds = (M + 127) >> 7;
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
   const unsigned wslice = (unsigned)(wave & 1) * 2048u;            // byte offset of this wave's slices in a row (global and LDS)
   const unsigned stg_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)sstg);
   const unsigned stile = (unsigned)(wave & 1);        // sigmoid rows: wave 2 copies tile 0 of all four waves, wave 3 tile 1
+  const unsigned junk_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)junk) + stile * 1024u;
   const unsigned gf_off = (unsigned)((wave * 32 + (lane & 15)) * 128 + 4 * g) * 4u;     // this lane's row / slot group in gfeat
   // byte offsets of the ring slots of chunks first .. first + SB_NS - 1 of a layer whose first chunk sits on slot r
   auto slots_from = [&](int r, unsigned (&st)[SB_NS]) {
@@ -125,6 +133,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
   u4 yh[2][8], yl[2][8];               // ... of the next layer; during B7 the next round's layer-7 sigmoids land here
 
   f4 skeep[2];                         // sigmoids of the chunk in the epilogue, per tile
+#ifdef SB_TRACE
+  int tr_n = 0;
+#endif
   auto mfma_kb = [&](int kb, SbAcc& acc) {
     const h8 wh = __builtin_bit_cast(h8, wreg[kb * 2]);
     const h8 wlo = __builtin_bit_cast(h8, wreg[kb * 2 + 1]);
@@ -143,27 +154,35 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
     }
   };
   // piece (tile, register pair) of a continuing chunk jb: g (.) sigmoid, lifted (the lift of the operands cancels: acc carries it)
-  auto hidden_piece = [&](const SbAcc& acc, int jb, int piece, float sa, int first) {
-    const int t = piece >> 1, q = piece & 1;
-    if (q == 0) {
-      // (an LDS-space pointer: through a generic one the re-read would be a FLAT load, which counts in vmcnt too and makes the
-      // compiler drain the whole copy queue at every check)
-      typedef volatile __attribute__((address_space(3))) f4 lds_f4;
-      lds_f4* slot = (lds_f4*)&sstg[(first + jb) & (SB_SS - 1)][t][tid];
-      f4 s = *slot;
-      while (__builtin_amdgcn_ballot_w64(!(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])) >= 0.0f)) != 0ull) {
+  // arrival of the sigmoid rows of the chunk at stream position pos (both tiles of this wave) -> skeep; marks the slots empty.
+  // Runs at the top of an iteration, outside the k-block loop, so that the loop body stays one basic block (below)
+  auto take_sigmoids = [&](int pos) {
+    // (an LDS-space pointer: through a generic one the re-read would be a FLAT load, which counts in vmcnt too and makes the
+    // compiler drain the whole copy queue at every check)
+    typedef volatile __attribute__((address_space(3))) f4 lds_f4;
+    lds_f4* slot0 = (lds_f4*)&sstg[pos & (SB_SS - 1)][0][tid];
+    lds_f4* slot1 = (lds_f4*)&sstg[pos & (SB_SS - 1)][1][tid];
+    f4 s0 = *slot0, s1 = *slot1;
+    while (__builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(s0[0], s0[1]), fminf(s0[2], s0[3])),
+                                                fminf(fminf(s1[0], s1[1]), fminf(s1[2], s1[3]))) >= 0.0f)) != 0ull) {
 #ifdef SB_DEBUG
-        if (lane == 0) atomicAdd(&g_sb_spins, 1ull);
+      if (lane == 0) atomicAdd(&g_sb_spins, 1ull);
 #endif
-        __builtin_amdgcn_s_sleep(1);                // the row has not arrived yet
-        s = *slot;
-      }
-#ifdef SB_DEBUG
-      if (lane == 0) atomicAdd(&g_sb_checks, 1ull);
-#endif
-      *slot = poison;                               // marks the slot empty for the row that lands here four chunks on
-      skeep[t] = s;
+      __builtin_amdgcn_s_sleep(1);                  // a row has not arrived yet
+      s0 = *slot0;
+      s1 = *slot1;
     }
+#ifdef SB_DEBUG
+    if (lane == 0) atomicAdd(&g_sb_checks, 1ull);
+#endif
+    *slot0 = poison;                                // marks the slots empty for the rows that land here eight chunks on
+    *slot1 = poison;
+    skeep[0] = s0;
+    skeep[1] = s1;
+  };
+  // piece (tile, register pair) of a continuing chunk jb: g (.) sigmoid, lifted (the lift of the operands cancels: acc carries it)
+  auto hidden_piece = [&](const SbAcc& acc, int jb, int piece, float sa) {
+    const int t = piece >> 1, q = piece & 1;
     const f4 s = skeep[t];
     unsigned hi, lo;
     split_pair_mix(acc.a[t][2 * q] * s[2 * q] * sa, acc.a[t][2 * q + 1] * s[2 * q + 1] * sa, hi, lo);
@@ -206,10 +225,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
       if constexpr (EPI == 2) {
         feature_piece(acc, jb, pc, 1, zf, gf);
       } else if constexpr (EPI == 1) {
-        if (jb < 13) hidden_piece(acc, jb, pc, sa, first);
+        if (jb < 13) hidden_piece(acc, jb, pc, sa);
         else if (jb < 17) feature_piece(acc, jb - 13, pc, 0, zf * inv_sqrt2, gf);
       } else {
-        hidden_piece(acc, jb, pc, sa, first);
+        hidden_piece(acc, jb, pc, sa);
       }
     };
 #pragma unroll
@@ -224,14 +243,39 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
       // store that retired early must not stand in for a row), which at worst waits for two slices more than necessary.
       // Sigmoid waves have nothing to wait for.  lgkmcnt: the markers written in the previous iteration are in LDS before the
       // barrier lets a sigmoid wave request the rows that replace them
+#ifdef SB_TRACE
+      if (blockIdx.x == 0 && lane == 0 && tr_n < 4090) g_sb_trace[wave][tr_n++] = __builtin_readcyclecounter();
+#endif
       if (w_wave) sb_wait<8 * (SB_D - 2)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef SB_TRACE
+      if (blockIdx.x == 0 && lane == 0 && tr_n < 4090) g_sb_trace[wave][tr_n++] = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef SB_TRACE
+      if (blockIdx.x == 0 && lane == 0 && tr_n < 4090) g_sb_trace[wave][tr_n++] = __builtin_readcyclecounter();
+#endif
+      if (jb > 0 && (EPI == 0 || (EPI == 1 && jb - 1 < 13))) take_sigmoids(first + jb - 1);
       const int KBn = (jb + 1 < NCH ? K : KF) / 32;             // next chunk: its fragments roll into wreg
       const u4* ring_n = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + st[(jb + 1) % SB_NS]) + lane;
-      const f4* src3 = src_of(jb + SB_D);
-      const unsigned dst3 = ring_b + st[(jb + SB_D) % SB_NS] + wslice;
+      // The eight copies this wave requests in this iteration, two in each of four k-block gaps, WITHOUT a branch on the wave's
+      // role (the loop body must stay one basic block for the scheduler to interleave it): a weight wave takes its two 1 KB
+      // slices of the four rows of chunk jb + SB_D, a sigmoid wave the four 1 KB rows (its tile, the four waves) of the chunk
+      // SB_SD positions ahead and four copies into a scratch row (all eight where that chunk takes no sigmoids).
+      const int spos = first + jb + SB_SD;
+      const f4* sb2 = sig_src(spos, sr, srn);
+      const bool s_real = sb2 != nullptr;
+      const f4* dma_src = w_wave ? src_of(jb + SB_D) + 4 + (wave & 1) * 128 : (s_real ? sb2 : sr) + stile * 256;
+      const unsigned dma_dst = w_wave ? ring_b + st[(jb + SB_D) % SB_NS] + wslice
+                                      : (s_real ? stg_b + (unsigned)(spos & (SB_SS - 1)) * 8192u + stile * 4096u : junk_b);
+      auto dma_slot = [&](int k) {
+        // weight wave: row k/2, slice k&1 of its pair; sigmoid wave: consumer wave k (k < 4), scratch otherwise
+        const f4* src = dma_src + (w_wave ? (k >> 1) * 256 + (k & 1) * 64 : (k < 4 ? k * 64 : 0));
+        const unsigned dst = w_wave ? dma_dst + (unsigned)((k >> 1) * 4096 + (k & 1) * 1024)
+                                    : (k < 4 ? dma_dst + (s_real ? (unsigned)(k * 1024) : 0u) : junk_b);
+        sb_dma16(src, lane16, dst);
+      };
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         if (!empty) mfma_kb(kb, acc);
@@ -246,10 +290,19 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (((i * KB) / 4 + 1 < KB ? (i * KB) / 4 + 1 : KB - 1) == kb && w_wave) {
-            sb_dma16(src3 + 4 + i * 256, wslice + lane16, dst3 + (unsigned)i * 4096u);
-            sb_dma16(src3 + 4 + i * 256 + 64, wslice + lane16, dst3 + (unsigned)i * 4096u + 1024u);
+          if (((i * KB) / 4 + 1 < KB ? (i * KB) / 4 + 1 : KB - 1) == kb) {
+            dma_slot(2 * i);
+            dma_slot(2 * i + 1);
           }
+        // One wave per SIMD issues in order: six MFMAs back to back (two dependent chains of three) block the wave for their
+        // whole 96 cycles, and the epilogue's VALU work then issues behind them -- matrix and vector time add up.  Ask the
+        // scheduler for one MFMA followed by a handful of other instructions, six times: the vector work issues in the
+        // 12 idle issue cycles behind each MFMA instead.
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x106, SB_FILL, 0);     // VALU | SALU | DS read
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -257,19 +310,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
         wreg[2 * kb] = ring_n[(2 * kb) * 64];
         wreg[2 * kb + 1] = ring_n[(2 * kb + 1) * 64];
       }
-      if (!w_wave) {   // sigmoid rows of the chunk SB_SD positions ahead (its set was emptied by the epilogue two iterations ago)
-        const int pos = first + jb + SB_SD;
-        const f4* sb2 = sig_src(pos, sr, srn);
-        const unsigned set = (unsigned)(pos & (SB_SS - 1));
-        if (sb2 != nullptr) {
-#pragma unroll
-          for (int w = 0; w < 4; ++w)
-            sb_dma16(sb2 + stile * 256 + w * 64, lane16, stg_b + set * 8192u + (unsigned)(w * 1024) + stile * 4096u);
-        }
-      }
       __builtin_amdgcn_sched_barrier(0);
       prev = acc;
     }
+    if constexpr (EPI == 0) take_sigmoids(first + NCH - 1);
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) epilogue(prev, NCH - 1, pc);
     if constexpr (EPI == 2) {
@@ -491,6 +535,20 @@ extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const 
     hipMemcpyFromSymbol(&a, HIP_SYMBOL(g_sb_spins), 8);
     hipMemcpyFromSymbol(&b, HIP_SYMBOL(g_sb_checks), 8);
     fprintf(stderr, "sdf_back: %llu sigmoid-row checks, %llu spins so far\n", b, a);
+  }
+#endif
+#ifdef SB_TRACE
+  {
+    static unsigned long long h[4][4096];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sb_trace), sizeof(h));
+    FILE* f = fopen("gpurun_out/sb_trace.txt", "w");
+    if (f) {
+      for (int w = 0; w < 4; ++w) {
+        for (int i = 0; i < 4090; ++i) fprintf(f, "%llu ", h[w][i]);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
   }
 #endif
   const long n = 3 * M;

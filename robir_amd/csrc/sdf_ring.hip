@@ -23,6 +23,9 @@
 
 namespace rb {
 
+#ifndef SR_FILL
+#define SR_FILL 8
+#endif
 constexpr int SR_SLOT_F4 = 1280;          // 20 KB per ring slot: five 4 KB DMA rows (K = 288 needs 4.5)
 
 // The chunk stream of one pass, in closed form (no loops: these fold to constants once the chunk loops are unrolled).
@@ -404,6 +407,15 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
         for (int i = 0; i < 5; ++i)
           if (i < P3 && ((i * KB) / P3 + 1 < KB ? (i * KB) / P3 + 1 : KB - 1) == kb)
             sr_dma16(src3 + 4 + i * 256, lane_off, dst3 + (unsigned)i * 4096u);
+        // One wave per SIMD issues in order: six MFMAs back to back (two dependent chains of three) block the wave for their
+        // whole 96 cycles and the activation work of the gap issues behind them -- matrix and vector time add up (cycle stamps:
+        // 1800 cycles per chunk for 768 cycles of MFMAs).  Ask the scheduler for one MFMA followed by a handful of other
+        // instructions, six times: the vector work issues in the 12 idle issue cycles behind each MFMA.
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x506, SR_FILL, 0);     // VALU | SALU | DS read | transcendental
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll

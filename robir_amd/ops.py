@@ -132,7 +132,7 @@ def sdf_mlp_h3(X, M, blob, mode, scale_log2, out_scale=1.0, grad_scale=1.0):
 
 
 SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)
-SDF_GRAD_MIN_POINTS = 4096        # below this a launch is latency-bound and the two-kernel reverse form does not pay
+SDF_GRAD_MIN_POINTS = 16384       # below this the three-launch reverse form does not pay (0.25 ms floor; measured crossover)
 SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB of scratch per point)
 _sdf_grad_scratch = {}
 
