@@ -142,6 +142,8 @@ def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
     wb, w8 = back
     out0 = torch.empty(M, 257, dtype=torch.float32, device=x.device)
     grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out0, grad
     slab = min(M, SDF_GRAD_SLAB)
     need = int(_lib.lib().rb_sdf_value_grad_scratch_floats(c_long(slab)))
     key = (x.device, torch.cuda.current_stream().cuda_stream)

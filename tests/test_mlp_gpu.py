@@ -206,6 +206,8 @@ def test_sdf_value_grad_sizes_slabs_and_repeatability(dev, synth_weights, monkey
     h3 = packing.pack_sdf_h3(sd, dev, full=True)
     back = packing.pack_sdf_back_h3(sd, dev)
     g = torch.Generator().manual_seed(11)
+    o0, g0 = ops.sdf_value_grad(torch.zeros(0, 3, device=dev), 0, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+    assert o0.shape == (0, 257) and g0.shape == (0, 3)
     for n in (1, 127, 129, 4097, 33000, 300001):
         x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.7).to(dev)
         out, grad = ops.sdf_value_grad(x, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
