@@ -43,6 +43,9 @@ constexpr int SB_SLOT_F4 = 1024;          // 16 KB per ring slot (K <= 256: four
 constexpr int SB_NS = 4;                  // ring slots; a chunk is requested SB_NS - 1 iterations before its MFMAs
 constexpr int SB_SS = 8;                  // sigmoid staging sets; a chunk's rows are requested SB_SD iterations before its MFMAs
 constexpr int SB_SD = 6;
+#ifndef SB_WWAIT
+#define SB_WWAIT (8 * (SB_D - 2))
+#endif
 #ifndef SB_FILL
 #define SB_FILL 6
 #endif
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
 #ifdef SB_TRACE
       if (blockIdx.x == 0 && lane == 0 && tr_n < 4090) g_sb_trace[wave][tr_n++] = __builtin_readcyclecounter();
 #endif
-      if (w_wave) sb_wait<8 * (SB_D - 2)>();
+      if (w_wave) sb_wait<SB_WWAIT>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef SB_TRACE
       if (blockIdx.x == 0 && lane == 0 && tr_n < 4090) g_sb_trace[wave][tr_n++] = __builtin_readcyclecounter();
