@@ -98,6 +98,10 @@ int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_l
  * persistent (n_workgroups <= 0: one per compute unit). */
 int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
                     float* out0, float* grad, int n_workgroups, rb_stream_t stream);
+/* Value rows (modes 0, 1 and the value pass of rb_sdf_value_grad) run as eight waves of one 16-row tile per workgroup -- two
+ * waves per SIMD, csrc/sdf_ring8.hip -- or as four waves of two tiles (csrc/sdf_ring.hip): same results.  Selects 8 (default)
+ * or 4 for the calling process; returns the previous setting. */
+int rb_sdf_ring_waves(int waves);
 /* All 257 outputs and the input gradient of the signed distance in REVERSE mode (csrc/sdf_back.hip; model/neus_model.py:440-452
  * is autograd too): one value pass (rb_sdf_mlp_ring's kernel, which also stores sigmoid(100 z) of every hidden pre-activation)
  * and one row vector per point back through the transposed layers -- twice the matrix work of the values instead of the four

@@ -45,6 +45,8 @@ def lib():
         _lib.rb_sdf_value_grad_scratch_floats.restype = ctypes.c_long
         if _lib.rb_abi_version() != 3:
             raise RobirHipError("librobir_hip.so ABI version mismatch")
+        if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
+            _lib.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))
     return _lib
 
 

@@ -576,6 +576,18 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
 
 using namespace rb;
 
+namespace rb {
+int launch_sdf_ring8(int mode, const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
+                     hipStream_t s);
+int g_sdf_ring_waves = 8;     // value rows (modes 0, 1, 5): 8 = k_sdf_ring8 (two waves per SIMD), 4 = k_sdf_ring
+}  // namespace rb
+
+extern "C" int rb_sdf_ring_waves(int waves) {
+  const int old = rb::g_sdf_ring_waves;
+  if (waves == 4 || waves == 8) rb::g_sdf_ring_waves = waves;
+  return old;
+}
+
 extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
                                float* out0, float* grad, int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -599,6 +611,7 @@ extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
+  if (mode < 2 && rb::g_sdf_ring_waves == 8) return rb::launch_sdf_ring8(mode, X, M, W, us, out_scale, out0, nullptr, grid, s);
   switch (mode) {
     case 0: hipLaunchKernelGGL(k_sdf_ring<0>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
     case 1: hipLaunchKernelGGL(k_sdf_ring<1>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
@@ -612,6 +625,7 @@ namespace rb {
 // forward half of the reverse-mode gradient (sdf_back.hip): all outputs of M points + the sigmoid blob
 int launch_sdf_ring_store(const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
                           hipStream_t s) {
+  if (g_sdf_ring_waves == 8) return launch_sdf_ring8(5, X, M, W, us, out_scale, out0, sig, grid, s);
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
   hipLaunchKernelGGL(k_sdf_ring<5>, dim3(grid), dim3(256), 0, s, X, M, W, us, out_scale, 0.0f, out0, nullptr, rw, sig);
   return check_launch("k_sdf_ring<5>");

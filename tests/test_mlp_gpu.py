@@ -225,6 +225,36 @@ def test_sdf_value_grad_sizes_slabs_and_repeatability(dev, synth_weights, monkey
     ops.range_check(sync=True)
 
 
+def test_sdf_value_kernels_eight_and_four_waves_agree(dev, synth_weights):
+    """Value rows (modes 0, 1, and the value pass + sigmoid blob of the reverse-mode gradient) as eight waves of one tile
+    (csrc/sdf_ring8.hip, the default) and as four waves of two tiles (csrc/sdf_ring.hip): bit-identical outputs -- the blob through
+    the backward pass that reads it."""
+    from robir_amd import _lib, ops, packing
+    g = torch.Generator().manual_seed(21)
+    full = packing.pack_sdf_h3(synth_weights, dev, full=True)
+    dist = packing.pack_sdf_h3(synth_weights, dev, full=False)
+    back = packing.pack_sdf_back_h3(synth_weights, dev)
+    L = _lib.lib()
+    res = {}
+    try:
+        for waves in (8, 4):
+            L.rb_sdf_ring_waves(waves)
+            out = []
+            for n in (1, 129, 40001):
+                x = ((torch.rand(n, 3, generator=torch.Generator().manual_seed(n)) - 0.5) * 1.6).to(dev)
+                X = ops.feat_pe10(x, scale=2.0)
+                out.append(ops.sdf_mlp_h3(X, n, dist, 0, packing.H3_SCALE_LOG2, out_scale=0.5)[0])
+                out.append(ops.sdf_mlp_h3(X, n, full, 1, packing.H3_SCALE_LOG2, out_scale=0.5)[0])
+                out.extend(ops.sdf_value_grad(x, n, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5))
+            res[waves] = out
+    finally:
+        L.rb_sdf_ring_waves(8)
+    assert len(res[8]) == len(res[4]) == 12
+    for a, b in zip(res[8], res[4]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    ops.range_check(sync=True)
+
+
 def test_eval_points_picks_the_reverse_mode_for_large_batches(dev, synth_weights, monkeypatch):
     from robir_amd import nets, ops, synth
     model = nets.NeuSModel()
