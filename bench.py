@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--exact-steps", type=int, default=3)
     ap.add_argument("--cpu-baseline-1thread-pixels", type=int, default=256,
                     help="pixels of the single-thread CPU baseline sample (the runners force torch.set_num_threads(1))")
-    ap.add_argument("--vis-precision", default="f16x3-auto", choices=["fp32", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
+    ap.add_argument("--vis-precision", default="f16x3-auto", choices=["fp32", "f16x3-auto", "f16x3-v4", "f16x3-v3", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
                     help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
                          "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
     ap.add_argument("--vis", default="mlp", choices=["mlp", "octree"],

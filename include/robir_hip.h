@@ -192,6 +192,11 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
 int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* rb_dvis_fused_v2 as eight waves of one 16-sample tile per workgroup (two waves per SIMD, csrc/vis_diffuse_v4.hip): same arguments,
+ * bit-identical vis_out. */
+int rb_dvis_fused_v4(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                     const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                     float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
  *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
  *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point

@@ -248,6 +248,7 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
 
 
 DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream", "f16x3-v2": "k_dvis_v2",
+                     "f16x3-v4": "k_dvis_v4",
                      "f16x3": "k_dvis_fused<H3>"}
 
 
@@ -269,7 +270,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     # the matrix pipe (csrc/vis_diffuse_v2.hip);
     # "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA;
     # "f16x3-regstage" = same with global->VGPR->LDS staging; "f16x3-nt2" = two tiles per wave, one workgroup per CU
-    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8}[precision]
+    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x3-v4": 9}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
@@ -289,8 +290,9 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
              c_int(split["h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
-    if precision == "f16x3-v2":
-        call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+    if precision in ("f16x3-v2", "f16x3-v4"):
+        # v4 = v2 as eight waves of one tile (two waves per SIMD, csrc/vis_diffuse_v4.hip): bit-identical
+        call("rb_dvis_fused_v2" if precision == "f16x3-v2" else "rb_dvis_fused_v4", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out

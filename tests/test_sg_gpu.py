@@ -23,7 +23,7 @@ def vis_net(dev, synth_weights):
     return v.to(dev).eval()
 
 
-@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2", "f16x3-v2", "f16x3-v3"])
+@pytest.fixture(params=["fp32", "f16x3", "f16x3-regstage", "f16x3-nt2", "f16x3-v2", "f16x3-v3", "f16x3-v4"])
 def precision(request):
     from robir_amd import sg_render
     old = sg_render.VIS_PRECISION
@@ -257,7 +257,7 @@ def test_streaming_kernel_equals_one_point_per_workgroup_kernel(dev, vis_net):
         outs = {}
         old_p, old_w = sg_render.VIS_PRECISION, ops.DVIS_STREAM_WORKGROUPS
         try:
-            for prec, wgs in (("f16x3-v2", 0), ("f16x3-v3", 0), ("f16x3-v3", 1), ("f16x3-v3", 7), ("f16x3-v3", 4096)):
+            for prec, wgs in (("f16x3-v2", 0), ("f16x3-v4", 0), ("f16x3-v3", 0), ("f16x3-v3", 1), ("f16x3-v3", 7), ("f16x3-v3", 4096)):
                 sg_render.VIS_PRECISION, ops.DVIS_STREAM_WORKGROUPS = prec, wgs
                 stats = {}
                 outs[(prec, wgs)] = (sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, C, stats),
