@@ -141,6 +141,51 @@ def cpu_baseline(model, n_chunks, uv, pose, K, cores=None, pixels=CHUNK):
             "hit_rays_per_s": hits / dt}
 
 
+class PowerProbe:
+    """Samples `rocm-smi --showpower` in a thread while the timed region runs: the dominant kernel sits on the package power
+    cap, and the bench line should say so with a number.  Best effort: no rocm-smi, no field."""
+
+    def __init__(self, period=0.4):
+        import re
+        import shutil
+        import subprocess
+        import threading
+        self.samples, self.cap, self._stop = [], None, threading.Event()
+        exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+
+        def read(extra):
+            out = subprocess.run([exe, "-d", str(dev), "--showpower"] + extra, capture_output=True, text=True, timeout=3).stdout
+            m = re.search(r"Package Power \(W\): ([0-9.]+)", out.split("Max")[0] if "Max" in out else out)
+            c = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+            return (float(m.group(1)) if m else None), (float(c.group(1)) if c else None)
+
+        def loop():
+            try:
+                _, self.cap = read(["--showmaxpower"])
+                while not self._stop.wait(period):
+                    w, _ = read([])
+                    if w is not None:
+                        self.samples.append(w)
+            except Exception:
+                pass
+
+        self._thread = threading.Thread(target=loop, daemon=True) if exe else None
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=5)
+        if not self.samples:
+            return None
+        s = sorted(self.samples)
+        return {"cap_w": self.cap, "max_w": s[-1], "median_w": s[len(s) // 2], "samples": len(s),
+                "note": "rocm-smi package power sampled during the timed steps (samples between two launches read lower)"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +264,9 @@ def main():
     barrier()
     stats.clear()
     timer.on = True
+    power = PowerProbe() if rank == 0 else None      # package power while the timed steps run (rocm-smi, best effort)
     dt, out = timed(step, args.steps)
+    power_line = power.stop() if power is not None else None
     timer.on = False
     ops.range_check(sync=True)                           # split-precision activation-range sentinel: raises on overflow
     rays_total = H * W * args.steps
@@ -278,6 +325,8 @@ def main():
                     "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                     "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                     "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
+        if power_line is not None:
+            roofline["package_power"] = power_line
         line = {
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
