@@ -183,13 +183,20 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
       const int n3 = jb + 3 < NCH ? NP : (jb + 3 == NCH ? NF0 : (jb + 3 == NCH + 1 ? NF1 : NF2));
       const f4* src3 = src_of(jb + 3) + 4 + wave * 64;                       // this wave's first 1 KB slice of chunk jb+3
       const unsigned dst3 = ring_b + sl[(jb + 3) & 3] + (unsigned)wave * 1024u;
-      u4 wa = frag[0], wb = frag[64];
+      // weight fragments: three k-blocks in registers, read two k-blocks (six MFMAs, ~100 cycles: the LDS latency) ahead
+      u4 wfa[3], wfb[3];
+      wfa[0] = frag[0];
+      wfb[0] = frag[64];
+      if (KB > 1) {
+        wfa[1] = frag[2 * 64];
+        wfb[1] = frag[3 * 64];
+      }
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        const h8 wh = __builtin_bit_cast(h8, wa), wlo = __builtin_bit_cast(h8, wb);
-        if (kb + 1 < KB) {                                                    // next k-block's fragments
-          wa = frag[(2 * kb + 2) * 64];
-          wb = frag[(2 * kb + 3) * 64];
+        const h8 wh = __builtin_bit_cast(h8, wfa[kb % 3]), wlo = __builtin_bit_cast(h8, wfb[kb % 3]);
+        if (kb + 2 < KB) {
+          wfa[(kb + 2) % 3] = frag[(2 * kb + 4) * 64];
+          wfb[(kb + 2) % 3] = frag[(2 * kb + 5) * 64];
         }
         const h8 a = __builtin_bit_cast(h8, xh[kb]), b = __builtin_bit_cast(h8, xl[kb]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, acc, 0, 0, 0);
