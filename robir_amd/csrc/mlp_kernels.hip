@@ -157,23 +157,6 @@ __device__ __forceinline__ void write_pe_tangent(const float x[3], int c, float*
   }
 }
 
-// X[M,128] = [PE10(p) | PE10(d) | 0 0]   (VisNetwork input, implicit_differentiable_renderer.py:250-256)
-__global__ void k_feat_vis(const float* __restrict__ p, const float* __restrict__ d, long M, int rep,
-                           float* __restrict__ X) {
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= M) return;
-  const long ip = i / rep;  // each point is paired with `rep` consecutive directions
-  float a[3] = {p[3 * ip], p[3 * ip + 1], p[3 * ip + 2]};
-  float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
-  float* row = X + i * 128;
-  write_pe<10>(a, row);
-  write_pe<10>(b, row + 63);
-  row[126] = 0.f;
-  row[127] = 0.f;
-}
-
-// X[M,64] = [PE10(x*scale) | extra]  (extra = 0, or hdr_shift for the indirect-illumination net)
-// jvp != 0: X[4M,64], row 4m = PE, rows 4m+1..3 = dPE/dx, dPE/dy, dPE/dz  (forward-mode SDF gradient)
 // Sixteen threads per row, one float4 of the row each: the stores of a wave are 4 x 256 contiguous bytes (a thread per row wrote
 // 64 floats 256 B apart from its neighbours': 0.29 ms per 2^20 rows, neither compute- nor bandwidth-bound).  Every feature is the
 // same sincosf of the same argument as before: identical rows.
@@ -188,6 +171,27 @@ __device__ __forceinline__ float pe10_feature(const float a[3], int f, int tange
   if (tangent_of < 0) return r >= 3 ? cs : sn;
   return r >= 3 ? -fr * sn : fr * cs;
 }
+// X[M,128] = [PE10(p) | PE10(d) | 0 0]   (VisNetwork input, implicit_differentiable_renderer.py:250-256); 32 threads per row
+__global__ void k_feat_vis(const float* __restrict__ p, const float* __restrict__ d, long M, int rep,
+                           float* __restrict__ X) {
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < M * 32; t += (long)gridDim.x * blockDim.x) {
+    const long i = t >> 5;
+    const int q = (int)(t & 31);
+    const long ip = i / rep;  // each point is paired with `rep` consecutive directions
+    const float a[3] = {p[3 * ip], p[3 * ip + 1], p[3 * ip + 2]};
+    const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+    f4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = 4 * q + e;
+      v[e] = f < 63 ? pe10_feature(a, f, -1, 0.f) : (f < 126 ? pe10_feature(b, f - 63, -1, 0.f) : 0.f);
+    }
+    reinterpret_cast<f4*>(X + i * 128)[q] = v;
+  }
+}
+
+// X[M,64] = [PE10(x*scale) | extra]  (extra = 0, or hdr_shift for the indirect-illumination net)
+// jvp != 0: X[4M,64], row 4m = PE, rows 4m+1..3 = dPE/dx, dPE/dy, dPE/dz  (forward-mode SDF gradient)
 __global__ void k_feat_pe10(const float* __restrict__ x, long M, float scale, const float* __restrict__ extra, int jvp,
                             float* __restrict__ X) {
   const long rows = jvp ? 4 * M : M;
@@ -762,7 +766,9 @@ int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_st
   if (M <= 0) return 0;
   RB_REQUIRE(p && d && X, "null pointer");
   RB_REQUIRE(rep >= 1, "rep must be >= 1");
-  hipLaunchKernelGGL(k_feat_vis, grid1d(M, 256), dim3(256), 0, (hipStream_t)stream, p, d, M, rep, X);
+  const long vblocks = (M * 32 + 255) / 256;
+  hipLaunchKernelGGL(k_feat_vis, dim3((unsigned)(vblocks < RB_MAX_BLOCKS ? vblocks : RB_MAX_BLOCKS)), dim3(256), 0, (hipStream_t)stream, p, d, M,
+                     rep, X);
   return check_launch("k_feat_vis");
 }
 
