@@ -252,3 +252,25 @@ def test_config5_cesr_chunks_of_1600x1200(dev):
             assert float(a["vis_shadow"][hit].min()) >= 0.0 and float(a["vis_shadow"][hit].max()) <= 1.0 + 1e-6
             assert float((a["normal_map"][hit].norm(dim=-1) - 1.0).abs().max()) < 1e-4
     assert n_hit_total > 15000         # the central chunks are on the object, the corner chunks are all-miss
+
+
+def test_feature_kernels_beyond_the_block_limit(dev):
+    """The encoding kernels use 16 / 32 threads per row and a grid-stride loop: 17.5 M points in forward-mode form are 70 M rows =
+    4.4 M workgroups' worth of threads, more than one launch may have (common.h RB_MAX_BLOCKS) -- the tail must still be written.
+    (The visibility features of 17.5 M rows stay under the limit: checked for the pairing of points and directions.)"""
+    from robir_amd import ops
+    M = 17_500_000
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = (torch.rand(M, 3, device=dev, generator=g) * 2 - 1) * 0.9
+    X = ops.feat_pe10(x, scale=2.0, jvp=True)                     # [4M, 64]: 17.9 GB
+    assert X.shape == (4 * M, 64)
+    pick = torch.cat([torch.arange(0, 1000, device=dev), torch.arange(M - 1000, M, device=dev),
+                      torch.randint(0, M, (3000,), device=dev, generator=g)])
+    ref = ops.feat_pe10(x[pick].contiguous(), scale=2.0, jvp=True).view(-1, 4, 64)
+    assert torch.equal(X.view(M, 4, 64)[pick], ref)
+    del X
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev, generator=g), dim=-1)
+    V = ops.feat_vis(x[:M // 2].contiguous(), d, rep=2)           # [M, 128]: 9 GB, two directions per point
+    vref = ops.feat_vis(x[pick[:2000] // 2].contiguous(), d[(pick[:2000] // 2 * 2)[:, None] + torch.arange(2, device=dev)].reshape(-1, 3),
+                        rep=2).view(-1, 2, 128)
+    assert torch.equal(V.view(M // 2, 2, 128)[pick[:2000] // 2], vref)
