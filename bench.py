@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- PBR-stage rays/s of the MI355X-native renderer (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -15,7 +15,14 @@ robir_amd.parallel.render_view_sharded, and the 17-float tiles are all-gathered 
 partition SURVEY.md 8e / north_star name).  `value` = rays of that image / step time.  For N > 1 a secondary figure times the
 weak form (rank r renders its own view r).  The octree build is one-off set-up and is reported separately.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fused light-SG visibility, fp32 MFMA bound) and, at
+Arithmetic (`--precision`): the headline is `exact` -- NOT narrower than the reference's fp32: the light-visibility MLP (98 % of
+the FLOPs) carries every fp32 operand exactly as three f16 pieces and forms the six partial products of weight >= 2^-22 on the
+f16 MFMA in three fp32 accumulators (csrc/vis_diffuse_x6.hip), every other MLP runs on the f32-input MFMA.  At N = 1 the line
+also carries `legs` (the same view on the f32-input MFMA everywhere, and in split precision = 22-bit operand pairs, each
+timed over its own loop, with image distances) and `configs` (BASELINE configs 1, 2, 3, 5; `--config N` prints one of them as
+its own line).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: fused light-SG visibility, MFMA bound) and, at
 N=1, `cpu_baseline` (the oracle restatement timed on this box's host cores on a bounded sample of the same workload).
 """
 import argparse
@@ -39,24 +46,47 @@ H = W = 800
 CHUNK = 1024
 
 
+PRECISIONS = {
+    # name: (light-visibility kernel, stand-alone MLP kernels, dtype string of the JSON line)
+    "exact": ("f16x6", "fp32",
+              "f32 (light-visibility MLP: every fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add "
+              "in three fp32 accumulators; every other MLP on the f32-input MFMA) -- not narrower than the reference's fp32"),
+    "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
+    "split": ("f16x3-auto", "f16x3", "f32 operands as 22-bit f16 hi/lo pairs, 3 f16 MFMA products per multiply-add, fp32 accumulate "
+                                     "(parity-tested throughput mode; NARROWER than fp32)"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configuration to time: 4 (default) = the one the metric is quoted on, 800x800 full PBR; "
+                         "1, 2, 3, 5 print one line for that configuration instead (tools/bench_configs.py; N = 1 only)")
+    ap.add_argument("--precision", default="exact", choices=sorted(PRECISIONS),
+                    help="arithmetic of the MLP layers.  exact (default, the headline): not narrower than fp32 -- the light-visibility "
+                         "MLP with exact three-piece f16 operands (6 MFMA products per multiply-add), the other MLPs on the "
+                         "f32-input MFMA; fp32-mfma: everything on the f32-input MFMA; split: 22-bit hi/lo operand pairs, 3 "
+                         "products (faster, narrower than fp32)")
     ap.add_argument("--chunks-per-batch", type=int, default=625,
                     help="1024-pixel chunks rendered per kernel pass (625 = the whole 800x800 view; 2.7 GB of tables)")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact", action="store_true",
-                    help="skip the exact-fp32 leg (N = 1): the same view with every MLP on the f32-input MFMA, timed over "
-                         "--exact-steps steps of its own, and the image distance of the default run from it")
-    ap.add_argument("--exact-steps", type=int, default=3)
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the side legs (N = 1): the same view in the other two precisions, each timed over --leg-steps steps "
+                         "of its own, and the image distances from the f32-input-MFMA image")
+    ap.add_argument("--leg-steps", type=int, default=3)
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` extras (N = 1): BASELINE configs 1, 2, 3, 5 timed after the headline")
+    ap.add_argument("--config5-chunks", type=int, default=None,
+                    help="chunks of the 1600x1200 CESR view (default: 1875 = the whole view for --config 5, a 125-chunk band "
+                         "for the extras of the default line)")
     ap.add_argument("--cpu-baseline-1thread-pixels", type=int, default=256,
                     help="pixels of the single-thread CPU baseline sample (the runners force torch.set_num_threads(1))")
-    ap.add_argument("--vis-precision", default="f16x3-auto", choices=["fp32", "f16x3-auto", "f16x3-v4", "f16x3-v3", "f16x3-v2", "f16x3", "f16x3-regstage", "f16x3-nt2"],
-                    help="hidden layers of the fused light-visibility kernel: exact f32-input MFMA, or the error-compensated "
-                         "hi/lo half split on the f16 MFMA (fp32 accumulate, same measured parity)")
+    ap.add_argument("--vis-precision", default=None, choices=["fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3"],
+                    help="override the light-visibility kernel of --precision (A/B runs)")
     ap.add_argument("--vis", default="mlp", choices=["mlp", "octree"],
                     help="light / BRDF-lobe visibility model: the visibility MLP (default, the reference's default) or traced "
                          "visibility = OctreeVisModel(octree_ray_tracer), the reference's `trace_vis` switch "
@@ -186,13 +216,57 @@ class PowerProbe:
                 "note": "rocm-smi package power sampled during the timed steps (samples between two launches read lower)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same command line
+    under torch.distributed.run on 127.0.0.1) and hand their exit code back.  On a box with fewer than N devices the ranks
+    share cuda:0 over gloo (RCCL refuses two ranks on one device) so that the multi-rank path can still be exercised; the
+    JSON line says which backend ran."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        env.setdefault("ROBIR_SHARE_GPU", "1")
+        env.setdefault("ROBIR_DIST_BACKEND", "gloo")
+        print(f"bench.py: {n_dev} device(s) visible for --gpus {args.gpus}: ranks share cuda:0 over "
+              f"{env['ROBIR_DIST_BACKEND']} (functional run, not a scaling figure)", file=sys.stderr)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def set_precision(name, vis_override=None):
+    """Select the arithmetic of every MLP kernel: returns (visibility-kernel mode, MLP mode, dtype string)."""
+    from robir_amd import sg_render
+    vis, mlp, dtype = PRECISIONS[name]
+    vis = vis_override or vis
+    sg_render.VIS_PRECISION = vis
+    os.environ["ROBIR_MLP_PRECISION"] = mlp
+    return vis, mlp, dtype
+
+
+def vis_peak(vis):
+    """Peak of the pipe the light-visibility kernel runs on, per ALGORITHMIC flop."""
+    if vis == "fp32":
+        return PEAK_FP32_MFMA_TFLOPS, "dense f32-input MFMA (v_mfma_f32_16x16x4_f32)"
+    if vis == "f16x6":
+        return PEAK_F16_MFMA_TFLOPS / 6.0, "dense f16 MFMA 2500 TFLOP/s / 6 products per multiply-add (exact three-piece operands)"
+    return PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)"
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py without a launcher (it starts its own "
+                         f"ranks) or with torch.distributed.run --nproc-per-node {args.gpus}")
     # ROBIR_SHARE_GPU=1 + ROBIR_DIST_BACKEND=gloo: all ranks on cuda:0 (lets the multi-rank code path be exercised on a
     # 1-GPU box; RCCL refuses two ranks on one device).  Normal runs: one rank per GPU over RCCL ("nccl" on ROCm).
     if os.environ.get("ROBIR_SHARE_GPU") == "1":
@@ -210,17 +284,37 @@ def main():
             dist.init_process_group(backend)
 
     from robir_amd import ops, renderer, synth, sg_render, parallel
-    if "ROBIR_VIS_PRECISION" not in os.environ:
-        sg_render.VIS_PRECISION = args.vis_precision
-    precision = sg_render.VIS_PRECISION
-    if precision == "fp32":        # exact f32-input MFMA everywhere, not only in the visibility kernel
-        os.environ.setdefault("ROBIR_MLP_PRECISION", "fp32")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    vis_mode, mlp_mode, dtype = set_precision(args.precision, os.environ.get("ROBIR_VIS_PRECISION") or args.vis_precision)
     t0 = time.time()
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the octree build prints like the reference; stdout carries only the JSON line
         model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
     torch.cuda.synchronize()
     build_s = time.time() - t0
+
+    if args.config != 4:
+        # one of the other BASELINE configurations as its own line (single GPU: they are parity-test cases, not scaling lines)
+        if world > 1:
+            raise SystemExit("--config 1/2/3/5 are single-GPU lines")
+        bench_configs.install_timers()
+        kw = {}
+        if args.config == 5:
+            n5 = args.config5_chunks or 1875
+            kw = dict(first=0 if n5 == 1875 else (1875 - n5) // 2, nch=n5)
+        with torch.no_grad():
+            r = bench_configs.CONFIGS[args.config](model, reps=max(1, args.steps), **kw)
+        ops.range_check(sync=True)
+        line = {"metric": f"BASELINE.json configs[{args.config - 1}]: " + r["workload"], "value": r["value"], "unit": r["unit"],
+                "n_gpus": 1, "steps": max(1, min(args.steps, bench_configs.REPS)), "warmup": 1, "ms_per_step": r["ms"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": {"workload": r["workload"], "precision": args.precision, "octree_build_s": round(build_s, 2),
+                           **{k: v for k, v in r.items() if k not in ("workload", "value", "unit", "ms", "roofline", "config")}},
+                "roofline": r["roofline"],
+                "note": "best of the timed repetitions; the headline metric is the default line (--config 4)"}
+        print(json.dumps(line), flush=True)
+        return
 
     timer = KernelTimer()
     if args.vis == "octree":
@@ -259,6 +353,22 @@ def main():
             dt = float(tmax)
         return dt, out
 
+    def vis_roofline(vis, k_ms, k_n, evals):
+        """`roofline` of the fused light-visibility kernel from its HIP-event durations and its own pair counter."""
+        flops_per_launch = 2.0 * VIS_MACS_PER_EVAL * evals / max(k_n, 1)
+        achieved = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        peak, note = vis_peak(vis)
+        kern = "k_dvis_v2" if vis == "f16x3-auto" else ops.DVIS_KERNEL_NAMES.get(vis, "k_dvis_fused")
+        return {"bound": "mfma", "kernel": kern + " (light-SG visibility MLP)", "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak,
+                # HBM bytes per launch: B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
+                # correction) + WRITE_SIZE on this kernel family (profiles/), scaled to this launch's pair count: well under
+                # 1 % of the HBM roofline -- the bound is the matrix pipe
+                "traffic": TRAFFIC_B_PER_PAIR * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
+                "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -268,13 +378,11 @@ def main():
     dt, out = timed(step, args.steps)
     power_line = power.stop() if power is not None else None
     timer.on = False
-    ops.range_check(sync=True)                           # split-precision activation-range sentinel: raises on overflow
+    ops.range_check(sync=True)                           # f16-piece activation-range sentinel: raises on overflow
     rays_total = H * W * args.steps
     hit_frac = float(out[:, 16].mean())
     evals = int(stats["diffuse_vis_evals"]) if "diffuse_vis_evals" in stats else 0
     k_ms, k_n = timer.stats()
-    flops_per_launch = 2.0 * VIS_MACS_PER_EVAL * evals / max(k_n, 1)
-    achieved = flops_per_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
     weak = None
     if world > 1:
@@ -307,37 +415,24 @@ def main():
                        "note": "gathers are dependent 32-byte reads of a 29 MB table (L2 / MALL resident): the bound is "
                                "latency x occupancy, not HBM bandwidth; frac is against the HBM peak as the metric asks"}
         octree_line["frac"] = octree_line["achieved"] / 8000.0
+    line = None
     if rank == 0:
-        h3 = precision.startswith("f16x3")
-        # peak of the pipe the dominant kernel runs on, per ALGORITHMIC flop: exact mode = dense f32-input MFMA;
-        # f16x3 = dense f16 MFMA (2.5 PFLOP/s) / 3 products per algorithmic multiply-add
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if h3 else PEAK_FP32_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": ops.DVIS_KERNEL_NAMES.get(precision, "k_dvis_fused") + " (light-SG visibility MLP)",
-                    "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak,
-                    # HBM bytes per launch: B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
-                    # correction) + WRITE_SIZE on this kernel (profiles/), scaled to this launch's pair count: well under 1 % of
-                    # the HBM roofline -- the bound is the matrix pipe
-                    "traffic": TRAFFIC_B_PER_PAIR * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
-                    "precision": precision,
-                    "peak_note": ("dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)" if h3
-                                  else "dense f32-input MFMA"),
-                    "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                    "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
-                    "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
+        roofline = vis_roofline(vis_mode, k_ms, k_n, evals)
         if power_line is not None:
             roofline["package_power"] = power_line
         line = {
             "metric": "PBR-stage rays/sec (128 SG lobes, 32 visibility samples/lobe), full forward render",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if precision == "fp32" else "f32 (MLP layers as 3x f16 hi/lo-split MFMA products, fp32 accumulate)",
-            "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "hotdog-like synthetic 800x800 full PBR forward (BASELINE.json configs[3]): ONE view = "
                                    "625 lock-step chunks of 1024 px, chunks sharded over the GPUs (c mod N), tiles all-gathered",
                        "image": [H, W], "chunk": CHUNK, "chunks_per_pass": args.chunks_per_batch,
                        "hit_fraction": round(hit_frac, 4), "octree_build_s": round(build_s, 2),
-                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B,
+                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "precision": args.precision,
+                       "visibility_kernel": vis_mode, "mlp_kernels": mlp_mode,
+                       "ranks": world, "collective_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
+                       "ranks_share_one_gpu": os.environ.get("ROBIR_SHARE_GPU") == "1" and world > 1,
                        "parallelism": f"chunk-shard x{world} of one view + all-gather"},
             "roofline": roofline if octree_line is None else octree_line,
         }
@@ -346,41 +441,63 @@ def main():
             line["config"]["visibility"] = "OctreeVisModel (secondary lock-step octree cast, max_iter 32, 2 M-pair batches)"
         if weak is not None:
             line["weak_views"] = weak
-    if world == 1 and precision != "fp32" and not args.no_exact and args.vis == "mlp":
-        # Second first-class figure: the same view with EVERY MLP on the exact f32-input MFMA (v_mfma_f32_16x16x4_f32),
-        # timed over its own loop -- the rate at the reference's own precision -- and how far the default image is from it
-        # under identical random draws.
-        torch.manual_seed(20260928)
-        split_img = step()
-        sg_render.VIS_PRECISION = "fp32"
-        os.environ["ROBIR_MLP_PRECISION"] = "fp32"
-        torch.manual_seed(20260928)
-        exact_img = step()                              # warm-up: packs the fp32 weight blobs
-        timer.pairs.clear()
-        timer.on = True
-        stats.clear()
-        t_exact, _ = timed(step, args.exact_steps)
-        timer.on = False
-        e_ms, e_n = timer.stats()
-        e_evals = int(stats["diffuse_vis_evals"]) if "diffuse_vis_evals" in stats else 0
-        e_tflops = 2.0 * VIS_MACS_PER_EVAL * e_evals / max(e_n, 1) / (e_ms * 1e-3) / 1e12 if e_ms > 0 else 0.0
-        ok = torch.isfinite(exact_img).all(-1) & torch.isfinite(split_img).all(-1)
-        a, b = split_img[ok], exact_img[ok]
-        rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
-        line["exact_fp32"] = {"value": H * W * args.exact_steps / t_exact, "unit": "rays/s", "steps": args.exact_steps,
-                              "warmup": 1, "ms_per_step": t_exact / args.exact_steps * 1e3, "dtype": "f32",
-                              "roofline": {"bound": "mfma", "kernel": "k_dvis_fused<fp32>", "achieved": e_tflops,
-                                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": e_tflops / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": e_ms, "launches": e_n},
-                              "max_rel_diff_of_split_precision_image": float(rel.max()),
-                              "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
-                              "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum()),
-                              "note": "same view and draws, every MLP on v_mfma_f32_16x16x4_f32; diff = |a-b|/(|b|+mean|b|) "
-                                      "over the 17 output channels of all rays; the outliers are rays where a sampled "
-                                      "direction sits on the n.d > 1e-6 cull (tests/test_precision_gpu.py anchors both modes "
-                                      "on a float64 evaluation of the reference's formulas)"}
-        sg_render.VIS_PRECISION = precision
-        os.environ["ROBIR_MLP_PRECISION"] = "f16x3"
+    if world == 1 and not args.no_legs and args.vis == "mlp":
+        # Side legs, each timed over its own loop: the same view and the same random draws in the other two precisions, and the
+        # distance of every image from the f32-input-MFMA one (|a-b| / (|b| + mean|b|) over the 17 channels of all rays).
+        images, legs = {}, {}
+        for name in ("fp32-mfma", "exact", "split"):
+            v_mode, m_mode, leg_dtype = set_precision(name, None if name != args.precision else
+                                                      (os.environ.get("ROBIR_VIS_PRECISION") or args.vis_precision))
+            torch.manual_seed(20260928)
+            images[name] = step()                           # also the warm-up of this precision (packs its weight blobs)
+            if name == args.precision:
+                continue
+            timer.pairs.clear()
+            timer.on = True
+            stats.clear()
+            t_leg, _ = timed(step, args.leg_steps)
+            timer.on = False
+            l_ms, l_n = timer.stats()
+            l_evals = int(stats["diffuse_vis_evals"]) if "diffuse_vis_evals" in stats else 0
+            legs[name] = {"value": H * W * args.leg_steps / t_leg, "unit": "rays/s", "steps": args.leg_steps, "warmup": 1,
+                          "ms_per_step": t_leg / args.leg_steps * 1e3, "dtype": leg_dtype,
+                          "roofline": vis_roofline(v_mode, l_ms, l_n, l_evals)}
+        ops.range_check(sync=True)
+        set_precision(args.precision, os.environ.get("ROBIR_VIS_PRECISION") or args.vis_precision)
+        ref_img = images["fp32-mfma"]
+        for name, img in images.items():
+            if name == "fp32-mfma":
+                continue
+            ok = torch.isfinite(ref_img).all(-1) & torch.isfinite(img).all(-1)
+            a, b = img[ok], ref_img[ok]
+            rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
+            d = {"max_rel_diff": float(rel.max()), "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
+                 "frac_entries_beyond_1e-5": float((rel > 1e-5).float().mean()), "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum())}
+            (legs[name] if name in legs else line.setdefault("headline_image", {}))["distance_from_fp32_mfma_image"] = d
+        line["legs"] = legs
+        line["legs_note"] = ("same view, same draws; outliers beyond 1e-3 are rays on which a sampled direction sits on the "
+                             "n.d > 1e-6 cull (tests/test_precision_gpu.py anchors the modes on a float64 evaluation)")
+    if world == 1 and not args.no_configs and args.vis == "mlp":
+        # The other BASELINE configurations, outside the timed region: at the headline precision and in split precision
+        bench_configs.install_timers()
+        cfgs = {}
+        n5 = args.config5_chunks or 125
+        for name in (args.precision, "split") if args.precision != "split" else ("split",):
+            set_precision(name)
+            with torch.no_grad():
+                res = []
+                for k in (1, 2, 3, 5):
+                    kw = dict(first=(1875 - n5) // 2, nch=n5) if k == 5 else {}
+                    r = bench_configs.CONFIGS[k](model, reps=2 if k != 5 else 1, **kw)
+                    r["dtype"] = PRECISIONS[name][2]
+                    res.append(r)
+            cfgs[name] = res
+        ops.range_check(sync=True)
+        set_precision(args.precision, os.environ.get("ROBIR_VIS_PRECISION") or args.vis_precision)
+        line["configs"] = cfgs
+        line["configs_note"] = ("BASELINE.json configs 1, 2, 3, 5 (tools/bench_configs.py), best of 2 repetitions after a warm-up "
+                                "(config 5: one pass over a band of chunks; `--config 5` times all 1875), single GPU, each with "
+                                "the roofline of the op that dominates it from HIP events around that op")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline_chunks, uv, pose, K)

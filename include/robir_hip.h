@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 3
+#define RB_ABI_VERSION 4
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -55,6 +55,11 @@ int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_
                      int scale_log2, float* out, rb_stream_t stream);
 int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
                   float w_scale, float* out, rb_stream_t stream);
+/* exact-operand packing ("f16x6"): every weight * 2^scale_log2 as three halves h, m, l with w = h + m 2^-11 + l 2^-22 exactly;
+ * chunk = 16 bias floats + [kb][h|m|l][lane][8 halves] = 16 + 24*k_pad floats; k_pad % 32 == 0. */
+long rb_packed_layer_x6_floats(int n_pad, int k_pad);
+int rb_pack_layer_x6(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* perm,
+                     int scale_log2, float* out, rb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Feature construction (positional encodings), accurate sinf/cosf.
@@ -167,11 +172,10 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
  *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
  *   precision 0: hidden layers on the f32-input MFMA (exact fp32 fma chain), Whid from rb_pack_layer;
- *   precision 1, 4, 5: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
- *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2.  5 = 1 tile per wave,
- *                2 workgroups per CU, LDS-DMA weight ring; 4 = same with register staging; 1 = 2 tiles per wave, one
- *                workgroup per CU.  All give identical results up to fp32 summation order.  The production path is
- *                rb_dvis_fused_v2 below.
+ *   precision 5: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
+ *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2: the first-generation kernel
+ *                (1 tile per wave, 2 workgroups per CU, LDS-DMA weight ring), kept as the independent implementation the
+ *                later generations are tested against.  The production paths are rb_dvis_fused_x6 / rb_dvis_fused_v2 below.
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, int direct, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream);
@@ -192,9 +196,12 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
 int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* rb_dvis_fused_v2 as eight waves of one 16-sample tile per workgroup (two waves per SIMD, csrc/vis_diffuse_v4.hip): same arguments,
- * bit-identical vis_out. */
-int rb_dvis_fused_v4(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+/* The same stage with EXACT fp32 operands on the f16 matrix pipe ("f16x6", csrc/vis_diffuse_x6.hip): every operand as three
+ * halves (h + m 2^-11 + l 2^-22 = the fp32 value exactly), the six partial products of weight >= 2^-22 in three fp32
+ * accumulators by weight class -- not narrower than the reference's fp32 (VisNetwork, model/implicit_differentiable_renderer.py:
+ * 241-258 evaluated by nn.Linear in fp32).  W49 = the same 49 chunks packed by rb_pack_layer_x6.  Same arguments as
+ * rb_dvis_fused_v2; vis_out agrees with precision 0 of rb_dvis_fused to fp32 summation order. */
+int rb_dvis_fused_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --

@@ -42,8 +42,9 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.rb_last_error.restype = ctypes.c_char_p
         _lib.rb_packed_layer_floats.restype = ctypes.c_long
+        _lib.rb_packed_layer_x6_floats.restype = ctypes.c_long
         _lib.rb_sdf_value_grad_scratch_floats.restype = ctypes.c_long
-        if _lib.rb_abi_version() != 3:
+        if _lib.rb_abi_version() != 4:
             raise RobirHipError("librobir_hip.so ABI version mismatch")
         if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
             _lib.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))

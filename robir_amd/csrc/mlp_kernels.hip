@@ -118,6 +118,48 @@ __global__ void k_pack_layer_h3(const float* __restrict__ W, const float* __rest
   }
 }
 
+// f16x6 packing (csrc/vis_diffuse_x6.hip): every weight as three halves, w 2^s = h + m 2^-11 + l 2^-22 exactly
+// (h, m round-to-nearest, the residuals are exact in fp32).  chunk jb = [bias*2^s (16 floats)] ++ [kb][piece h|m|l][lane][8 halves],
+// half slots mapped to input columns like the f16x3 layout above.
+__global__ void k_pack_layer_x6(const float* __restrict__ W, const float* __restrict__ b, int n_out, int k_in,
+                                int n_pad, int k_pad, const int* __restrict__ perm, float scale, float* __restrict__ out) {
+  const long chunk = 16 + (long)k_pad * 24;        // in floats (one float = two halves)
+  const long total = (long)(n_pad / 16) * chunk;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int jb = (int)(i / chunk);
+    const long o = i - (long)jb * chunk;
+    if (o < 16) {
+      const int j = jb * 16 + (int)o;
+      out[i] = (b != nullptr && j < n_out) ? b[j] * scale : 0.f;
+      continue;
+    }
+    const long q = o - 16;                         // [kb][piece][lane][4 floats = 8 halves]
+    const int pair = (int)(q & 3), lane = (int)((q >> 2) & 63), kp = (int)(q >> 8), kb = kp / 3, piece = kp - 3 * kb;
+    const int row = jb * 16 + (lane & 15), g = lane >> 4;
+    _Float16 hv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int j = pair * 2 + e;
+      const int k = 32 * kb + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+      float v = 0.f;
+      const int kin = perm ? perm[k] : k;
+      if (row < n_out && kin >= 0 && kin < k_in) v = W[(long)row * k_in + kin] * scale;
+      const _Float16 h = (_Float16)v;
+      const float r1 = (v - (float)h) * 2048.0f;   // exact
+      const _Float16 m = (_Float16)r1;
+      const float r2 = (r1 - (float)m) * 2048.0f;  // exact
+      hv[e] = piece == 0 ? h : (piece == 1 ? m : (_Float16)r2);
+    }
+    union {
+      _Float16 h[2];
+      float f;
+    } u;
+    u.h[0] = hv[0];
+    u.h[1] = hv[1];
+    out[i] = u.f;
+  }
+}
+
 // =====================================================================================================
 // Feature construction (positional encodings).  Accurate sinf/cosf: arguments reach 2^9*|x|.
 // PE layout (model/embedder.py:17-38): [x(3) | sin(2^0 x)(3) | cos(2^0 x)(3) | sin(2^1 x)(3) | ...].
@@ -760,6 +802,21 @@ int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_
   hipLaunchKernelGGL(k_pack_layer_h3, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, b, n_out, k_in, n_pad, k_pad,
                      perm, ldexpf(1.0f, scale_log2), out);
   return check_launch("k_pack_layer_h3");
+}
+
+long rb_packed_layer_x6_floats(int n_pad, int k_pad) { return (long)(n_pad / 16) * (16 + (long)k_pad * 24); }
+
+int rb_pack_layer_x6(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* perm,
+                     int scale_log2, float* out, rb_stream_t stream) {
+  RB_REQUIRE(W && out, "null pointer");
+  RB_REQUIRE(n_pad % 16 == 0 && k_pad % 32 == 0 && n_pad >= n_out && (perm || k_pad >= k_in), "bad padding");
+  RB_REQUIRE(scale_log2 >= -14 && scale_log2 <= 14, "scale_log2 out of range");
+  long total = rb_packed_layer_x6_floats(n_pad, k_pad);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_layer_x6, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, b, n_out, k_in, n_pad, k_pad,
+                     perm, ldexpf(1.0f, scale_log2), out);
+  return check_launch("k_pack_layer_x6");
 }
 
 int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_stream_t stream) {

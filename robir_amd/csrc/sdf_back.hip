@@ -166,8 +166,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back(long M, const f4* __restric
     lds_f4* slot0 = (lds_f4*)&sstg[pos & (SB_SS - 1)][0][tid];
     lds_f4* slot1 = (lds_f4*)&sstg[pos & (SB_SS - 1)][1][tid];
     f4 s0 = *slot0, s1 = *slot1;
-    while (__builtin_amdgcn_ballot_w64(!(fminf(fminf(fminf(s0[0], s0[1]), fminf(s0[2], s0[3])),
-                                                fminf(fminf(s1[0], s1[1]), fminf(s1[2], s1[3]))) >= 0.0f)) != 0ull) {
+    // "not arrived" = some component still holds the negative marker.  fminf skips NaN operands, so a row of NaN sigmoids
+    // (a NaN / inf input point: the value pass stores sigmoid(NaN)) counts as arrived -- `!(min >= 0)` would spin on it
+    // for ever -- and the NaN then flows into that point's gradient like everywhere else in the library.
+    while (__builtin_amdgcn_ballot_w64(fminf(fminf(fminf(s0[0], s0[1]), fminf(s0[2], s0[3])),
+                                              fminf(fminf(s1[0], s1[1]), fminf(s1[2], s1[3]))) < 0.0f) != 0ull) {
 #ifdef SB_DEBUG
       if (lane == 0) atomicAdd(&g_sb_spins, 1ull);
 #endif

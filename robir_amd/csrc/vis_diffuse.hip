@@ -269,8 +269,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                   int nsamp, int argmax_vis, int precision, int scale_log2, float* vis_out,
                   unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
-  RB_REQUIRE(precision == 0 || precision == 1 || precision == 4 || precision == 5,
-             "precision: 0 = fp32 MFMA; f16x3 split: 5 = LDS-DMA staging, 4 = register staging, 1 = two tiles per wave");
+  RB_REQUIRE(precision == 0 || precision == 5, "precision: 0 = fp32 MFMA; 5 = f16x3 split (first-generation kernel)");
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && Whid && wlast && blast && vis_out, "null pointer");
   RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= DV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
@@ -284,13 +283,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                      n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
                      ldexpf(1.0f, -scale_log2), vis_out, eval_count,                                                   \
                      range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr)
-    if (precision == 1) {
-      RB_LAUNCH_H3(2, 2);       // two tiles per wave, one workgroup per CU, register staging
-    } else if (precision == 4) {
-      RB_LAUNCH_H3(2, 1);       // one tile per wave, two workgroups per CU, register staging
-    } else {
-      RB_LAUNCH_H3(2, 1, true); // same, weights staged by LDS-DMA (global_load_lds)
-    }
+    RB_LAUNCH_H3(2, 1, true);   // one tile per wave, two workgroups per CU, weights staged by LDS-DMA (global_load_lds)
 #undef RB_LAUNCH_H3
   }
   return check_launch("k_dvis_fused");

@@ -137,6 +137,11 @@ SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB 
 _sdf_grad_scratch = {}
 
 
+def release_scratch():
+    """Drop the cached per-(device, stream) scratch of sdf_value_grad (8.9 GB per stream at the default slab)."""
+    _sdf_grad_scratch.clear()
+
+
 def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
     """All 257 outputs + d sdf / dx by the reverse-mode pass: x [M,3] -> out [M,257], grad [M,3]."""
     wb, w8 = back
@@ -247,9 +252,8 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
     return dirs, wdir, wsum
 
 
-DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream", "f16x3-v2": "k_dvis_v2",
-                     "f16x3-v4": "k_dvis_v4",
-                     "f16x3": "k_dvis_fused<H3>"}
+DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
+                     "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
 
 
 DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
@@ -258,19 +262,19 @@ DVIS_STREAM_MAX_POINTS = 8192     # "f16x3-auto": launches up to this many surfa
 
 def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,
                precision="fp32"):
-    """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain) or 'f16x3' (split-precision, ~2^-22 relative)."""
+    """precision: 'fp32' (f32-input MFMA, exact fp32 fma chain), 'f16x6' (exact fp32 operands as three halves each, six f16
+    MFMA products per multiply-add: not narrower than fp32) or 'f16x3*' (split precision, 22-bit operands, ~2^-22 relative)."""
     normals = _f32(normals)
     if precision == "f16x3-auto":
         # same arithmetic, bit-identical results: the streaming family balances small launches (a single 1024-pixel chunk) over
         # the CUs; at whole-view sizes the one-point-per-workgroup kernel is as fast and needs no scratch
         precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
     h3 = precision.startswith("f16x3")
-    assert h3 or precision == "fp32", precision
-    # "f16x3-v2" (default of sg_render) = second-generation kernel: two tiles per wave, one workgroup per CU, head on
-    # the matrix pipe (csrc/vis_diffuse_v2.hip);
-    # "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU, weights staged by LDS-DMA;
-    # "f16x3-regstage" = same with global->VGPR->LDS staging; "f16x3-nt2" = two tiles per wave, one workgroup per CU
-    code = {"fp32": 0, "f16x3-nt2": 1, "f16x3-regstage": 4, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x3-v4": 9}[precision]
+    assert h3 or precision in ("fp32", "f16x6"), precision
+    # "f16x3-v2" = second-generation split-precision kernel: two tiles per wave, one workgroup per CU, head on the matrix
+    # pipe (csrc/vis_diffuse_v2.hip); "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU,
+    # weights staged by LDS-DMA; "f16x6" = the v2 machine with exact three-piece operands (csrc/vis_diffuse_x6.hip)
+    code = {"fp32": 0, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x6": 10}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
@@ -290,9 +294,13 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
              c_int(split["h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
-    if precision in ("f16x3-v2", "f16x3-v4"):
-        # v4 = v2 as eight waves of one tile (two waves per SIMD, csrc/vis_diffuse_v4.hip): bit-identical
-        call("rb_dvis_fused_v2" if precision == "f16x3-v2" else "rb_dvis_fused_v4", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+    if precision == "f16x6":
+        call("rb_dvis_fused_x6", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+             ptr(split["hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
+        return out
+    if precision == "f16x3-v2":
+        call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
@@ -431,7 +439,12 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
     if n == 0:
         return out
     cap = n * LS
+    # group table size: groups per chunk from the largest chunk population (k_ovis_layout would truncate the table otherwise).
+    # Callers with chunks beyond 1024 points pass max_points_per_chunk; a count that cannot fit is caught here (host read
+    # only in that case)
     per_chunk = n if chunk_id is None else max_points_per_chunk
+    if chunk_id is not None and n > n_chunks * per_chunk:
+        per_chunk = int(torch.bincount(chunk_id.long()).max())
     max_groups = n_chunks * ((per_chunk * LS + batch_pairs - 1) // batch_pairs) + 1
     i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
     i64 = lambda m: torch.empty(m, dtype=torch.int64, device=dev)

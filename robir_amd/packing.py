@@ -79,6 +79,28 @@ def pack_layers_h3(layers, device, scale_log2=H3_SCALE_LOG2):
     return blob
 
 
+def pack_layers_x6(layers, device, scale_log2=H3_SCALE_LOG2):
+    """Exact-operand (f16x6) packing of 256-wide hidden layers: every weight as three halves (rb_pack_layer_x6)."""
+    L = _lib.lib()
+    sizes = [int(L.rb_packed_layer_x6_floats(l["n_pad"], l["k_pad"])) for l in layers]
+    blob = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    off, keep = 0, []
+    for l, sz in zip(layers, sizes):
+        W = l["W"].to(device=device, dtype=torch.float32).contiguous()
+        b = l["b"].to(device=device, dtype=torch.float32).contiguous() if l.get("b") is not None else None
+        wmax = float(W.abs().max()) * 2.0 ** scale_log2
+        if not wmax < 65504.0:
+            raise ValueError("exact-operand packing: |w| * 2^%d = %.3g exceeds the f16 range; run this network with "
+                             "ROBIR_VIS_PRECISION=fp32" % (scale_log2, wmax))
+        keep += [W, b]
+        _lib.call("rb_pack_layer_x6", _lib.ptr(W), _lib.ptr(b), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
+                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), ctypes.c_void_p(0), ctypes.c_int(scale_log2),
+                  ctypes.c_void_p(blob[off:off + sz].data_ptr()), _lib.stream_ptr())
+        off += sz
+    torch.cuda.current_stream().synchronize()
+    return blob
+
+
 def _t(sd, k):
     v = sd[k]
     return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
@@ -116,7 +138,10 @@ def pack_vis_split(sd, device):
     b_last = _t(sd, VIS + "8.bias").to(device=device, dtype=torch.float32).contiguous()        # [2]
     # 49 chunks: hidden stack + the output layer as one more 16-row chunk (rb_dvis_fused_v2)
     hid_h3_head = pack_layers_h3(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
+    # the same 49 chunks with every weight as three halves (rb_dvis_fused_x6: exact fp32 operands on the f16 MFMA)
+    hid_x6_head = pack_layers_x6(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
     return dict(point=wp, dir=wd, hidden=hid, hidden_h3=hid_h3, hidden_h3_head=hid_h3_head, h3_scale_log2=H3_SCALE_LOG2,
+                hidden_x6_head=hid_x6_head,
                 h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last)
 
 

@@ -97,7 +97,10 @@ def render_view_sharded(model, uv, pose, K, hdr_shift, chunk=1024, draws_for=Non
         if is_ragged:                                           # its own lock-step batch, like the reference's last chunk
             t = torch.cat([t, t.new_zeros(chunk - t.shape[0], t.shape[1])])
         parts.append(t)
-    local = torch.cat(parts) if len(parts) != 1 else parts[0]
+    if not parts:                                               # fewer chunks than ranks: this rank only joins the gather
+        local = uv.new_zeros(0, 17)
+    else:
+        local = torch.cat(parts) if len(parts) != 1 else parts[0]
     if plan["world"] == 1:
         return local[:N]
     return gather_image(local, plan["n_chunks"], chunk, plan["interleave"])[:N]

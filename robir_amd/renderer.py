@@ -136,6 +136,9 @@ class IDRNetwork(nn.Module):
             spec = deferred.output_spec(trainstage, self.indirect_illum_network.num_lgt_sgs, hdr is not None)
             q = deferred.ChunkQueue(self, sig, spec, N, limit, pose, K, hdr is not None, uv.device,
                                     (trainstage, fun_spec, lin_diff, None, None, None))
+            # the signature identifies the caller's pose / intrinsics tensors by id(): keep them alive while the queue is, so
+            # that a freed tensor's id cannot come back as another view's pose at version 0
+            q.sources = (input["pose"], input["intrinsics"])
             self.__dict__["_pending"] = q
         slot = q.add(uv, mask, hdr)
         given = {"object_mask": mask}

@@ -22,14 +22,16 @@ from .octree_tracing import OctreeVisModel
 
 TINY_NUMBER = 1e-6
 OCTREE_VIS_BATCH = 2000000      # pairs per VisModel call of the reference (sg_render.py:158): one lock-step cast each
-# Arithmetic of the hidden layers of the fused light-visibility kernel: "fp32" = f32-input MFMA (bitwise an fp32 fma
-# chain); "f16x3-auto" (default) = split precision on the f16 MFMA (hi/lo half pairs, fp32 accumulate, ~2^-22 relative
-# error, measured parity identical to "fp32": tests/test_sg_gpu.py runs all of them, tests/test_precision_gpu.py anchors
-# both on float64) with the kernel generation picked by launch size: "f16x3-v3" (global tile list + persistent grid) for
-# small launches, "f16x3-v2" (one point per workgroup) for whole views -- bit-identical results; "f16x3" = first
-# generation; "f16x3-nt2*", "f16x3-regstage" = its register-blocking / staging variants.
+# Arithmetic of the hidden layers of the fused light-visibility kernel:
+#   "f16x6"      (default) exact fp32 operands as three halves each, the six partial products of weight >= 2^-22 on the f16
+#                MFMA in three fp32 accumulators (csrc/vis_diffuse_x6.hip): not narrower than the reference's fp32;
+#   "fp32"       f32-input MFMA (bitwise an fp32 fma chain): the same results to summation order at ~half the speed;
+#   "f16x3-auto" split precision (hi/lo half pairs = 22-bit operands, three products, ~2^-22 relative error; parity-tested
+#                throughput mode, tests/test_precision_gpu.py anchors it on float64) with the kernel generation picked by
+#                launch size: "f16x3-v3" (global tile list + persistent grid) for small launches, "f16x3-v2" (one point per
+#                workgroup) for whole views -- bit-identical to each other; "f16x3" = first generation.
 import os as _os
-VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x3-auto")
+VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x6")
 
 
 # ----------------------------------------------------------------------------------------- small public helpers

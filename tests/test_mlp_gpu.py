@@ -225,6 +225,44 @@ def test_sdf_value_grad_sizes_slabs_and_repeatability(dev, synth_weights, monkey
     ops.range_check(sync=True)
 
 
+_NAN_ROWS_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from robir_amd import ops, packing, synth
+dev = torch.device("cuda:0")
+sd = synth.synth_state_dict(0, variance=0.3)
+h3 = packing.pack_sdf_h3(sd, dev, full=True)
+back = packing.pack_sdf_back_h3(sd, dev)
+g = torch.Generator().manual_seed(3)
+n = 40000
+x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.7).to(dev)
+clean_o, clean_g = ops.sdf_value_grad(x, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+bad = x.clone()
+bad[1000:1100] = float("nan")                 # 100 consecutive NaN points: whole 32-point wave blocks of NaN sigmoid rows
+bad[5000:5040, 1] = float("inf")
+bad[20000] = float("nan")                     # and a single one inside a tile
+o, gr = ops.sdf_value_grad(bad, n, h3, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+torch.cuda.synchronize()
+isbad = torch.zeros(n, dtype=torch.bool, device=dev)
+isbad[1000:1100] = True; isbad[5000:5040] = True; isbad[20000] = True
+assert bool(torch.isnan(o[isbad]).all(-1).all()) and bool(torch.isnan(gr[isbad]).all(-1).all()), "NaN rows must stay NaN"
+assert torch.equal(o[~isbad], clean_o[~isbad]) and torch.equal(gr[~isbad], clean_g[~isbad]), "other rows must not change"
+print("nan rows ok")
+"""
+
+
+def test_sdf_value_grad_nan_and_inf_rows_do_not_hang():
+    """The backward kernel detects the arrival of a sigmoid row from its content.  Rows of NaN sigmoids (NaN / inf input points:
+    all 128 samples of a ray that grazes a cell face) must count as arrived -- the first version spun on them for ever --
+    and must not disturb their neighbours.  Runs in a child process under a timeout so that a regression fails, not hangs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _NAN_ROWS_SCRIPT, root], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "nan rows ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_sdf_value_kernels_eight_and_four_waves_agree(dev, synth_weights):
     """Value rows (modes 0, 1, and the value pass + sigmoid blob of the reverse-mode gradient) as eight waves of one tile
     (csrc/sdf_ring8.hip, the default) and as four waves of two tiles (csrc/sdf_ring.hip): bit-identical outputs -- the blob through

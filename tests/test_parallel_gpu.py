@@ -103,3 +103,23 @@ def test_two_ranks_render_one_view_bit_identically(hw):
     assert res[0][3] + res[1][3] == n_chunks and abs(res[0][3] - res[1][3]) <= 1
     assert res[0][2] is True, "2-rank gathered image differs from the single-rank image"
     assert res[0][4] == res[1][4] and 0.2 < res[0][4] < 0.9          # both ranks hold the same full image
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from the plain driver command (no launcher, WORLD_SIZE unset): bench.py starts the two ranks
+    itself; on this one-GPU box they share cuda:0 over gloo, on a node the same entry uses RCCL.  One JSON line, two ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--precision", "split"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["value"] > 0
+    if torch.cuda.device_count() < 2:
+        assert d["config"]["ranks_share_one_gpu"] and d["config"]["collective_backend"] == "gloo"
+    assert "weak_views" in d and d["roofline"]["frac"] > 0
