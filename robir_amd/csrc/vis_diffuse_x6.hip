@@ -33,6 +33,16 @@ constexpr int X6_WF4 = 1536;             // weight part of a packed chunk: [kb 8
 constexpr int X6_CF4 = 4 + X6_WF4;       // packed chunk in global memory: 16 bias floats + weights
 constexpr int X6_SLOTS = 4, X6_DIST = 3;
 constexpr int X6_PIECES = 6;             // 4 KB rows (1 KB per wave) of one chunk copy
+#ifndef X6_VOFF
+#define X6_VOFF 1                        // 1: the six rows of a chunk copy addressed by per-row VGPR offsets (no scalar adds)
+#endif
+#ifndef X6_UNSCALE
+#define X6_UNSCALE 0                     // 0: weights packed with scale 2^0, no un-scaling multiply in the epilogue
+// (A/B on an MI355X, 32 chunks: both off 121 ms; per-row offsets alone 120.4; no un-scaling alone 120.1; the VGPR form of the MFMAs
+// alone (-amdgpu-mfma-vgpr-form, Makefile) 119.3; all three together 114.7 -- the three remove 30 of a chunk's 127 non-MFMA
+// instructions.  Unlike the (hi, lo) pairs of the f16x3 kernels the m and l pieces are re-scaled by 2^11 / 2^22, so the weights need
+// no power-of-two lift to keep them out of the f16 subnormal range: scale_log2 = 0.)
+#endif
 
 __device__ __forceinline__ void x6_dma16(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_uniform), "v"(lane_byte_off),
@@ -116,6 +126,14 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
     for (int i = 0; i < X6_PIECES; ++i)
       x6_dma16(chunk_weights_uniform + i * 256, lane_off, wave_lds + (unsigned)slot * 24576u + (unsigned)i * 4096u);
   };
+#if X6_VOFF
+  unsigned row_off[X6_PIECES];
+#pragma unroll
+  for (int i = 0; i < X6_PIECES; ++i) {
+    row_off[i] = lane_off + (unsigned)i * 4096u;
+    asm volatile("" : "+v"(row_off[i]));       // keep six registers: re-deriving them per copy is what this variant avoids
+  }
+#endif
   const u4* ring_u = reinterpret_cast<const u4*>(ring) + lane;
   // fragment (kb, piece) of a slot: ring_u[slot * X6_WF4 + (kb * 3 + piece) * 64]
   u4 wh[8], wm[8], wl[8];
@@ -150,8 +168,13 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
   auto ep_stage1 = [&](const X6Acc& acc, int q) {
     const float r0 = __builtin_fmaf(__builtin_fmaf(acc.c2[2 * q], C11, acc.c1[2 * q]), C11, acc.c0[2 * q]);
     const float r1 = __builtin_fmaf(__builtin_fmaf(acc.c2[2 * q + 1], C11, acc.c1[2 * q + 1]), C11, acc.c0[2 * q + 1]);
+#if X6_UNSCALE
     ev0[q] = fmaxf(r0 * w_unscale, 0.f);
     ev1[q] = fmaxf(r1 * w_unscale, 0.f);
+#else
+    ev0[q] = fmaxf(r0, 0.f);
+    ev1[q] = fmaxf(r1, 0.f);
+#endif
   };
   auto ep_stage2 = [&](int q) {
     const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ev0[q], ev1[q]));
@@ -238,7 +261,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
         // the three stages of the previous chunk's two register pairs.
 #define X6_RUN(ACC, WP, XP, K0) \
   _Pragma("unroll") for (int kb = (K0); kb < (K0) + 4; ++kb) X6_MFMA(ACC, WP[kb], XP[kb])
+#if X6_VOFF
+#define X6_COPY(I) x6_dma16(dsrc, row_off[I], ddst + (unsigned)(I) * 4096u)
+#else
 #define X6_COPY(I) x6_dma16(dsrc + (I) * 256, lane_off, ddst + (unsigned)(I) * 4096u)
+#endif
 #define X6_FENCE __builtin_amdgcn_sched_barrier(0)
         X6_RUN(acc.c2, wl, xh, 0);      // run A: wl.xh -> class 2
         X6_COPY(0);
@@ -367,6 +394,9 @@ extern "C" int rb_dvis_fused_x6(const float* normals, const int* chunk_id, long 
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
   RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= X6_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
+#if !X6_UNSCALE
+  RB_REQUIRE(scale_log2 == 0, "this build of k_dvis_x6 takes weights packed with scale_log2 = 0");
+#endif
   hipLaunchKernelGGL(k_dvis_x6, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, wdir,
                      wsum, (const f4*)W49, L, nsamp, argmax_vis, ldexpf(1.0f, -scale_log2), vis_out, eval_count,
                      range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr);

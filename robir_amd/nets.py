@@ -103,14 +103,7 @@ def _dev(module):
 
 
 # ----------------------------------------------------------------------------------------- visibility
-def mlp_precision():
-    """Arithmetic of the stand-alone MLP kernels: 'f16x3' (default; split-precision f16 MFMA, fp32 accumulate, ~2^-22
-    relative error) or 'fp32' (exact f32-input MFMA).  Environment: ROBIR_MLP_PRECISION."""
-    import os
-    p = os.environ.get("ROBIR_MLP_PRECISION", "f16x3")
-    if p not in ("f16x3", "fp32"):
-        raise ValueError("ROBIR_MLP_PRECISION must be f16x3 or fp32")
-    return p
+from .precision import mlp_precision  # noqa: E402,F401  ('fp32' under the default policy, 'f16x3' under ROBIR_PRECISION=split)
 
 
 class VisNetwork(nn.Module):

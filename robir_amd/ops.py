@@ -297,7 +297,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     if precision == "f16x6":
         call("rb_dvis_fused_x6", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
-             c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
+             c_int(split["x6_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
     if precision == "f16x3-v2":
         call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),

@@ -139,9 +139,10 @@ def pack_vis_split(sd, device):
     # 49 chunks: hidden stack + the output layer as one more 16-row chunk (rb_dvis_fused_v2)
     hid_h3_head = pack_layers_h3(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
     # the same 49 chunks with every weight as three halves (rb_dvis_fused_x6: exact fp32 operands on the f16 MFMA)
-    hid_x6_head = pack_layers_x6(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
+    x6_scale = 0         # the m / l pieces carry their own 2^11 / 2^22: no lift needed (csrc/vis_diffuse_x6.hip)
+    hid_x6_head = pack_layers_x6(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device, scale_log2=x6_scale)
     return dict(point=wp, dir=wd, hidden=hid, hidden_h3=hid_h3, hidden_h3_head=hid_h3_head, h3_scale_log2=H3_SCALE_LOG2,
-                hidden_x6_head=hid_x6_head,
+                hidden_x6_head=hid_x6_head, x6_head_scale_log2=x6_scale,
                 h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last)
 
 

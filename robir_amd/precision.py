@@ -1,0 +1,39 @@
+"""One switch for the arithmetic of every MLP kernel.
+
+  ROBIR_PRECISION=exact  (default)  not narrower than the reference's fp32: the fused light-visibility kernel carries every
+                                    fp32 operand exactly as three f16 pieces (six f16 MFMA products per multiply-add, three fp32
+                                    accumulators: csrc/vis_diffuse_x6.hip), every other MLP runs on the f32-input MFMA;
+  ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
+                                    2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
+                                    guarded by the activation-range sentinel (ops.range_check).
+ROBIR_VIS_PRECISION / ROBIR_MLP_PRECISION override the two halves of the policy separately (A/B runs, tests).
+"""
+import os
+
+POLICIES = {"exact": ("f16x6", "fp32"), "split": ("f16x3-auto", "f16x3")}
+VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3")
+
+
+def policy():
+    p = os.environ.get("ROBIR_PRECISION", "exact")
+    if p not in POLICIES:
+        raise ValueError("ROBIR_PRECISION must be exact or split")
+    return p
+
+
+def mlp_precision():
+    """Arithmetic of the stand-alone MLP kernels (SDF, colour, visibility, 512-wide nets): 'fp32' (f32-input MFMA) or
+    'f16x3' (split precision)."""
+    p = os.environ.get("ROBIR_MLP_PRECISION") or POLICIES[policy()][1]
+    if p not in ("f16x3", "fp32"):
+        raise ValueError("ROBIR_MLP_PRECISION must be f16x3 or fp32")
+    return p
+
+
+def vis_precision():
+    """Arithmetic of the fused light-visibility kernel at import time of robir_amd.sg_render (its VIS_PRECISION attribute is
+    what is read per call)."""
+    p = os.environ.get("ROBIR_VIS_PRECISION") or POLICIES[policy()][0]
+    if p not in VIS_MODES:
+        raise ValueError("ROBIR_VIS_PRECISION must be one of " + ", ".join(VIS_MODES))
+    return p

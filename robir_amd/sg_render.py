@@ -31,7 +31,8 @@ OCTREE_VIS_BATCH = 2000000      # pairs per VisModel call of the reference (sg_r
 #                launch size: "f16x3-v3" (global tile list + persistent grid) for small launches, "f16x3-v2" (one point per
 #                workgroup) for whole views -- bit-identical to each other; "f16x3" = first generation.
 import os as _os
-VIS_PRECISION = _os.environ.get("ROBIR_VIS_PRECISION", "f16x6")
+from .precision import vis_precision as _vis_precision
+VIS_PRECISION = _vis_precision()
 
 
 # ----------------------------------------------------------------------------------------- small public helpers

@@ -71,8 +71,13 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
 def test_mlp_precision_switch(monkeypatch):
     """ROBIR_MLP_PRECISION selects the arithmetic of the stand-alone MLP kernels; anything else is an error, not a guess."""
     from robir_amd import nets
+    from robir_amd import precision
     monkeypatch.delenv("ROBIR_MLP_PRECISION", raising=False)
-    assert nets.mlp_precision() == "f16x3"
+    monkeypatch.delenv("ROBIR_VIS_PRECISION", raising=False)
+    monkeypatch.delenv("ROBIR_PRECISION", raising=False)
+    assert nets.mlp_precision() == "fp32" and precision.vis_precision() == "f16x6"     # default policy: not narrower than fp32
+    monkeypatch.setenv("ROBIR_PRECISION", "split")
+    assert nets.mlp_precision() == "f16x3" and precision.vis_precision() == "f16x3-auto"
     monkeypatch.setenv("ROBIR_MLP_PRECISION", "fp32")
     assert nets.mlp_precision() == "fp32"
     monkeypatch.setenv("ROBIR_MLP_PRECISION", "bf16")

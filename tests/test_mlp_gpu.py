@@ -303,6 +303,7 @@ def test_eval_points_picks_the_reverse_mode_for_large_batches(dev, synth_weights
     calls = []
     real = ops.sdf_value_grad
     monkeypatch.setattr(ops, "sdf_value_grad", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", "f16x3")           # the reverse-mode pass exists in split precision
     o_r, g_r = net.eval_points(x, 2.0, 0.5, full=True, grad=True)
     assert calls == [1]
     net.eval_points(x[:1000], 2.0, 0.5, full=True, grad=True)    # small batches keep the forward-mode rows

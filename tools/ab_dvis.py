@@ -48,7 +48,7 @@ for rep in range(5):
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        o = ops.dvis_fused(nrm, cid, A, Bd, d_, w_, ws_, sp, 128, 32, argmax, None, precision="f16x3-v2")
+        o = ops.dvis_fused(nrm, cid, A, Bd, d_, w_, ws_, sp, 128, 32, argmax, None, precision=os.environ.get("AB_PRECISION", "f16x6"))
         e.record()
         torch.cuda.synchronize()
         if not argmax:
