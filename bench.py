@@ -85,6 +85,10 @@ def parse():
                          "for the extras of the default line)")
     ap.add_argument("--cpu-baseline-1thread-pixels", type=int, default=256,
                     help="pixels of the single-thread CPU baseline sample (the runners force torch.set_num_threads(1))")
+    ap.add_argument("--scene", default="sphere", choices=["sphere", "nonconvex"],
+                    help="synthetic SDF: the geometric-init sphere (default; the scene of every earlier round) or the non-convex "
+                         "fit of two spheres + a torus (robir_amd/data/nonconvex_sdf.npz); the default line carries the other "
+                         "scene as an extra")
     ap.add_argument("--vis-precision", default=None, choices=["fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3"],
                     help="override the light-visibility kernel of --precision (A/B runs)")
     ap.add_argument("--vis", default="mlp", choices=["mlp", "octree"],
@@ -290,7 +294,7 @@ def main():
     t0 = time.time()
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the octree build prints like the reference; stdout carries only the JSON line
-        model = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+        model = renderer.build_synthetic_model(dev, seed=0, variance=0.3, scene=args.scene)
     torch.cuda.synchronize()
     build_s = time.time() - t0
 
@@ -429,7 +433,7 @@ def main():
                                    "625 lock-step chunks of 1024 px, chunks sharded over the GPUs (c mod N), tiles all-gathered",
                        "image": [H, W], "chunk": CHUNK, "chunks_per_pass": args.chunks_per_batch,
                        "hit_fraction": round(hit_frac, 4), "octree_build_s": round(build_s, 2),
-                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "precision": args.precision,
+                       "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "precision": args.precision, "scene": args.scene,
                        "visibility_kernel": vis_mode, "mlp_kernels": mlp_mode,
                        "ranks": world, "collective_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
                        "ranks_share_one_gpu": os.environ.get("ROBIR_SHARE_GPU") == "1" and world > 1,
@@ -477,6 +481,24 @@ def main():
         line["legs"] = legs
         line["legs_note"] = ("same view, same draws; outliers beyond 1e-3 are rays on which a sampled direction sits on the "
                              "n.d > 1e-6 cull (tests/test_precision_gpu.py anchors the modes on a float64 evaluation)")
+    if world == 1 and not args.no_legs and args.vis == "mlp":
+        # The other synthetic scene at the headline precision (2 steps): hit fraction, visibility pairs per hit ray and rate
+        other = "nonconvex" if args.scene == "sphere" else "sphere"
+        with contextlib.redirect_stdout(sys.stderr):
+            model2 = renderer.build_synthetic_model(dev, seed=0, variance=0.3, scene=other)
+        st2 = {}
+
+        def step2():
+            return parallel.render_view_sharded(model2, uv_d, pose_d, K_d, hdr, CHUNK, stats=st2, plan=plan)
+        step2()
+        st2.clear()
+        t2, out2 = timed(step2, 2)
+        hits2 = float(out2[:, 16].sum())
+        line["other_scene"] = {"scene": other, "value": H * W * 2 / t2, "unit": "rays/s", "steps": 2, "ms_per_step": t2 / 2 * 1e3,
+                               "hit_fraction": hits2 / (H * W), "octree_nodes": model2.ray_tracer.sdf_octree.tables.B,
+                               "visibility_pairs_per_hit_ray": int(st2["diffuse_vis_evals"]) / 2 / max(hits2, 1.0),
+                               "this_scene_pairs_per_hit_ray": evals / max(args.steps, 1) / max(hit_frac * H * W, 1.0)}
+        del model2
     if world == 1 and not args.no_configs and args.vis == "mlp":
         # The other BASELINE configurations, outside the timed region: at the headline precision and in split precision
         bench_configs.install_timers()

@@ -323,6 +323,8 @@ int rb_octree_cast_finish(const float* node, const float* nrm, long B, const flo
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv, long N, float* dirs,
                    rb_stream_t stream);
+/* the same arithmetic with pose[16] / K[9] in DEVICE memory (no host copy on the per-chunk path) */
+int rb_camera_rays_dev(const float* pose_dev, const float* K_dev, const float* uv, long N, float* dirs, rb_stream_t stream);
 int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,
                     float* pts, rb_stream_t stream);
 /* ACESToneMapping (model/color_correction.py:31-73,116-134): mode = op + 16 * curve; op 0 hdr2ldr, 1 ldr2hdr, 2 ldr2hdr(x^2.2);

@@ -32,6 +32,31 @@ __global__ void k_camera_rays(Cam c, const float* __restrict__ uv, long N, float
   dirs[3 * i + 2] = w[2] / n;
 }
 
+// the same with pose / intrinsics read from device memory (a per-chunk forward() must not wait for a device-to-host copy)
+__global__ void k_camera_rays_dev(const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ uv, long N,
+                                  float* __restrict__ dirs) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+  const float x = uv[2 * i], y = uv[2 * i + 1], z = 1.0f;
+  const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * z;
+  const float yl = (y - cy) / fy * z;
+  const float pc[4] = {xl, -yl, -z, 1.0f};
+  float w[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = pose[4 * r] * pc[0];
+    acc = acc + pose[4 * r + 1] * pc[1];
+    acc = acc + pose[4 * r + 2] * pc[2];
+    acc = acc + pose[4 * r + 3] * pc[3];
+    w[r] = acc - pose[4 * r + 3];
+  }
+  const float n = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
+  dirs[3 * i] = w[0] / n;
+  dirs[3 * i + 1] = w[1] / n;
+  dirs[3 * i + 2] = w[2] / n;
+}
+
 // points = origin (+ per-ray or shared) + t * dir      (implicit_differentiable_renderer.py:324)
 __global__ void k_points_along(const float* __restrict__ origins, int per_ray_origin, long batch,
                                const float* __restrict__ dirs, const float* __restrict__ t, long N,
@@ -240,6 +265,13 @@ int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv,
   c.cy = K_host[5];
   hipLaunchKernelGGL(k_camera_rays, grid1d(N, 256), dim3(256), 0, (hipStream_t)stream, c, uv, N, dirs);
   return check_launch("k_camera_rays");
+}
+
+int rb_camera_rays_dev(const float* pose_dev, const float* K_dev, const float* uv, long N, float* dirs, rb_stream_t stream) {
+  if (N <= 0) return 0;
+  RB_REQUIRE(pose_dev && K_dev && uv && dirs, "null pointer");
+  hipLaunchKernelGGL(k_camera_rays_dev, grid1d(N, 256), dim3(256), 0, (hipStream_t)stream, pose_dev, K_dev, uv, N, dirs);
+  return check_launch("k_camera_rays_dev");
 }
 
 int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,

@@ -28,7 +28,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_THREADS = 256;  // 4 waves of 64
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2, ACT_SOFTPLUS100 = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY02 = 2, ACT_SOFTPLUS100 = 3, ACT_SOFTPLUS100_FAST = 4 };
 
 __host__ __device__ constexpr int chunk_f4(int K) { return K > 0 ? 4 + K * 4 : 0; }  // float4s per chunk
 
@@ -59,6 +59,24 @@ __device__ __forceinline__ float softplus100(float z, float* dsig) {
   return bz > 20.0f ? z : sp;
 }
 
+// Softplus(beta=100) of the SPLIT-PRECISION kernels (22-bit operand pairs): log(1 + e) straight from the hardware log2, without the
+// log1p correction above and without clamping the exponent (an overflowing exp2 gives +inf, which only ever reaches the branch
+// the select discards; NaN still propagates).  6 vector ops + 2 transcendentals instead of 13 + 3.  The missing correction is an
+// ABSOLUTE error <= 2^-24 ln(2) / 100 = 4e-10 on activations whose operand pairs resolve 2^-25 / 64 = 5e-10 anyway: below what
+// this arithmetic carries.  The f32-input-MFMA kernels (the precision the reference has) keep softplus100<> above.
+constexpr float SP_T_PER_Z = 144.26950408889634074f;      // 100 log2(e): exp(100 z) = exp2(z * this)
+constexpr float SP_T_LINEAR = 28.853900817779268147f;     // 20 log2(e): beyond it softplus(z) = z (torch threshold = 20)
+constexpr float SP_LN2_OVER_100 = 0.0069314718055994530942f;
+__device__ __forceinline__ float softplus100_fast(float z, float* dsig) {
+  const float t = z * SP_T_PER_Z;
+  const float e = __builtin_amdgcn_exp2f(t);
+  const float u = 1.0f + e;
+  const float sp = __builtin_amdgcn_logf(u) * SP_LN2_OVER_100;        // v_log_f32 is log2
+  const bool lin = t > SP_T_LINEAR;
+  if (dsig) *dsig = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
+  return lin ? z : sp;
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fn(float z) {
   if constexpr (ACT == ACT_RELU) {
@@ -67,6 +85,8 @@ __device__ __forceinline__ float act_fn(float z) {
     return z > 0.0f ? z : 0.2f * z;
   } else if constexpr (ACT == ACT_SOFTPLUS100) {
     return softplus100<false>(z, nullptr);
+  } else if constexpr (ACT == ACT_SOFTPLUS100_FAST) {
+    return softplus100_fast(z, nullptr);
   } else {
     return z;
   }
@@ -584,9 +604,10 @@ __host__ __device__ constexpr long layer_f4() { return (long)(N / 16) * chunk_f4
 // Softplus(beta=100) of a layer's pre-activations (two tiles).  JVP: rows come in groups of four (value row + three tangent
 // rows of a point, lane & 3): the value row gets softplus, the tangent rows z' * sigmoid(100 z) with z read from the
 // value lane.  `zs` un-scales the MFMA result first (split-precision layers), `scale` scales the output (skip: 1/sqrt 2).
-template <int NREG, int HREG, bool JVP, bool PRECISE = false>
+template <int NREG, int HREG, bool JVP, bool PRECISE = false, bool FAST = false>
 __device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (&h)[2][HREG], int lane, float scale,
                                               float zs = 1.0f) {
+  auto sp_fn = [](float v, float* sig) { if constexpr (FAST) return softplus100_fast(v, sig); else return softplus100<PRECISE>(v, sig); };
   if constexpr (JVP) {
     const bool is_val = (lane & 3) == 0;
     const int src = lane & ~3;
@@ -597,7 +618,7 @@ __device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (
         const float zi = z[t][i] * zs;
         const float zv = __shfl(zi, src);
         float sig;
-        const float sp = softplus100<PRECISE>(zv, &sig);   // value row: softplus; tangent rows: z' * sigmoid(100 z)
+        const float sp = sp_fn(zv, &sig);   // value row: softplus; tangent rows: z' * sigmoid(100 z)
         const float v = is_val ? sp : zi * sig;
         h[t][i] = v * scale;
       }
@@ -605,7 +626,7 @@ __device__ __forceinline__ void softplus_into(const float (&z)[2][NREG], float (
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < NREG; ++i) h[t][i] = softplus100<PRECISE>(z[t][i] * zs, nullptr) * scale;
+      for (int i = 0; i < NREG; ++i) h[t][i] = sp_fn(z[t][i] * zs, nullptr) * scale;
   }
 }
 

@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
     ws.prime<chunk_f4(64)>(w0);
     dense_layer_h3<64, 256, 2, 256>(ws, w0, w1, ih, il, z, lane, bm);
   }
-  softplus_into<64, 64, JVP>(z, z, lane, 1.0f, zs);
+  softplus_into<64, 64, JVP, false, true>(z, z, lane, 1.0f, zs);
   split_operands<256, 64, 2>(z, xh, xl, asc);
 #pragma unroll 1
   for (int l = 0; l < 2; ++l) {
     dense_layer_h3<256, 256, 2, 256>(ws, w1 + l * LF, w1 + (l + 1) * LF, xh, xl, z, lane, bm);
-    softplus_into<64, 64, JVP>(z, z, lane, 1.0f, zs);
+    softplus_into<64, 64, JVP, false, true>(z, z, lane, 1.0f, zs);
     split_operands<256, 64, 2>(z, xh, xl, asc);
   }
   {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
     {
       float z3[2][52];
       dense_layer_h3<256, 208, 2, 288>(ws, w3, w4, xh, xl, z3, lane, bm);
-      softplus_into<52, 68, JVP>(z3, hs, lane, inv_sqrt2, zs);   // neurons 193..207 are padding: zero weights downstream
+      softplus_into<52, 68, JVP, false, true>(z3, hs, lane, inv_sqrt2, zs);   // neurons 193..207 are padding: zero weights downstream
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -114,12 +114,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
     split_operands<288, 68, 2>(hs, sh, sl, asc);
     dense_layer_h3<288, 256, 2, 256>(ws, w4, w5, sh, sl, z, lane, bm);
   }
-  softplus_into<64, 64, JVP>(z, z, lane, 1.0f, zs);
+  softplus_into<64, 64, JVP, false, true>(z, z, lane, 1.0f, zs);
   split_operands<256, 64, 2>(z, xh, xl, asc);
 #pragma unroll 1
   for (int l = 0; l < 3; ++l) {
     dense_layer_h3<256, 256, 2, 256>(ws, w5 + l * LF, w5 + (l + 1) * LF, xh, xl, z, lane, bm);
-    softplus_into<64, 64, JVP>(z, z, lane, 1.0f, zs);
+    softplus_into<64, 64, JVP, false, true>(z, z, lane, 1.0f, zs);
     split_operands<256, 64, 2>(z, xh, xl, asc);
   }
   float zo[2][NL / 4];
@@ -341,17 +341,17 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
   }
 #pragma unroll 1
   for (int l = 0; l < 2; ++l) {
-    act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+    act_split<512, 1, ACT_SOFTPLUS100_FAST>(z, zs, xh, xl, AS);
     dense_layer_h3<512, 512, 1, 512>(ws, w1 + l * LF, w1 + (l + 1) * LF, xh, xl, z, lane, AS);
   }
-  act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+  act_split<512, 1, ACT_SOFTPLUS100_FAST>(z, zs, xh, xl, AS);
   {
     float hs[1][K4 / 4];
     {
       float z3[1][N3P / 4];
       dense_layer_h3<512, N3P, 1, K4P>(ws, w3, w4, xh, xl, z3, lane, AS);
 #pragma unroll
-      for (int i = 0; i < N3P / 4; ++i) hs[0][i] = act_fn<ACT_SOFTPLUS100>(z3[0][i] * zs) * inv_sqrt2;
+      for (int i = 0; i < N3P / 4; ++i) hs[0][i] = act_fn<ACT_SOFTPLUS100_FAST>(z3[0][i] * zs) * inv_sqrt2;
     }
 #pragma unroll
     for (int i = 0; i < K0P / 4; ++i) hs[0][N3P / 4 + i] = x0[0][i] * inv_sqrt2;
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
   }
 #pragma unroll 1
   for (int l = 0; l < 3; ++l) {
-    act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+    act_split<512, 1, ACT_SOFTPLUS100_FAST>(z, zs, xh, xl, AS);
     dense_layer_h3<512, 512, 1, 512>(ws, w5 + l * LF, w5 + (l + 1) * LF, xh, xl, z, lane, AS);
   }
-  act_split<512, 1, ACT_SOFTPLUS100>(z, zs, xh, xl, AS);
+  act_split<512, 1, ACT_SOFTPLUS100_FAST>(z, zs, xh, xl, AS);
   float o[1][4];
   dense_layer_h3<512, 16, 1, 0>(ws, w8, nullptr, xh, xl, o, lane, AS);
   range_report(ws.sat, range_word);

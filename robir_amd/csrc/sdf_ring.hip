@@ -178,18 +178,18 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     float v0, v1;
     if constexpr (STORE) {
       float s0, s1;
-      v0 = softplus100<false>(z0, &s0);
-      v1 = softplus100<false>(z1, &s1);
+      v0 = softplus100_fast(z0, &s0);
+      v1 = softplus100_fast(z1, &s1);
       sstage[2 * q] = s0;
       sstage[2 * q + 1] = s1;
     } else if constexpr (JVP) {
       float s0, s1;
-      const float p0 = softplus100<false>(sr_quad0(z0), &s0), p1 = softplus100<false>(sr_quad0(z1), &s1);
+      const float p0 = softplus100_fast(sr_quad0(z0), &s0), p1 = softplus100_fast(sr_quad0(z1), &s1);
       v0 = is_val ? p0 : z0 * s0;
       v1 = is_val ? p1 : z1 * s1;
     } else {
-      v0 = softplus100<false>(z0, nullptr);
-      v1 = softplus100<false>(z1, nullptr);
+      v0 = softplus100_fast(z0, nullptr);
+      v1 = softplus100_fast(z1, nullptr);
     }
     split_pair_mix(v0 * sa, v1 * sa, hi, lo);
     sat = sat_acc(sat, hi);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
       b[r] = quad_bcast(qz[r], 0);
     }
     const float zk = qk == 0 ? b[0] : (qk == 1 ? b[1] : (qk == 2 ? b[2] : b[3]));
-    qsp = softplus100<false>(zk, &qsig);
+    qsp = softplus100_fast(zk, &qsig);
   };
   auto jvp_stage_b = [&](int jb, int t, float sa) {
     float v[4];
@@ -236,28 +236,27 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
       sat = sat_acc(sat, hi);
     }
   };
-  // Value rows, staged: softplus is a chain of three transcendentals (exp -> rcp, log) whose latencies an in-order wave waits out
-  // when the chain sits in one gap between MFMAs.  Cut at the transcendentals and spread over three consecutive k-block gaps
-  // (six MFMAs between the stages), the same operations in the same order (results unchanged bit for bit) issue without the
-  // stalls: stage 1 pre-activation + exponential, stage 2 reciprocal + logarithm, stage 3 combine, lift, split, store.
-  float pz[4][2], pe[4][2], pr[4][2], pl[4][2], pcr[4][2];      // per piece (tile, register pair) and element
-  auto val_stage1 = [&](const SrAcc& acc, int piece) {
+  // Value rows, staged: softplus is a chain of transcendentals (exp -> log, and rcp for the sigmoid) whose latencies an in-order
+  // wave waits out when the chain sits in one gap between MFMAs.  Cut at the transcendentals and spread over three consecutive
+  // k-block gaps (six MFMAs between the stages), the operations of softplus100_fast in the same order (bit-identical results)
+  // issue without the stalls: stage 1 pre-activation + exponential, stage 2 (reciprocal +) logarithm, stage 3 select, lift, split, store.
+  float pz[4][2], pt[4][2], pe[4][2], pr[4][2], pl[4][2];      // per piece (tile, register pair) and element
+  auto val_stage1 = [&](const SrAcc& acc, int piece) {         // softplus100_fast, cut at its transcendentals
     const int t = piece >> 1, q = piece & 1;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float z = acc.a[t][2 * q + e] * zs;
-      const float bz = 100.0f * z;
       pz[piece][e] = z;
-      pe[piece][e] = __builtin_amdgcn_exp2f((bz > 20.0f ? 20.0f : bz) * 1.44269504088896340736f);
+      pt[piece][e] = z * SP_T_PER_Z;
+      pe[piece][e] = __builtin_amdgcn_exp2f(pt[piece][e]);
     }
   };
   auto val_stage2 = [&](int piece) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float u = 1.0f + pe[piece][e];
-      pr[piece][e] = __builtin_amdgcn_rcpf(u);
-      pcr[piece][e] = pe[piece][e] - (u - 1.0f);
-      pl[piece][e] = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+      if constexpr (STORE) pr[piece][e] = __builtin_amdgcn_rcpf(u);
+      pl[piece][e] = __builtin_amdgcn_logf(u);
     }
   };
   auto val_stage3 = [&](int jb, int piece, float sa, int cb) {
@@ -265,10 +264,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     float v[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float z = pz[piece][e], bz = 100.0f * z;
-      const float sp = (pl[piece][e] + pcr[piece][e] * pr[piece][e]) * 0.01f;
-      v[e] = bz > 20.0f ? z : sp;
-      if constexpr (STORE) sstage[2 * q + e] = bz > 20.0f ? 1.0f : pe[piece][e] * pr[piece][e];
+      const bool lin = pt[piece][e] > SP_T_LINEAR;
+      const float sp = pl[piece][e] * SP_LN2_OVER_100;
+      v[e] = lin ? pz[piece][e] : sp;
+      if constexpr (STORE) sstage[2 * q + e] = lin ? 1.0f : pe[piece][e] * pr[piece][e];
     }
     unsigned hi, lo;
     split_pair_mix(v[0] * sa, v[1] * sa, hi, lo);

@@ -101,33 +101,32 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
   // ---- value rows, staged over three k-block gaps (sdf_ring.hip): per piece q = register pair (2q, 2q+1) of the tile
   f4 sstage = {0.f, 0.f, 0.f, 0.f};
   const f4* sig_round = sig;
-  float pz[2][2], pe[2][2], pr[2][2], pl[2][2], pcr[2][2];
-  auto val_stage1 = [&](const f4& acc, int q) {
+  float pz[2][2], pt[2][2], pe[2][2], pr[2][2], pl[2][2];
+  auto val_stage1 = [&](const f4& acc, int q) {                // softplus100_fast (mlp_engine.h), cut at its transcendentals
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float z = acc[2 * q + e] * zs;
-      const float bz = 100.0f * z;
       pz[q][e] = z;
-      pe[q][e] = __builtin_amdgcn_exp2f((bz > 20.0f ? 20.0f : bz) * 1.44269504088896340736f);
+      pt[q][e] = z * SP_T_PER_Z;
+      pe[q][e] = __builtin_amdgcn_exp2f(pt[q][e]);
     }
   };
   auto val_stage2 = [&](int q) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float u = 1.0f + pe[q][e];
-      pr[q][e] = __builtin_amdgcn_rcpf(u);
-      pcr[q][e] = pe[q][e] - (u - 1.0f);
-      pl[q][e] = __builtin_amdgcn_logf(u) * 0.69314718055994530942f;
+      if constexpr (STORE) pr[q][e] = __builtin_amdgcn_rcpf(u);
+      pl[q][e] = __builtin_amdgcn_logf(u);
     }
   };
   auto val_stage3 = [&](int jb, int q, float sa, int cb) {
     float v[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float z = pz[q][e], bz = 100.0f * z;
-      const float sp = (pl[q][e] + pcr[q][e] * pr[q][e]) * 0.01f;
-      v[e] = bz > 20.0f ? z : sp;
-      if constexpr (STORE) sstage[2 * q + e] = bz > 20.0f ? 1.0f : pe[q][e] * pr[q][e];
+      const bool lin = pt[q][e] > SP_T_LINEAR;
+      const float sp = pl[q][e] * SP_LN2_OVER_100;
+      v[e] = lin ? pz[q][e] : sp;
+      if constexpr (STORE) sstage[2 * q + e] = lin ? 1.0f : pe[q][e] * pr[q][e];
     }
     unsigned hi, lo;
     split_pair_mix(v[0] * sa, v[1] * sa, hi, lo);

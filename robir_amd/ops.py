@@ -488,8 +488,15 @@ def octree_cast_grouped(T, origins, dirs, group_start, max_iter=32):
 
 
 def camera_rays(pose, K, uv):
-    """pose [4,4], K [3,3] host-side tensors/arrays; uv [N,2] device."""
+    """pose [4,4], K [3,3]: host arrays, or device tensors (then they are read on the device: no blocking copy); uv [N,2] device."""
     import numpy as np
+    if isinstance(pose, torch.Tensor) and pose.is_cuda and isinstance(K, torch.Tensor) and K.is_cuda:
+        uv = _f32(uv)
+        N = uv.shape[0]
+        dirs = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
+        call("rb_camera_rays_dev", ptr(_f32(pose.detach()).reshape(16)), ptr(_f32(K.detach()).reshape(9)), ptr(uv), c_long(N),
+             ptr(dirs), stream_ptr())
+        return dirs
     p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).reshape(16))
     k = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(9))
     uv = _f32(uv)

@@ -213,10 +213,12 @@ class IDRNetwork(nn.Module):
                                lin_diff, draws, stats, albedo_ratio)
         dev = uv.device
         N = uv.shape[0]
-        pose_h = pose.detach().cpu().numpy()
         cam = pose[:3, 3].float().reshape(1, 3).contiguous()
         with torch.no_grad():
-            dirs = ops.camera_rays(pose_h, K.detach().cpu().numpy(), uv.float().contiguous())
+            if pose.is_cuda and K.is_cuda:        # read on the device: a .cpu() here would block every per-chunk forward()
+                dirs = ops.camera_rays(pose[:4, :4].float().contiguous(), K[:3, :3].float().contiguous(), uv.float().contiguous())
+            else:
+                dirs = ops.camera_rays(pose.detach().cpu().numpy(), K.detach().cpu().numpy(), uv.float().contiguous())
             if not self.use_octree:       # independent rays: the IDR tracer takes all chunks of the pass at once
                 _, hit, dist = self.ray_tracer(sdf=self.implicit_network.sdf_only, cam_loc=cam, object_mask=object_mask,
                                                ray_directions=dirs[None])
@@ -475,11 +477,11 @@ def hotdog_conf(use_octree=True):
     })
 
 
-def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True, use_octree=True):
+def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build_octrees=True, use_octree=True, scene="sphere"):
     """IDRNetwork with the synthetic weights of robir_amd.synth (the configuration tests and bench.py use)."""
     from . import synth
     import warnings
-    sd = synth.synth_state_dict(seed, variance=variance, sharp_light=sharp_light)
+    sd = synth.synth_state_dict(seed, variance=variance, sharp_light=sharp_light, scene=scene)
     with warnings.catch_warnings():      # the full state dict is loaded two lines down
         warnings.simplefilter("ignore", RuntimeWarning)
         model = IDRNetwork(hotdog_conf(use_octree))

@@ -1,0 +1,217 @@
+"""The NON-CONVEX synthetic scene (two overlapping spheres + a torus, robir_amd/data/nonconvex_sdf.npz, recipe
+oracle/fit_nonconvex.py): the geometric-init sphere every other test renders is convex -- secondary rays almost never re-hit it,
+the lock-step schedules see the easy case, the encoding columns and the skip connection of the SDF network carry no weight.
+Here the cast, the traced visibility, trace_radiance and the whole Material forward run on a scene with concavities and a hole,
+against the REFERENCE's own outputs (tests/golden/nc_*.npz, oracle/gen_golden_r3.py) and against the oracle on the same cells."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, bad_frac, load_golden, oracle_tables_from_device, record_metric
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def nc_model(dev):
+    from robir_amd import renderer
+    return renderer.build_synthetic_model(dev, seed=0, variance=0.3, scene="nonconvex")
+
+
+@pytest.fixture(scope="module")
+def nc_sd():
+    from robir_amd import synth
+    from robir_oracle import nets
+    return nets.as_torch(synth.synth_state_dict(0, variance=0.3, scene="nonconvex"))
+
+
+def two_part(name, a, b, tol, frac, cap):
+    """At most `frac` of the entries beyond `tol` and none beyond `cap` (the outliers are rays on a hit / cull threshold)."""
+    f, m = bad_frac(a, b, tol), rel_err(a, b)
+    record_metric("nonconvex/" + name, tol=tol, frac=f, max=m, frac_limit=frac, cap=cap)
+    assert f <= frac and m <= cap, (name, "beyond", tol, ":", f, "max", m)
+
+
+def _inputs(dev, c):
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(64, 64)
+    sl = slice(c * 1024, (c + 1) * 1024)
+    return torch.from_numpy(uv[sl]).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+
+
+def test_sdf_network_carries_encoding_weight(nc_sd):
+    """What the fit changed: the encoding columns of layer 0 and of the skip layer are no longer zero."""
+    from robir_oracle import nets
+    w0, w4 = nets.wn_weight(nc_sd, nets.SDF + "lin0."), nets.wn_weight(nc_sd, nets.SDF + "lin4.")
+    assert float(w0[:, 3:].abs().max()) > 0.05 and float(w4[:, -60:].abs().max()) > 0.02
+
+
+def test_sdf_and_gradient_vs_oracle(dev, nc_model, nc_sd):
+    from robir_oracle import nets
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(20000, 3, generator=g) - 0.5) * 0.7
+    out = nc_model.implicit_network(x.to(dev)).cpu()
+    grad = nc_model.implicit_network.gradient(x.to(dev))[:, 0, :].cpu()
+    assert rel_err(out, nets.implicit_forward(nc_sd, x)) <= 1e-4
+    ref_g = nets.implicit_gradient(nc_sd, x)
+    assert rel_err(grad, ref_g) <= 1e-4 and float(ref_g.norm(dim=-1).std()) > 0.01
+
+
+def test_octree_build_close_to_reference(nc_model):
+    """Device build vs the reference's build of the same SDF: same size up to threshold cells."""
+    g = load_golden("nc_cast_primary")
+    T = nc_model.ray_tracer.sdf_octree.tables
+    node = T.node.cpu()
+    record_metric("nonconvex/octree", nodes=T.B, ref_nodes=int(g["oct_nodes"]), hit=int((node[:, 7] <= 1e-4).sum()), ref_hit=int(g["oct_hit"]))
+    assert abs(T.B - int(g["oct_nodes"])) <= 8 * 16                      # <= 16 cells split on one side only
+    assert abs(int((node[:, 7] <= 1e-4).sum()) - int(g["oct_hit"])) <= 64
+    assert abs(float(node[:, 7].double().abs().sum()) / float(g["oct_sdf_abs_sum"]) - 1.0) <= 1e-3
+
+
+def test_primary_cast_vs_reference_golden(dev, nc_model):
+    g = load_golden("nc_cast_primary")
+    tree = nc_model.ray_tracer.sdf_octree
+    cam, dirs = torch.from_numpy(g["cam"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
+    x, hit, t = tree.cast_chunks(cam, dirs, chunk=1024, sched_cap=128)
+    sched = tree.last_sched.cpu()
+    for i, c in enumerate((1, 2)):
+        sl = slice(i * 1024, (i + 1) * 1024)
+        rh, rt = torch.from_numpy(g["hit"][i]), torch.from_numpy(g["t"][i])
+        assert 300 < int(rh.sum()) < 900                                   # silhouette + hole: neither empty nor full
+        assert int((hit[sl].cpu() != rh).sum()) <= 4
+        both = hit[sl].cpu() & rh
+        two_part("cast_t_c%d" % c, t[sl].cpu()[both], rt[both], 1e-4, 0.01, 5e-2)
+        ref_m = [int(v) for v in g["sched_m_c%d" % c]]
+        got_m = [int(v) for v in sched[i, :len(ref_m), 1]]
+        # the schedule depends on the number of rays still active: identical unless a threshold ray flips
+        assert sum(a != b for a, b in zip(got_m, ref_m)) <= 3, (got_m, ref_m)
+
+
+def test_primary_and_secondary_cast_bit_parity_with_oracle_on_device_cells(dev, nc_model):
+    """Same cells (the device-built tables handed to the oracle), same rays: hits and the lock-step schedule exactly, t to 1e-6 --
+    primary chunk and a secondary batch that starts ON the surface (re-hits through the concavities)."""
+    from robir_amd import synth
+    from robir_oracle import octree as ooct, renderer as orend
+    tree = nc_model.ray_tracer.sdf_octree
+    T = oracle_tables_from_device(tree.tables)
+    uv, pose, K = synth.synth_camera(64, 64)
+    dirs, cam = orend.camera_rays(torch.from_numpy(uv[1024:2048])[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None])
+    log = []
+    xo, ho, to = ooct.trace(T, cam, dirs, -1, log)
+    x, hit, t = tree.cast_chunks(cam.to(dev), dirs[0].to(dev), chunk=1024, sched_cap=128)
+    sched = tree.last_sched.cpu()
+    assert bool((hit.cpu() == ho).all())
+    assert [int(v) for v in sched[0, :len(log), 1]] == [m for _, m in log]
+    assert rel_err(t.cpu(), to) <= 1e-6
+    # secondary: rays leaving surface points
+    sec = nc_model.octree_ray_tracer.sdf_octree
+    pts = xo[ho][:400]
+    g = torch.Generator().manual_seed(9)
+    d = torch.nn.functional.normalize(torch.randn(pts.shape[0], 3, generator=g), dim=-1)
+    t_o, h_o = ooct.cast(T, pts, d, 32)
+    _, h_d, t_d = sec.cast_full(pts.to(dev), d.to(dev))
+    assert bool((h_d.cpu() == h_o).all()) and rel_err(t_d.cpu(), t_o) <= 1e-6
+    assert 0.3 < float(h_o.float().mean()) < 0.9
+
+
+def test_octree_vis_model_rehits_vs_reference(dev, nc_model):
+    """OctreeVisModel on rays that LEAVE the surface: every hit is a re-hit (12 % on this scene, 0 on the sphere)."""
+    from robir_amd.octree_tracing import OctreeVisModel
+    g = load_golden("nc_octree_vis")
+    vis = OctreeVisModel(nc_model.octree_ray_tracer)
+    lg = vis(torch.from_numpy(g["direct_points"]).to(dev), torch.from_numpy(g["direct_dirs"]).to(dev)).cpu()
+    ref = torch.from_numpy(g["direct_logits"])
+    assert int(ref[:, 0].sum()) >= 40
+    assert int((lg != ref).any(-1).sum()) <= 4
+
+
+def test_trace_radiance_vs_reference_golden(dev, nc_model):
+    """Stage parity of trace_radiance (secondary cast, borrow_color at the secondary hits, visibility MLP) fed with the
+    reference's own Illum output; geometry = the device-built octree."""
+    g = load_golden("nc_trace_radiance")
+    fwd = {"points": torch.from_numpy(g["in_points"]).to(dev), "hdr_shift": torch.from_numpy(g["in_hdr_shift"]).to(dev),
+           "network_object_mask": torch.from_numpy(g["in_mask"]).to(dev), "normals": torch.from_numpy(g["in_normals"]).to(dev)}
+    out = nc_model.trace_radiance(fwd, nsamp=int(g["nsamp"]), draws=(torch.from_numpy(g["u1"]), torch.from_numpy(g["u2"])))
+    assert rel_err(out["sample_dirs"].cpu(), g["out_sample_dirs"]) <= 1e-5
+    n_sec = int(g["out_gt_vis"].sum())
+    assert n_sec > 2000
+    assert int((out["gt_vis"].cpu().numpy() != g["out_gt_vis"]).sum()) <= 12          # threshold rays of 5696
+    assert rel_err(out["pred_vis"].cpu(), g["out_pred_vis"]) <= 1e-4
+    two_part("trace_radiance", out["trace_radiance"].cpu(), g["out_trace_radiance"], 1e-3, 0.005, 2.0)
+    two_part("gt_integral", out["gt_integral"].cpu(), g["out_gt_integral"], 1e-3, 0.02, 0.5)
+
+
+def test_forward_material_vs_reference_golden(dev, nc_model):
+    """End to end (device-built octree) against the reference's forward('Material') with the PBR runner hook."""
+    g = load_golden("nc_forward_material")
+    c = int(g["chunk"])
+    uv_d, pose_d, K_d = _inputs(dev, c)
+    draws = {k[5:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("draw_")}
+    inp = {"uv": uv_d[None], "pose": pose_d[None], "intrinsics": K_d[None],
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+           "hdr_shift": torch.from_numpy(g["hdr_shift"]).expand(1024, 1).contiguous().to(dev)}
+    out = nc_model(inp, trainstage="Material", train_spec=True, draws=draws)
+    ref_mask = torch.from_numpy(g["out_network_object_mask"])
+    if int((out["network_object_mask"].cpu() != ref_mask).sum()) != 0:
+        pytest.skip("a threshold ray flipped the hit mask: the per-hit draws no longer line up with the reference's")
+    same = ref_mask
+    for k in ("points", "sdf_output"):
+        two_part("fwd/" + k, out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 1e-4, 0.01, 5e-2)
+    for k in ("diffuse_albedo", "roughness", "normal_map", "normals"):
+        two_part("fwd/" + k, out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 2e-3, 0.01, 0.5)
+    for k in ("sg_rgb", "indir_rgb", "vis_shadow", "sg_diffuse_rgb"):
+        two_part("fwd/" + k, out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 2e-3, 0.02, 1.0)
+
+
+def test_forward_material_vs_oracle_same_cells(dev, nc_model, nc_sd):
+    """The same forward against the ORACLE tracing the device-built cells with the same draws: chained tolerance."""
+    from robir_amd import synth
+    from robir_oracle import octree as ooct, renderer as orend
+    T = oracle_tables_from_device(nc_model.ray_tracer.sdf_octree.tables)
+    c = 2
+    uv, pose, K = synth.synth_camera(64, 64)
+    sl = slice(c * 1024, (c + 1) * 1024)
+    uv_t, pose_t, K_t = torch.from_numpy(uv[sl])[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None]
+    dirs, cam = orend.camera_rays(uv_t, pose_t, K_t)
+    _, hit, _ = ooct.trace(T, cam, dirs, -1)
+    dr = synth.pbr_draws(11, int(hit.sum()), chunk_id=c)
+    drt = {k: torch.from_numpy(v) for k, v in dr.items()}
+    hdr = torch.full((1024, 1), 0.5)
+    ref = orend.forward(nc_sd, T, uv_t, pose_t, K_t, torch.ones(1, 1024, dtype=torch.bool), hdr, drt, "Material", testing=True)
+    inp = {"uv": uv_t.to(dev), "pose": pose_t.to(dev), "intrinsics": K_t.to(dev),
+           "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev), "hdr_shift": hdr.to(dev)}
+    out = nc_model(inp, trainstage="Material", train_spec=True, draws={k: v.to(dev) for k, v in drt.items()})
+    assert bool((out["network_object_mask"].cpu() == ref["network_object_mask"]).all())
+    for k in ("points", "sdf_output", "diffuse_albedo", "roughness", "normal_map"):
+        two_part("oracle/" + k, out[k].cpu(), ref[k], 1e-4, 0.002, 2e-3)
+    for k in ("sg_rgb", "indir_rgb", "vis_shadow"):
+        two_part("oracle/" + k, out[k].cpu(), ref[k], 2e-4, 0.01, 5e-3)
+
+
+def test_full_view_statistics(dev, nc_model):
+    """800x800 of the non-convex scene through render_chunks: hit fraction, light-visibility pairs per hit ray, finite outputs,
+    run-to-run determinism under one seed (the numbers bench.py --scene nonconvex reports next to the sphere's)."""
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(400, 400)
+    uv_d, pose_d, K_d = torch.from_numpy(uv).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    hdr = torch.full((uv.shape[0], 1), 0.5, device=dev)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        stats = {}
+        o = nc_model.render_chunks(uv_d, pose_d, K_d, hdr, chunk=1024, stats=stats)
+        outs.append((o, int(stats["diffuse_vis_evals"])))
+    (a, ea), (b, eb) = outs
+    hit = a["network_object_mask"]
+    hf = float(hit.float().mean())
+    record_metric("nonconvex/view400", hit_fraction=hf, pairs_per_hit=ea / max(1, int(hit.sum())))
+    assert 0.2 < hf < 0.6 and ea == eb
+    for k in ("sg_rgb", "indir_rgb", "vis_shadow", "normal_map"):
+        assert torch.equal(a[k], b[k]), k
+        assert bool(torch.isfinite(a[k][hit]).all()), k
+    assert bool((a["sg_rgb"][~hit] == 1.0).all())
