@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Timing ablations (tools/ab_sdf.py; results are WRONG with any of them): -DS8_ABL_NOBAR no per-chunk barrier, -DS8_ABL_NODMA no
+// weight copies, -DS8_ABL_NOLDS one fragment read per chunk instead of sixteen, -DS8_ABL_NOVAL no softplus / split / output work.
 namespace rb {
 
 constexpr int S8_SLOT_B = 24 * 1024;
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
         if (allowed <= 2) s8_wait<2>(); else if (allowed == 3) s8_wait<3>(); else if (allowed == 4) s8_wait<4>();
         else if (allowed == 5) s8_wait<5>(); else s8_wait<6>();
       }
+#ifndef S8_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
       const u4* frag = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + sl[jb & 3]) + lane;
       const int n3 = jb + 3 < NCH ? NP : (jb + 3 == NCH ? NF0 : (jb + 3 == NCH + 1 ? NF1 : NF2));
@@ -193,14 +197,22 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         const h8 wh = __builtin_bit_cast(h8, wfa[kb % 3]), wlo = __builtin_bit_cast(h8, wfb[kb % 3]);
+#ifndef S8_ABL_NOLDS
         if (kb + 2 < KB) {
           wfa[(kb + 2) % 3] = frag[(2 * kb + 4) * 64];
           wfb[(kb + 2) % 3] = frag[(2 * kb + 5) * 64];
         }
+#else
+        if (kb + 2 < KB) {
+          wfa[(kb + 2) % 3] = wfa[kb % 3];
+          wfb[(kb + 2) % 3] = wfb[kb % 3];
+        }
+#endif
         const h8 a = __builtin_bit_cast(h8, xh[kb]), b = __builtin_bit_cast(h8, xl[kb]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a, acc, 0, 0, 0);
+#ifndef S8_ABL_NOVAL
         if (jb > 0) {
           const f4& prev = accs[(jb - 1) & 1];
           if constexpr (EPI == 2) {
@@ -218,9 +230,14 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
             if (kb == KB - 1) { val_stage1(prev, 1); val_stage2(1); val_stage3(jb - 1, 1, sa, cb); }
           }
         }
+#else
+        if (jb > 0 && kb == 0) { yh[(jb - 1) >> 1][0] ^= __builtin_bit_cast(unsigned, accs[(jb - 1) & 1][0]); }
+#endif
+#ifndef S8_ABL_NODMA
 #pragma unroll
         for (int d = 0; d < 3; ++d)
           if (d < n3 && (2 * d + 1 < KB ? 2 * d + 1 : KB - 1) == kb) s8_dma16(src3 + d * 512, lane16, dst3 + (unsigned)d * 8192u);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
