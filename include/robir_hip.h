@@ -121,8 +121,23 @@ long rb_sdf_value_grad_scratch_floats(long M);
 int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
                       float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
                       rb_stream_t stream);
+/* The same two ops with the positional encoding FUSED into the network kernel (SDFNetwork.forward = embed_fn + layers,
+ * model/neus_model.py:385-417; model/embedder.py:17-38): x [M,3] points, evaluated at x * in_scale -- no feature rows, no encoding
+ * kernel.  The four lanes that share a point evaluate its 30 sine / cosine pairs between them once per round (the sincosf calls of
+ * rb_feat_pe10), so outputs are bit-identical to the row forms above.
+ *   rb_sdf_points_ring        mode 0 = signed distance [M], 1 = all 257 outputs [M,257]          (= rb_feat_pe10 + rb_sdf_mlp_ring)
+ *   rb_sdf_value_grad_points  all outputs + d sdf / dx; grad_scale multiplies the gradient           (= rb_feat_pe10 + rb_sdf_value_grad) */
+int rb_sdf_points_ring(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
+                       float* out0, int n_workgroups, rb_stream_t stream);
+int rb_sdf_value_grad_points(const float* x, long M, float in_scale, const float* Wp, const float* Wb, const float* w8row,
+                             int scale_log2, float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                             int n_workgroups, rb_stream_t stream);
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream);
+/* rb_sdf_mlp with the positional encoding fused (every mode, tangent rows of the forward-mode gradient included): x [M,3],
+ * evaluated at x * in_scale; bit-identical to rb_feat_pe10 (jvp for modes 2, 3, 6) + rb_sdf_mlp. */
+int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float grad_scale,
+                      float* out0, float* grad, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);
@@ -134,6 +149,13 @@ int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, flo
 int rb_feat_color_tail(const float* x, float x_scale, const float* view, const float* normal, long M, float* tail, rb_stream_t stream);
 int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, const float* tail, long M, const float* Wp,
                         int scale_log2, float* rgb, rb_stream_t stream);
+/* The same with the 48 encoded columns computed IN the kernel from x / view / normal [M,3] (embedview_fn fused into the network,
+ * model/neus_model.py:535-545): no tail rows, no rb_feat_color_tail launch; bit-identical rgb. */
+int rb_color_mlp_h3_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                           const float* normal, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
+/* f32-input-MFMA form of the same (rb_feat_color + rb_color_mlp without the assembled [M,304] rows). */
+int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                        const float* normal, long M, const float* Wp, float* rgb, rb_stream_t stream);
 /* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
  * Wp packed [64->512, 512->512 x3, 512->144]. */
 /* Split-precision (f16x3) form of rb_illum_mlp (encoder = 0, raw[M,144]) and rb_ae_encode (encoder = 1, raw_latent[M,32]):

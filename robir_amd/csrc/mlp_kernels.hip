@@ -408,10 +408,32 @@ __global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restric
 // MODE 0: sdf only -> out0[M]          MODE 1: sdf+feat -> out0[M,257]
 // MODE 2: forward-mode jvp, sdf only: X[4M,64] (value row + 3 tangent rows per point); out0[M], grad[M,3]
 // MODE 3: forward-mode jvp, full:     X[4M,64]; out0[M,257], grad[M,3]
-template <int MODE, bool PRECISE = false>
+// FUSED: rows are not read but ENCODED HERE from the points xyz[M,3] (x in_scale): lane (n, g) evaluates the sixteen features
+// 16 kb + 4 g + r of its row with pe10_feature -- the function k_feat_pe10 fills the rows with, so the operands are bit-identical
+// (value rows and the three tangent rows of the forward-mode gradient alike).  On the f32-input MFMA the 32 sincosf per lane are
+// ~2 % of the kernel; the 256 B (1 KB with tangent rows) per point of feature rows and the encoding launch disappear.
+template <bool JVP>
+__device__ __forceinline__ void load_features_pe10(const float* __restrict__ xyz, float scale, long row, long MR, int lane,
+                                                   float (&in)[16]) {
+  const int g = lane >> 4;
+  const bool ok = row < MR;
+  const long i = ok ? (JVP ? row >> 2 : row) : 0;
+  const int tangent_of = JVP ? (int)(row & 3) - 1 : -1;
+  const float a[3] = {xyz[3 * i] * scale, xyz[3 * i + 1] * scale, xyz[3 * i + 2] * scale};
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    float v[4];
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) v[r] = pe10_feature(a, 16 * kb + 4 * g + r, tangent_of, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
+  }
+}
+
+template <int MODE, bool PRECISE = false, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
                                                      float out_scale, float grad_scale, float* __restrict__ out0,
-                                                     float* __restrict__ grad) {
+                                                     float* __restrict__ grad, float in_scale) {
   constexpr bool JVP = MODE >= 2;
   constexpr bool FULL = (MODE == 1 || MODE == 3);
   constexpr int NL = FULL ? 272 : 16;
@@ -430,8 +452,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
   const bool bias_on = JVP ? ((lane & 3) == 0) : true;
   const float inv_sqrt2 = 0.70710678118654752440f;
   float x0[2][16], ha[2][64], z[2][64];
-  load_features<64>(X, row0, MR, lane, x0[0]);
-  load_features<64>(X, row0 + 16, MR, lane, x0[1]);
+  if constexpr (FUSED) {                               // X = the points xyz[M,3]
+    load_features_pe10<JVP>(X, in_scale, row0, MR, lane, x0[0]);
+    load_features_pe10<JVP>(X, in_scale, row0 + 16, MR, lane, x0[1]);
+  } else {
+    load_features<64>(X, row0, MR, lane, x0[0]);
+    load_features<64>(X, row0 + 16, MR, lane, x0[1]);
+  }
   ws.prime<chunk_f4(64)>(w0);
   dense_layer<64, 256, 2, 256>(ws, w0, w1, x0, z, lane, bias_on);
   softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
@@ -502,8 +529,24 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
 }
 
 // ---- NeuS colour network (model/neus_model.py:535-560): 289(304) -> 256 x4 ReLU -> 3(16) -> sigmoid
+// FUSED: no assembled rows: the 256 feature columns are read in place from the SDF net's output rows and lane (n, g) ENCODES its
+// twelve tail columns [x * x_scale | PE4(view) | normal | 0 x15] itself (embedview_fn, model/neus_model.py:535-545; the sincosf
+// calls of write_pe<4>: bit-identical operands).
+__device__ __forceinline__ float color_tail_feature(const float* __restrict__ px, float x_scale, const float* __restrict__ pv,
+                                                    const float* __restrict__ pn, long i, int f) {
+  if (f < 3) return px[3 * i + f] * x_scale;
+  if (f < 6) return pv[3 * i + f - 3];
+  if (f >= 30) return f < 33 ? pn[3 * i + f - 30] : 0.f;
+  const int k = (f - 6) / 6, r = (f - 6) - 6 * k, c = r >= 3 ? r - 3 : r;
+  float sn, cs;
+  sincosf(pv[3 * i + c] * (float)(1 << k), &sn, &cs);
+  return r >= 3 ? cs : sn;
+}
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void k_color_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                       float* __restrict__ rgb) {
+                                                       float* __restrict__ rgb, const float* __restrict__ feat, long feat_stride,
+                                                       float feat_scale, const float* __restrict__ px, float x_scale,
+                                                       const float* __restrict__ pv, const float* __restrict__ pn) {
   __shared__ f4 lds[2 * chunk_f4(304)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<304> ws;
@@ -516,8 +559,31 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp(const float* __restrict__ 
   float h[2][64], z[2][64];
   {
     float in0[2][76];
-    load_features<304>(X, row0, M, lane, in0[0]);
-    load_features<304>(X, row0 + 16, M, lane, in0[1]);
+    if constexpr (FUSED) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const long row = row0 + 16 * t;
+        const bool ok = row < M;
+        const long rr = ok ? row : 0;
+        const float* pf = feat + rr * feat_stride + g * 4;
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in0[t][kb * 4 + r] = ok ? pf[kb * 16 + r] * feat_scale : 0.f;
+#pragma unroll 1
+        for (int kb = 0; kb < 3; ++kb) {
+          float v[4];
+#pragma unroll 1
+          for (int r = 0; r < 4; ++r) v[r] = color_tail_feature(px, x_scale, pv, pn, rr, 16 * kb + 4 * g + r);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) in0[t][64 + kb * 4 + r] = ok ? v[r] : 0.f;
+        }
+      }
+    } else {
+      load_features<304>(X, row0, M, lane, in0[0]);
+      load_features<304>(X, row0 + 16, M, lane, in0[1]);
+    }
     ws.prime<chunk_f4(304)>(w0);
     dense_layer<304, 256, 2, 256>(ws, w0, w1, in0, z, lane, true);
   }
@@ -888,21 +954,52 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
   switch (mode) {
-    case 0: hipLaunchKernelGGL(k_sdf_mlp<0>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    case 1: hipLaunchKernelGGL(k_sdf_mlp<1>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    case 2: hipLaunchKernelGGL(k_sdf_mlp<2>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    case 3: hipLaunchKernelGGL(k_sdf_mlp<3>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    case 4: hipLaunchKernelGGL((k_sdf_mlp<0, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
-    default: hipLaunchKernelGGL((k_sdf_mlp<2, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad); break;
+    case 0: hipLaunchKernelGGL(k_sdf_mlp<0>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
+    case 1: hipLaunchKernelGGL(k_sdf_mlp<1>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
+    case 2: hipLaunchKernelGGL(k_sdf_mlp<2>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
+    case 3: hipLaunchKernelGGL(k_sdf_mlp<3>, grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
+    case 4: hipLaunchKernelGGL((k_sdf_mlp<0, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
+    default: hipLaunchKernelGGL((k_sdf_mlp<2, true>), grid, block, 0, s, X, MR, W, out_scale, grad_scale, out0, grad, 1.0f); break;
   }
   return check_launch("k_sdf_mlp");
+}
+
+int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float grad_scale,
+                      float* out0, float* grad, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && out0, "null pointer");
+  RB_REQUIRE((mode >= 0 && mode <= 3) || mode == 4 || mode == 6, "mode must be 0..3, or 4 / 6 (= 0 / 2 with library-grade activations)");
+  RB_REQUIRE((mode & 3) < 2 || grad, "jvp modes need a gradient output");
+  const long MR = (mode & 3) >= 2 ? 4 * M : M;
+  dim3 grid = grid1d(MR, 128), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  const f4* W = (const f4*)Wp;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_sdf_mlp<0, false, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+    case 1: hipLaunchKernelGGL((k_sdf_mlp<1, false, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+    case 2: hipLaunchKernelGGL((k_sdf_mlp<2, false, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+    case 3: hipLaunchKernelGGL((k_sdf_mlp<3, false, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+    case 4: hipLaunchKernelGGL((k_sdf_mlp<0, true, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+    default: hipLaunchKernelGGL((k_sdf_mlp<2, true, true>), grid, block, 0, s, x, MR, W, out_scale, grad_scale, out0, grad, in_scale); break;
+  }
+  return check_launch("k_sdf_mlp<points>");
 }
 
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && rgb, "null pointer");
-  hipLaunchKernelGGL(k_color_mlp, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, rgb);
+  hipLaunchKernelGGL(k_color_mlp<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, rgb, nullptr, 0L, 1.0f,
+                     nullptr, 1.0f, nullptr, nullptr);
   return check_launch("k_color_mlp");
+}
+
+int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                        const float* normal, long M, const float* Wp, float* rgb, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
+  hipLaunchKernelGGL(k_color_mlp<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, nullptr, M, (const f4*)Wp, rgb, feat, feat_stride,
+                     feat_scale, x, x_scale, view, normal);
+  return check_launch("k_color_mlp<points>");
 }
 
 int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream) {

@@ -171,13 +171,20 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp_h3(const float* __restrict__
 // TWO: the 304 input columns come from two places -- columns 0..255 straight from the SDF net's output rows (feat, any row stride,
 // 4-byte aligned: rows of 257 floats), columns 256..303 from a 48-float tail row [x | PE4(view) | normal | 0 x15] (rb_feat_color_tail)
 // -- instead of a 1.2 KB row that rb_feat_color first copies together (19 ms of config 2 were that copy).  Same values, same order.
+// TWO = 2: the tail is not read either: [x * x_scale | PE4(view) | normal | 0 x15] is ENCODED IN THE KERNEL from pxyz / pview /
+// pnormal [M,3] (RenderingNetwork.forward = embedview_fn + layers, model/neus_model.py:535-560): the four lanes that share a row
+// evaluate its 12 (frequency, axis) sincosf pairs between them (the calls of k_feat_color_tail: bit-identical columns) and exchange
+// them through a 3 KB LDS scratch per tile.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-template <bool TWO>
+template <int TWO>
 __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict__ X, const float* __restrict__ feat, long feat_stride,
                                                           float feat_scale, long M, const f4* __restrict__ Wp, float us,
-                                                          float* __restrict__ rgb, unsigned* __restrict__ range_word) {
+                                                          float* __restrict__ rgb, unsigned* __restrict__ range_word,
+                                                          const float* __restrict__ pxyz, float x_scale,
+                                                          const float* __restrict__ pview, const float* __restrict__ pnormal) {
   constexpr float AS = 16.0f;
   __shared__ f4 lds[2 * chunk_f4(320)];
+  __shared__ float tail_lds[TWO == 2 ? 4 * 2 * 16 * 48 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<320> ws;
   ws.init(lds, tid);
@@ -191,14 +198,42 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict
   unsigned xh[2][8][4], xl[2][8][4];
   {
     float in0[2][76];
-    if constexpr (TWO) {
+    if constexpr (TWO != 0) {
       const int g = lane >> 4;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const long row = row0 + 16 * t;
         const bool ok = row < M;
         const float* pf = feat + (ok ? row : 0) * feat_stride + g * 4;
-        const f4* pt = reinterpret_cast<const f4*>(X + (ok ? row : 0) * 48) + g;
+        const f4* pt;
+        if constexpr (TWO == 2) {
+          float* trow = tail_lds + ((wave * 2 + t) * 16 + (lane & 15)) * 48;
+          const long rr = ok ? row : 0;
+          const float v[3] = {pview[3 * rr], pview[3 * rr + 1], pview[3 * rr + 2]};
+          if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              trow[c] = pxyz[3 * rr + c] * x_scale;
+              trow[3 + c] = v[c];
+              trow[30 + c] = pnormal[3 * rr + c];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) trow[33 + (g - 1) * 5 + i] = 0.f;
+          }
+#pragma unroll 1
+          for (int j = g; j < 12; j += 4) {         // write_pe<4>: frequency k = j / 3, axis c = j % 3
+            const int k = j / 3, c = j - 3 * k;
+            float sn, cs;
+            sincosf((c == 0 ? v[0] : (c == 1 ? v[1] : v[2])) * (float)(1 << k), &sn, &cs);
+            trow[6 + 6 * k + c] = sn;
+            trow[6 + 6 * k + 3 + c] = cs;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave, in-order LDS: all four lane groups have written
+          pt = reinterpret_cast<const f4*>(trow) + g;
+        } else {
+          pt = reinterpret_cast<const f4*>(X + (ok ? row : 0) * 48) + g;
+        }
 #pragma unroll
         for (int kb = 0; kb < 16; ++kb) {
           const f4u v = ok ? *reinterpret_cast<const f4u*>(pf + kb * 16) : f4u{0.f, 0.f, 0.f, 0.f};
@@ -412,8 +447,9 @@ int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_l
 int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && rgb, "null pointer");
-  hipLaunchKernelGGL(k_color_mlp_h3<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, nullptr, 0L, 1.0f, M, (const f4*)Wp,
-                     ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
+  hipLaunchKernelGGL(k_color_mlp_h3<0>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, nullptr, 0L, 1.0f, M, (const f4*)Wp,
+                     ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr, nullptr, 1.0f, nullptr,
+                     nullptr);
   return check_launch("k_color_mlp_h3");
 }
 
@@ -421,9 +457,20 @@ int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, c
                         int scale_log2, float* rgb, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(feat && tail && Wp && rgb, "null pointer");
-  hipLaunchKernelGGL(k_color_mlp_h3<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, tail, feat, feat_stride, feat_scale, M,
-                     (const f4*)Wp, ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
+  hipLaunchKernelGGL(k_color_mlp_h3<1>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, tail, feat, feat_stride, feat_scale, M,
+                     (const f4*)Wp, ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr, nullptr, 1.0f,
+                     nullptr, nullptr);
   return check_launch("k_color_mlp_h3<two>");
+}
+
+int rb_color_mlp_h3_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                           const float* normal, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
+  hipLaunchKernelGGL(k_color_mlp_h3<2>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, nullptr, feat, feat_stride, feat_scale, M,
+                     (const f4*)Wp, ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr, x, x_scale,
+                     view, normal);
+  return check_launch("k_color_mlp_h3<points>");
 }
 
 int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, rb_stream_t stream) {

@@ -36,8 +36,8 @@
 
 namespace rb {
 
-int launch_sdf_ring_store(const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
-                          hipStream_t s);
+int launch_sdf_ring_store(const float* X, const float* xyz, float in_scale, long M, const f4* W, float us, float out_scale,
+                          float* out0, f4* sig, unsigned grid, hipStream_t s);
 
 constexpr int SB_SLOT_F4 = 1024;          // 16 KB per ring slot (K <= 256: four 4 KB DMA rows)
 constexpr int SB_NS = 4;                  // ring slots; a chunk is requested SB_NS - 1 iterations before its MFMAs
@@ -501,6 +501,28 @@ __global__ void k_pe_grad(const float* __restrict__ gfeat, const float* __restri
   grad[i] = acc * grad_scale;
 }
 
+// The same contraction with the encoding recomputed from the points (the fused form keeps no feature rows): the same sincosf of
+// the same argument as the features the value pass used.
+__global__ void k_pe_grad_points(const float* __restrict__ gfeat, const float* __restrict__ xyz, float in_scale, long M,
+                                 float grad_scale, float* __restrict__ grad) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= 3 * M) return;
+  const long m = i / 3;
+  const int c = (int)(i - 3 * m);
+  const float* gf = gfeat + m * 128;
+  const float a = xyz[i] * in_scale;
+  float acc = gf[c] + gf[64 + c];
+#pragma unroll 1
+  for (int k = 0; k < 10; ++k) {
+    const float f = (float)(1 << k);
+    float sn, cs;
+    sincosf(a * f, &sn, &cs);
+    const int is = 3 + 6 * k + c, ic = is + 3;
+    acc += f * ((gf[is] + gf[64 + is]) * cs - (gf[ic] + gf[64 + ic]) * sn);
+  }
+  grad[i] = acc * grad_scale;
+}
+
 }  // namespace rb
 
 using namespace rb;
@@ -510,11 +532,12 @@ extern "C" long rb_sdf_value_grad_scratch_floats(long M) {
   return rounds * (SB_SIG_ROUND_F4 * 4 + 128L * 128);
 }
 
-extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
-                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
-                                 rb_stream_t stream) {
+// X != nullptr: feature rows; X == nullptr: points xyz[M,3] x in_scale with the encoding fused into the value pass
+static int sdf_value_grad_impl(const float* X, const float* xyz, float in_scale, long M, const float* Wp, const float* Wb,
+                               const float* w8row, int scale_log2, float out_scale, float grad_scale, float* out0, float* grad,
+                               float* scratch, int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
-  RB_REQUIRE(X && Wp && Wb && w8row && out0 && grad && scratch, "null pointer");
+  RB_REQUIRE((X || xyz) && Wp && Wb && w8row && out0 && grad && scratch, "null pointer");
   const long rounds = (M + 127) / 128;
   if (n_workgroups <= 0) {
     static int cus = 0;
@@ -531,7 +554,7 @@ extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const 
   hipStream_t s = (hipStream_t)stream;
   f4* sig = reinterpret_cast<f4*>(scratch);
   float* gfeat = scratch + rounds * SB_SIG_ROUND_F4 * 4;
-  if (int rc = launch_sdf_ring_store(X, M, (const f4*)Wp, us, out_scale, out0, sig, grid, s)) return rc;
+  if (int rc = launch_sdf_ring_store(X, xyz, in_scale, M, (const f4*)Wp, us, out_scale, out0, sig, grid, s)) return rc;
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
   hipLaunchKernelGGL(k_sdf_back, dim3(grid), dim3(256), 0, s, M, (const f4*)Wb, w8row, us, sig, gfeat, rw);
   if (int rc = check_launch("k_sdf_back")) return rc;
@@ -558,6 +581,26 @@ extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const 
   }
 #endif
   const long n = 3 * M;
-  hipLaunchKernelGGL(k_pe_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, X, M, grad_scale, grad);
+  if (X) {
+    hipLaunchKernelGGL(k_pe_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, X, M, grad_scale, grad);
+  } else {
+    hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, xyz, in_scale, M, grad_scale, grad);
+  }
   return check_launch("k_pe_grad");
+}
+
+extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
+                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
+                                 rb_stream_t stream) {
+  RB_REQUIRE(X || M <= 0, "null pointer");
+  return sdf_value_grad_impl(X, nullptr, 1.0f, M, Wp, Wb, w8row, scale_log2, out_scale, grad_scale, out0, grad, scratch, n_workgroups,
+                             stream);
+}
+
+extern "C" int rb_sdf_value_grad_points(const float* x, long M, float in_scale, const float* Wp, const float* Wb, const float* w8row,
+                                        int scale_log2, float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                                        int n_workgroups, rb_stream_t stream) {
+  RB_REQUIRE(x || M <= 0, "null pointer");
+  return sdf_value_grad_impl(nullptr, x, in_scale, M, Wp, Wb, w8row, scale_log2, out_scale, grad_scale, out0, grad, scratch,
+                             n_workgroups, stream);
 }

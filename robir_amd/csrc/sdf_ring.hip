@@ -576,8 +576,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
 using namespace rb;
 
 namespace rb {
-int launch_sdf_ring8(int mode, const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
-                     hipStream_t s);
+int launch_sdf_ring8(int mode, const float* X, const float* xyz, float in_scale, long M, const f4* W, float us, float out_scale,
+                     float* out0, f4* sig, unsigned grid, hipStream_t s);
 int g_sdf_ring_waves = 8;     // value rows (modes 0, 1, 5): 8 = k_sdf_ring8 (two waves per SIMD), 4 = k_sdf_ring
 }  // namespace rb
 
@@ -610,7 +610,7 @@ extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
-  if (mode < 2 && rb::g_sdf_ring_waves == 8) return rb::launch_sdf_ring8(mode, X, M, W, us, out_scale, out0, nullptr, grid, s);
+  if (mode < 2 && rb::g_sdf_ring_waves == 8) return rb::launch_sdf_ring8(mode, X, nullptr, 1.0f, M, W, us, out_scale, out0, nullptr, grid, s);
   switch (mode) {
     case 0: hipLaunchKernelGGL(k_sdf_ring<0>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
     case 1: hipLaunchKernelGGL(k_sdf_ring<1>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
@@ -620,11 +620,34 @@ extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode
   return check_launch("k_sdf_ring");
 }
 
+// Value rows straight from the points (positional encoding fused into k_sdf_ring8): x[M,3], evaluated at x * in_scale.
+// mode 0 = signed distance only, 1 = all 257 outputs; results bit-identical to rb_feat_pe10 + rb_sdf_mlp_ring.
+extern "C" int rb_sdf_points_ring(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
+                                  float* out0, int n_workgroups, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && out0, "null pointer");
+  RB_REQUIRE(mode == 0 || mode == 1, "mode: 0 = signed distance, 1 = all 257 outputs (gradients: rb_sdf_value_grad_points)");
+  const long rounds = (M + 127) / 128;
+  if (n_workgroups <= 0) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
+      cus = prop.multiProcessorCount;
+    }
+    n_workgroups = cus;
+  }
+  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  return rb::launch_sdf_ring8(mode, nullptr, x, in_scale, M, (const f4*)Wp, ldexpf(1.0f, -scale_log2), out_scale, out0, nullptr, grid,
+                              (hipStream_t)stream);
+}
+
 namespace rb {
 // forward half of the reverse-mode gradient (sdf_back.hip): all outputs of M points + the sigmoid blob
-int launch_sdf_ring_store(const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
-                          hipStream_t s) {
-  if (g_sdf_ring_waves == 8) return launch_sdf_ring8(5, X, M, W, us, out_scale, out0, sig, grid, s);
+int launch_sdf_ring_store(const float* X, const float* xyz, float in_scale, long M, const f4* W, float us, float out_scale,
+                          float* out0, f4* sig, unsigned grid, hipStream_t s) {
+  if (g_sdf_ring_waves == 8 || !X) return launch_sdf_ring8(5, X, xyz, in_scale, M, W, us, out_scale, out0, sig, grid, s);
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
   hipLaunchKernelGGL(k_sdf_ring<5>, dim3(grid), dim3(256), 0, s, X, M, W, us, out_scale, 0.0f, out0, nullptr, rw, sig);
   return check_launch("k_sdf_ring<5>");

@@ -54,8 +54,15 @@ __device__ __forceinline__ void s8_wait() {
 }
 
 // MODE: 0 = signed distance only, 1 = all 257 outputs, 5 = all outputs + the sigmoid blob of the reverse-mode gradient
-template <int MODE>
-__global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ X, long M, const f4* __restrict__ Wp, float us,
+// FUSED: the positional encoding is computed HERE from the points xyz[M,3] (x in_scale) instead of being read as rows X[M,64]
+// (model/embedder.py:17-38 + model/neus_model.py:385-417 in one kernel): once per round the four lanes that share a point
+// evaluate its 30 (frequency, axis) sine / cosine pairs between them -- the same sincosf of the same argument as k_feat_pe10
+// (mlp_kernels.hip), so the features and everything downstream are bit-identical to the row form --, exchange them through a
+// 4 KB LDS scratch per wave and pick up their sixteen B-operand features.  8 x 16 x 30 sincosf per round of 142 chunks: 1 % of
+// the round; the 256 B per point of feature rows and the encoding kernel disappear.
+template <int MODE, bool FUSED>
+__global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ X, const float* __restrict__ xyz, float in_scale,
+                                                       long M, const f4* __restrict__ Wp, float us,
                                                        float out_scale, float* __restrict__ out0,
                                                        unsigned* __restrict__ range_word, f4* __restrict__ sig) {
   constexpr bool FULL = (MODE & 1) != 0;
@@ -66,6 +73,7 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
   constexpr float AS = 64.0f;
   __shared__ f4 ring[4 * S8_SLOT_B / 16];             // 96 KB
   __shared__ f4 bias_tab[NCHUNK * 4];
+  __shared__ float feat_lds[FUSED ? 8 * 16 * 64 : 4];   // FUSED: one 64-float encoding row per point of the round (32 KB)
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0 .. 7: rows wave * 16 .. + 15 of the round
   const long nrounds = (M + 127) >> 7;
@@ -92,12 +100,47 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
   f4 fraw[4];                          // input features of the NEXT round (prefetched)
   long rrow = 0;
 
+  float pxyz[3] = {0.f, 0.f, 0.f};     // FUSED: the NEXT round's point of this lane (prefetched like the rows)
+  bool pok = false;
   auto fetch_features = [&](long round) {
     const long row = round * 128 + wave * 16 + (lane & 15);
     const bool ok = round < nrounds && row < M;
-    const f4* p = reinterpret_cast<const f4*>(X + (ok ? row : 0) * 64) + g;
+    if constexpr (FUSED) {
+      const float* p = xyz + (ok ? row : 0) * 3;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) fraw[kb] = ok ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 3; ++c) pxyz[c] = p[c];
+      pok = ok;
+    } else {
+      const f4* p = reinterpret_cast<const f4*>(X + (ok ? row : 0) * 64) + g;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) fraw[kb] = ok ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // FUSED: encoding of this round's 16 points of the wave -> fraw (lane (n, g): features 16 kb + 4 g + r of point n).
+  // Lane group g evaluates the (frequency k, axis c) pairs j = g, g + 4, ... < 30 (j = 3 k + c) of its point.
+  auto encode_round = [&]() {
+    float* frow = feat_lds + (wave * 16 + (lane & 15)) * 64;
+    const float a[3] = {pxyz[0] * in_scale, pxyz[1] * in_scale, pxyz[2] * in_scale};
+    if (g == 0) {
+      frow[0] = a[0];
+      frow[1] = a[1];
+      frow[2] = a[2];
+      frow[63] = 0.f;
+    }
+#pragma unroll 1
+    for (int j = g; j < 30; j += 4) {
+      const int k = j / 3, c = j - 3 * k;
+      const float fr = (float)(1 << k);
+      float sn, cs;
+      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * fr, &sn, &cs);
+      frow[3 + 6 * k + c] = sn;
+      frow[3 + 6 * k + 3 + c] = cs;
+    }
+    // (same wave, in-order LDS: the reads below follow the writes of all four lane groups)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) fraw[kb] = pok ? fr4[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- value rows, staged over three k-block gaps (sdf_ring.hip): per piece q = register pair (2q, 2q+1) of the tile
@@ -175,8 +218,12 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
         const int n1 = jb + 1 < NCH ? NP : (jb + 1 == NCH ? NF0 : NF1);
         const int n2 = jb + 2 < NCH ? NP : (jb + 2 == NCH ? NF0 : (jb + 2 == NCH + 1 ? NF1 : NF2));
         const int allowed = n1 + n2;
+#ifndef S8_REGSTAGE
         if (allowed <= 2) s8_wait<2>(); else if (allowed == 3) s8_wait<3>(); else if (allowed == 4) s8_wait<4>();
         else if (allowed == 5) s8_wait<5>(); else s8_wait<6>();
+#else
+        (void)allowed;
+#endif
       }
 #ifndef S8_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
@@ -186,6 +233,15 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
       const int n3 = jb + 3 < NCH ? NP : (jb + 3 == NCH ? NF0 : (jb + 3 == NCH + 1 ? NF1 : NF2));
       const f4* src3 = src_of(jb + 3) + 4 + wave * 64;                       // this wave's first 1 KB slice of chunk jb+3
       const unsigned dst3 = ring_b + sl[(jb + 3) & 3] + (unsigned)wave * 1024u;
+#ifdef S8_REGSTAGE
+      // register staging instead of LDS-DMA: this wave's slices of chunk jb+3 are loaded at the top of chunk jb and stored into
+      // the ring slot of chunk jb-1 (free since this chunk's barrier) at its end; in-order LDS puts the stores ahead of the
+      // fragment reads of the next two chunks, whose waits therefore cover them before the barrier of chunk jb+3
+      f4 stg[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (d < n3) stg[d] = src3[d * 512 + lane];
+#endif
       // weight fragments: three k-blocks in registers, read two k-blocks (six MFMAs, ~100 cycles: the LDS latency) ahead
       u4 wfa[3], wfb[3];
       wfa[0] = frag[0];
@@ -234,9 +290,18 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
         if (jb > 0 && kb == 0) { yh[(jb - 1) >> 1][0] ^= __builtin_bit_cast(unsigned, accs[(jb - 1) & 1][0]); }
 #endif
 #ifndef S8_ABL_NODMA
+#ifdef S8_REGSTAGE
+        if (kb == KB - 1) {
+          f4* wdst = reinterpret_cast<f4*>(reinterpret_cast<char*>(ring) + sl[(jb + 3) & 3]) + wave * 64 + lane;
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            if (d < n3) wdst[d * 512] = stg[d];
+        }
+#else
 #pragma unroll
         for (int d = 0; d < 3; ++d)
           if (d < n3 && (2 * d + 1 < KB ? 2 * d + 1 : KB - 1) == kb) s8_dma16(src3 + d * 512, lane16, dst3 + (unsigned)d * 8192u);
+#endif
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -280,9 +345,19 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
     const int n = c < 2 ? NP_HEAD : 1;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
-      if (d < n) s8_dma16(Wp + s8_coff(c) + 4 + wave * 64 + d * 512, lane16, ring_b + slot_b[c] + (unsigned)wave * 1024u + (unsigned)d * 8192u);
+      if (d < n) {
+#ifdef S8_REGSTAGE
+        reinterpret_cast<f4*>(reinterpret_cast<char*>(ring) + slot_b[c])[wave * 64 + d * 512 + lane] = (Wp + s8_coff(c) + 4 + wave * 64 + d * 512)[lane];
+#else
+        s8_dma16(Wp + s8_coff(c) + 4 + wave * 64 + d * 512, lane16, ring_b + slot_b[c] + (unsigned)wave * 1024u + (unsigned)d * 8192u);
+#endif
+      }
   }
+#ifdef S8_REGSTAGE
+  __syncthreads();
+#else
   s8_wait<0>();
+#endif
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -291,6 +366,7 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
     rrow = round * 128 + wave * 16 + (lane & 15);
     if constexpr (STORE) sig_round = sig + round * (125L * 2 * 256);
     // ---- input features -> operands of layer 0 and the skip operands of layer 4
+    if constexpr (FUSED) encode_round();
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const f4 v = fraw[kb];
@@ -392,14 +468,26 @@ __global__ __launch_bounds__(512, 1) void k_sdf_ring8(const float* __restrict__ 
   __syncthreads();
 }
 
-int launch_sdf_ring8(int mode, const float* X, long M, const f4* W, float us, float out_scale, float* out0, f4* sig, unsigned grid,
-                     hipStream_t s) {
+// X != nullptr: feature rows X[M,64]; X == nullptr: points xyz[M,3] x in_scale, encoded in the kernel
+int launch_sdf_ring8(int mode, const float* X, const float* xyz, float in_scale, long M, const f4* W, float us, float out_scale,
+                     float* out0, f4* sig, unsigned grid, hipStream_t s) {
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
-  switch (mode) {
-    case 0: hipLaunchKernelGGL(k_sdf_ring8<0>, dim3(grid), dim3(512), 0, s, X, M, W, us, out_scale, out0, rw, sig); break;
-    case 1: hipLaunchKernelGGL(k_sdf_ring8<1>, dim3(grid), dim3(512), 0, s, X, M, W, us, out_scale, out0, rw, sig); break;
-    default: hipLaunchKernelGGL(k_sdf_ring8<5>, dim3(grid), dim3(512), 0, s, X, M, W, us, out_scale, out0, rw, sig); break;
+#define RB_S8(MODE, FUSED) \
+  hipLaunchKernelGGL((k_sdf_ring8<MODE, FUSED>), dim3(grid), dim3(512), 0, s, X, xyz, in_scale, M, W, us, out_scale, out0, rw, sig)
+  if (X) {
+    switch (mode) {
+      case 0: RB_S8(0, false); break;
+      case 1: RB_S8(1, false); break;
+      default: RB_S8(5, false); break;
+    }
+  } else {
+    switch (mode) {
+      case 0: RB_S8(0, true); break;
+      case 1: RB_S8(1, true); break;
+      default: RB_S8(5, true); break;
+    }
   }
+#undef RB_S8
   return check_launch("k_sdf_ring8");
 }
 

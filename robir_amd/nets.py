@@ -451,6 +451,13 @@ class SDFNetwork(nn.Module):
             # values once + one row vector back through the transposed layers, instead of three tangent rows per point
             return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
                                       out_scale)
+        if (not grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE
+                and ops.sdf_ring_waves() == 8):
+            # value rows straight from the points: positional encoding fused into the network kernel (csrc/sdf_ring8.hip)
+            return ops.sdf_points_h3(x, M, self.packed_h3(full), full, packing.H3_SCALE_LOG2, in_scale, out_scale), None
+        if ops.SDF_FUSED_PE and (precise or mlp_precision() == "fp32"):
+            # f32-input MFMA kernel with the encoding (tangent rows included) evaluated inside it
+            return ops.sdf_mlp_points(x, M, self.packed(full), mode, in_scale, out_scale, out_scale * in_scale)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
         if not precise and mlp_precision() == "f16x3":
             return ops.sdf_mlp_h3(X, M, self.packed_h3(full), mode, packing.H3_SCALE_LOG2, out_scale, out_scale * in_scale)
@@ -520,8 +527,12 @@ class RenderingNetwork(nn.Module):
     def forward(self, points, normals, view_dirs, feature_vectors, x_scale=1.0, feat_scale=1.0):
         forward_only_guard(self)
         if mlp_precision() == "f16x3":
-            return ops.color_mlp_h3_two(points, view_dirs, normals, feature_vectors, self.packed_h3(), packing.H3_SCALE_LOG2,
-                                        x_scale=x_scale, feat_scale=feat_scale)
+            fn = ops.color_mlp_h3_points if ops.SDF_FUSED_PE else ops.color_mlp_h3_two      # encoding inside the kernel | tail rows
+            return fn(points, view_dirs, normals, feature_vectors, self.packed_h3(), packing.H3_SCALE_LOG2,
+                      x_scale=x_scale, feat_scale=feat_scale)
+        if ops.SDF_FUSED_PE:
+            return ops.color_mlp_points(points, view_dirs, normals, feature_vectors, self.packed(), x_scale=x_scale,
+                                        feat_scale=feat_scale)
         X = ops.feat_color(points.float().contiguous(), view_dirs.float().contiguous(), normals.float().contiguous(),
                            feature_vectors, x_scale=x_scale, feat_scale=feat_scale)
         if mlp_precision() == "f16x3":

@@ -84,6 +84,17 @@ def color_mlp_h3_two(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_
     return rgb
 
 
+def color_mlp_h3_points(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_scale=1.0):
+    """The colour net with its encoding fused: feature columns read in place, [x | PE4(view) | normal] encoded inside the kernel."""
+    x, view, normal = _f32(x), _f32(view), _f32(normal)
+    assert feat.dtype == torch.float32 and feat.stride(-1) == 1
+    M = x.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    call("rb_color_mlp_h3_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
+         ptr(view), ptr(normal), c_long(M), ptr(blob), c_int(scale_log2), ptr(rgb), stream_ptr())
+    return rgb
+
+
 def vis_mlp(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 2, dtype=torch.float32, device=X.device)
@@ -114,6 +125,28 @@ def sdf_mlp(X, M, blob, mode, out_scale=1.0, grad_scale=1.0):
     return out0, grad
 
 
+def sdf_mlp_points(x, M, blob, mode, in_scale=1.0, out_scale=1.0, grad_scale=1.0):
+    """rb_sdf_mlp (f32-input MFMA) straight from the points: the encoding, tangent rows included, is evaluated inside the kernel."""
+    x = _f32(x)
+    full = mode in (1, 3)
+    out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
+    grad = torch.empty(M, 3, dtype=torch.float32, device=x.device) if (mode & 3) >= 2 else None
+    call("rb_sdf_mlp_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(mode), c_float(out_scale), c_float(grad_scale),
+         ptr(out0), ptr(grad), stream_ptr())
+    return out0, grad
+
+
+def color_mlp_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0):
+    """rb_color_mlp (f32-input MFMA) with the feature columns read in place and [x | PE4(view) | normal] encoded in the kernel."""
+    x, view, normal = _f32(x), _f32(view), _f32(normal)
+    assert feat.dtype == torch.float32 and feat.stride(-1) == 1
+    M = x.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    call("rb_color_mlp_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
+         ptr(view), ptr(normal), c_long(M), ptr(blob), ptr(rgb), stream_ptr())
+    return rgb
+
+
 import os as _os
 SDF_KERNEL = _os.environ.get("ROBIR_SDF_KERNEL", "ring")     # "ring" | "v1" (first-generation k_sdf_mlp_h3)
 
@@ -131,6 +164,19 @@ def sdf_mlp_h3(X, M, blob, mode, scale_log2, out_scale=1.0, grad_scale=1.0):
     return out0, grad
 
 
+SDF_FUSED_PE = _os.environ.get("ROBIR_SDF_FUSED_PE", "1") == "1"   # value rows / value+gradient straight from the points (csrc/sdf_ring8.hip)
+
+
+def sdf_points_h3(x, M, blob, full, scale_log2, in_scale=1.0, out_scale=1.0):
+    """SDF network on points x [M,3] (evaluated at x * in_scale) with the positional encoding fused into the kernel:
+    -> [M,257] (full) or [M].  Bit-identical to feat_pe10 + sdf_mlp_h3 (modes 1 / 0)."""
+    x = _f32(x)
+    out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
+    call("rb_sdf_points_ring", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_int(scale_log2),
+         c_float(out_scale), ptr(out0), c_int(0), stream_ptr())
+    return out0
+
+
 SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)
 SDF_GRAD_MIN_POINTS = 16384       # below this the three-launch reverse form does not pay (0.25 ms floor; measured crossover)
 SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB of scratch per point)
@@ -140,6 +186,11 @@ _sdf_grad_scratch = {}
 def release_scratch():
     """Drop the cached per-(device, stream) scratch of sdf_value_grad (8.9 GB per stream at the default slab)."""
     _sdf_grad_scratch.clear()
+
+
+def sdf_ring_waves():
+    """Current setting of rb_sdf_ring_waves (8 = csrc/sdf_ring8.hip, 4 = csrc/sdf_ring.hip) without changing it."""
+    return int(_lib.lib().rb_sdf_ring_waves(0))
 
 
 def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
@@ -155,11 +206,18 @@ def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
     scratch = _sdf_grad_scratch.get(key)
     if scratch is None or scratch.numel() < need:
         scratch = _sdf_grad_scratch[key] = torch.empty(need, dtype=torch.float32, device=x.device)
+    x = _f32(x)
+    fused = SDF_FUSED_PE and sdf_ring_waves() == 8      # the encoding is fused into the eight-wave kernel
     for a in range(0, M, slab):
         n = min(slab, M - a)
-        X = feat_pe10(x[a:a + n], scale=in_scale)
-        call("rb_sdf_value_grad", ptr(X), c_long(n), ptr(blob), ptr(wb), ptr(w8), c_int(scale_log2), c_float(out_scale),
-             c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), c_int(0), stream_ptr())
+        if fused:
+            call("rb_sdf_value_grad_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob), ptr(wb), ptr(w8),
+                 c_int(scale_log2), c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]),
+                 ptr(scratch), c_int(0), stream_ptr())
+        else:
+            X = feat_pe10(x[a:a + n], scale=in_scale)
+            call("rb_sdf_value_grad", ptr(X), c_long(n), ptr(blob), ptr(wb), ptr(w8), c_int(scale_log2), c_float(out_scale),
+                 c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), c_int(0), stream_ptr())
     return out0, grad
 
 

@@ -453,3 +453,74 @@ def test_side_streams_give_identical_results(dev, synth_weights, monkeypatch):
     a, b, c = outs[True][0], outs[False][0], outs[True][1]
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+def test_fused_positional_encoding_is_bit_identical_to_the_row_form(dev, synth_weights, monkeypatch):
+    """k_sdf_ring8<.., FUSED>: the SDF network straight from the points (encoding evaluated inside the kernel, once per round, by
+    the four lanes that share a point) against rb_feat_pe10 rows + the same kernel -- distance only, all 257 outputs and the
+    value + reverse-mode-gradient op; sizes that are not multiples of the 128-row round, one point, and weights whose encoding
+    columns carry real weight (the non-convex fit)."""
+    from robir_amd import ops, packing, synth
+    g = torch.Generator().manual_seed(31)
+    for sd in (synth_weights, synth.synth_state_dict(0, scene="nonconvex")):
+        full = packing.pack_sdf_h3(sd, dev, full=True)
+        dist = packing.pack_sdf_h3(sd, dev, full=False)
+        back = packing.pack_sdf_back_h3(sd, dev)
+        for n in (1, 127, 128, 1000, 40001):
+            x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.9).to(dev)
+            X = ops.feat_pe10(x, scale=2.0)
+            r0, _ = ops.sdf_mlp_h3(X, n, dist, 0, packing.H3_SCALE_LOG2, 0.5, 1.0)
+            r1, _ = ops.sdf_mlp_h3(X, n, full, 1, packing.H3_SCALE_LOG2, 0.5, 1.0)
+            f0 = ops.sdf_points_h3(x, n, dist, False, packing.H3_SCALE_LOG2, 2.0, 0.5)
+            f1 = ops.sdf_points_h3(x, n, full, True, packing.H3_SCALE_LOG2, 2.0, 0.5)
+            assert torch.equal(f0, r0) and torch.equal(f1, r1), n
+        x = ((torch.rand(50000, 3, generator=g) - 0.5) * 1.9).to(dev)
+        monkeypatch.setattr(ops, "SDF_FUSED_PE", True)
+        of, gf = ops.sdf_value_grad(x, 50000, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+        monkeypatch.setattr(ops, "SDF_FUSED_PE", False)
+        orow, grow = ops.sdf_value_grad(x, 50000, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
+        assert torch.equal(of, orow) and torch.equal(gf, grow)
+    ops.range_check(sync=True)
+
+
+def test_colour_net_with_fused_encoding_is_bit_identical(dev, synth_weights):
+    """k_color_mlp_h3<2>: [x | PE4(view) | normal] encoded inside the kernel against the tail-row form, ragged row counts."""
+    from robir_amd import ops, packing
+    blob = packing.pack_color_h3(synth_weights, dev)
+    g = torch.Generator().manual_seed(77)
+    for n in (1, 31, 128, 129, 5000):
+        x = ((torch.rand(n, 3, generator=g) - 0.5)).to(dev)
+        v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        out = torch.randn(n, 257, generator=g).to(dev)          # SDF-net rows: the 256 feature columns are read in place
+        a = ops.color_mlp_h3_two(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0)
+        b = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0)
+        assert torch.equal(a, b), n
+    ops.range_check(sync=True)
+
+
+def test_f32_kernels_with_fused_encoding_are_bit_identical(dev, synth_weights):
+    """rb_sdf_mlp_points (every mode: value rows, forward-mode tangent rows, library-grade activations) and rb_color_mlp_points
+    against the row forms they replace."""
+    from robir_amd import ops, packing, synth
+    g = torch.Generator().manual_seed(41)
+    for sd in (synth_weights, synth.synth_state_dict(0, scene="nonconvex")):
+        full, dist = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf(sd, dev, full=False)
+        for n in (1, 33, 130, 3000):
+            x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.9).to(dev)
+            for mode in (0, 1, 2, 3, 4, 6):
+                blob = full if mode in (1, 3) else dist
+                X = ops.feat_pe10(x, scale=2.0, jvp=(mode & 3) >= 2)
+                r0, rg = ops.sdf_mlp(X, n, blob, mode, 0.5, 1.0)
+                f0, fg = ops.sdf_mlp_points(x, n, blob, mode, 2.0, 0.5, 1.0)
+                assert torch.equal(f0, r0), (n, mode)
+                assert (rg is None and fg is None) or torch.equal(fg, rg), (n, mode)
+    cb = packing.pack_color(synth_weights, dev)
+    for n in (1, 31, 129, 2000):
+        x = (torch.rand(n, 3, generator=g) - 0.5).to(dev)
+        v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        out = torch.randn(n, 257, generator=g).to(dev)
+        a = ops.color_mlp(ops.feat_color(x, v, nr, out[:, 1:], x_scale=2.0, feat_scale=2.0), cb)
+        b = ops.color_mlp_points(x, v, nr, out[:, 1:], cb, x_scale=2.0, feat_scale=2.0)
+        assert torch.equal(a, b), n
