@@ -408,23 +408,67 @@ __global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restric
 // MODE 0: sdf only -> out0[M]          MODE 1: sdf+feat -> out0[M,257]
 // MODE 2: forward-mode jvp, sdf only: X[4M,64] (value row + 3 tangent rows per point); out0[M], grad[M,3]
 // MODE 3: forward-mode jvp, full:     X[4M,64]; out0[M,257], grad[M,3]
-// FUSED: rows are not read but ENCODED HERE from the points xyz[M,3] (x in_scale): lane (n, g) evaluates the sixteen features
-// 16 kb + 4 g + r of its row with pe10_feature -- the function k_feat_pe10 fills the rows with, so the operands are bit-identical
-// (value rows and the three tangent rows of the forward-mode gradient alike).  On the f32-input MFMA the 32 sincosf per lane are
-// ~2 % of the kernel; the 256 B (1 KB with tangent rows) per point of feature rows and the encoding launch disappear.
+// FUSED: rows are not read but ENCODED HERE from the points xyz[M,3] (x in_scale), cooperatively: the lanes that share a point
+// (four for value rows; sixteen when a tile holds the value row and the three tangent rows of four points) evaluate its 30
+// (frequency, axis) sincosf pairs between them -- the calls k_feat_pe10 fills the rows with, so the operands are bit-identical --
+// and exchange them through a 4 KB LDS scratch per tile (same wave, in-order LDS: no barrier).  8 resp. 2 sincosf per lane and
+// tile instead of a 256 B (1 KB with tangent rows) row per point and the encoding launch.
 template <bool JVP>
 __device__ __forceinline__ void load_features_pe10(const float* __restrict__ xyz, float scale, long row, long MR, int lane,
+                                                   float* __restrict__ scratch /* [16][64], private to this wave and tile */,
                                                    float (&in)[16]) {
-  const int g = lane >> 4;
+  const int n = lane & 15, g = lane >> 4;
   const bool ok = row < MR;
   const long i = ok ? (JVP ? row >> 2 : row) : 0;
-  const int tangent_of = JVP ? (int)(row & 3) - 1 : -1;
   const float a[3] = {xyz[3 * i] * scale, xyz[3 * i + 1] * scale, xyz[3 * i + 2] * scale};
+  float* frow = scratch + n * 64;
+  if constexpr (!JVP) {
+    if (g == 0) {
+      frow[0] = a[0];
+      frow[1] = a[1];
+      frow[2] = a[2];
+      frow[63] = 0.f;
+    }
 #pragma unroll 1
+    for (int j = g; j < 30; j += 4) {                 // pair j = 3 k + c
+      const int k = j / 3, c = j - 3 * k;
+      float sn, cs;
+      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * (float)(1 << k), &sn, &cs);
+      frow[3 + 6 * k + c] = sn;
+      frow[3 + 6 * k + 3 + c] = cs;
+    }
+  } else {
+    // rows 4q .. 4q+3 of the tile = (value, d/dx, d/dy, d/dz) of point q: tangent row c is zero except in the columns of axis c
+    const int tangent_of = (n & 3) - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) frow[16 * g + e] = 0.f;
+    if (g == 0) {
+      if (tangent_of < 0) {
+        frow[0] = a[0];
+        frow[1] = a[1];
+        frow[2] = a[2];
+      } else {
+        frow[tangent_of] = 1.f;
+      }
+    }
+    float* prow = scratch + (n & ~3) * 64;            // the value row of this lane's point; tangent row c is prow + 64 (c + 1)
+#pragma unroll 1
+    for (int j = (n & 3) * 4 + g; j < 30; j += 16) {
+      const int k = j / 3, c = j - 3 * k;
+      const float fr = (float)(1 << k);
+      float sn, cs;
+      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * fr, &sn, &cs);
+      prow[3 + 6 * k + c] = sn;
+      prow[3 + 6 * k + 3 + c] = cs;
+      prow[64 * (c + 1) + 3 + 6 * k + c] = fr * cs;
+      prow[64 * (c + 1) + 3 + 6 * k + 3 + c] = -fr * sn;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
+#pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
-    float v[4];
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) v[r] = pe10_feature(a, 16 * kb + 4 * g + r, tangent_of, 0.f);
+    const f4 v = fr4[kb * 4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
   }
@@ -453,8 +497,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
   const float inv_sqrt2 = 0.70710678118654752440f;
   float x0[2][16], ha[2][64], z[2][64];
   if constexpr (FUSED) {                               // X = the points xyz[M,3]
-    load_features_pe10<JVP>(X, in_scale, row0, MR, lane, x0[0]);
-    load_features_pe10<JVP>(X, in_scale, row0 + 16, MR, lane, x0[1]);
+    __shared__ float pe_scratch[4 * 2 * 16 * 64];      // 32 KB: one encoded tile per wave and tile
+    load_features_pe10<JVP>(X, in_scale, row0, MR, lane, pe_scratch + (wave * 2 + 0) * 1024, x0[0]);
+    load_features_pe10<JVP>(X, in_scale, row0 + 16, MR, lane, pe_scratch + (wave * 2 + 1) * 1024, x0[1]);
   } else {
     load_features<64>(X, row0, MR, lane, x0[0]);
     load_features<64>(X, row0 + 16, MR, lane, x0[1]);

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_mlp_gpu.py -x -q -m gpu -k "fused or bit_identical" > gpurun_out/s8_fused.log 2>&1; echo "fused rc $?"; tail -n 3 gpurun_out/s8_fused.log
+timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/s8_all_exact.log 2>&1; echo "exact rc $?"
+ROBIR_PRECISION=split timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/s8_all_split.log 2>&1; echo "split rc $?"
+timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/s8_bench.json 2> gpurun_out/s8_bench.err; echo "bench rc $?"
+tail -n 4 gpurun_out/s8_all_exact.log; tail -n 4 gpurun_out/s8_all_split.log; tail -n 3 gpurun_out/s8_bench.err
