@@ -126,9 +126,12 @@ int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, 
  * kernel.  The four lanes that share a point evaluate its 30 sine / cosine pairs between them once per round (the sincosf calls of
  * rb_feat_pe10), so outputs are bit-identical to the row forms above.
  *   rb_sdf_points_ring        mode 0 = signed distance [M], 1 = all 257 outputs [M,257]          (= rb_feat_pe10 + rb_sdf_mlp_ring)
+ *   rb_sdf_points_ring_jvp    mode 2 / 3 = the same + the forward-mode gradient (small batches)   (= rb_feat_pe10(jvp) + rb_sdf_mlp_ring)
  *   rb_sdf_value_grad_points  all outputs + d sdf / dx; grad_scale multiplies the gradient           (= rb_feat_pe10 + rb_sdf_value_grad) */
 int rb_sdf_points_ring(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
                        float* out0, int n_workgroups, rb_stream_t stream);
+int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
+                           float grad_scale, float* out0, float* grad, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_points(const float* x, long M, float in_scale, const float* Wp, const float* Wb, const float* w8row,
                              int scale_log2, float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
                              int n_workgroups, rb_stream_t stream);
@@ -138,6 +141,19 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
  * evaluated at x * in_scale; bit-identical to rb_feat_pe10 (jvp for modes 2, 3, 6) + rb_sdf_mlp. */
 int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float grad_scale,
                       float* out0, float* grad, rb_stream_t stream);
+/* The small MLPs that take an encoded point straight from the points (encoding fused, load_features_pe10x / load_features_vis in
+ * csrc/mlp_engine.h; each bit-identical to the row form named):
+ *   rb_vis_mlp_points / _h3_points   VisNetwork.forward(p, d): rep consecutive directions per point   (= rb_feat_vis + rb_vis_mlp[_h3])
+ *   rb_linear_pe10_256               the 64 -> 256 first-layer halves of the light-visibility net        (= rb_feat_pe10 + rb_linear_64_256)
+ *   rb_wide_mlp_points / _h3_points  64 -> 512 x4 nets on [PE10(x) | extra]: indirect-illumination lobes (extra = hdr_shift [M]) and
+ *                                    SparseAE encoders (extra NULL)                                       (= rb_feat_pe10 + rb_illum_mlp / rb_ae_encode / rb_wide_mlp_h3) */
+int rb_vis_mlp_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, rb_stream_t stream);
+int rb_vis_mlp_h3_points(const float* p, const float* d, long M, int rep, const float* Wp, int scale_log2, float* logits,
+                         rb_stream_t stream);
+int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_stream_t stream);
+int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, rb_stream_t stream);
+int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
+                          rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);

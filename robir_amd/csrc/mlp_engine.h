@@ -597,6 +597,122 @@ __device__ __forceinline__ void load_features(const float* __restrict__ X, long 
   }
 }
 
+// Positional encoding fused into the network kernels: rows are not read but ENCODED IN THE KERNEL from the points xyz[M,3] (x in_scale), cooperatively: the lanes that share a point
+// (four for value rows; sixteen when a tile holds the value row and the three tangent rows of four points) evaluate its 30
+// (frequency, axis) sincosf pairs between them -- the calls k_feat_pe10 (mlp_kernels.hip; model/embedder.py:17-38) fills the rows with, so the operands are bit-identical --
+// and exchange them through a 4 KB LDS scratch per tile (same wave, in-order LDS: no barrier).  8 resp. 2 sincosf per lane and
+// tile instead of a 256 B (1 KB with tangent rows) row per point and the encoding launch.
+// the 63 encoded columns of one point written by the four lanes (g = 0..3) that share its row: frow[0..62]
+__device__ __forceinline__ void pe10_coop_write(float* __restrict__ frow, const float (&a)[3], int g) {
+  if (g == 0) {
+    frow[0] = a[0];
+    frow[1] = a[1];
+    frow[2] = a[2];
+  }
+#pragma unroll 1
+  for (int j = g; j < 30; j += 4) {                 // pair j = 3 k + c
+    const int k = j / 3, c = j - 3 * k;
+    float sn, cs;
+    sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * (float)(1 << k), &sn, &cs);
+    frow[3 + 6 * k + c] = sn;
+    frow[3 + 6 * k + 3 + c] = cs;
+  }
+}
+// [PE10(p) | extra] rows of the 64-input nets (IndirctIllumNetwork: extra = hdr_shift; SparseAE encoders / light-visibility
+// first-layer halves: extra = 0), one 16-row tile: model/implicit_differentiable_renderer.py:199-222, model/sg_envmap_material.py:188-247
+__device__ __forceinline__ void load_features_pe10x(const float* __restrict__ xyz, const float* __restrict__ extra, long row, long M,
+                                                    int lane, float* __restrict__ scratch, float (&in)[16]) {
+  const int n = lane & 15, g = lane >> 4;
+  const bool ok = row < M;
+  const long i = ok ? row : 0;
+  const float a[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  float* frow = scratch + n * 64;
+  pe10_coop_write(frow, a, g);
+  if (g == 1) frow[63] = extra ? extra[i] : 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const f4 v = fr4[kb * 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
+  }
+}
+// [PE10(p) | PE10(d) | 0 0] rows of the visibility MLP (VisNetwork.forward, model/implicit_differentiable_renderer.py:250-256), one
+// 16-row tile; point of row i = i / rep (rep consecutive directions per point).  scratch [16][128].
+__device__ __forceinline__ void load_features_vis(const float* __restrict__ p, const float* __restrict__ d, int rep, long row, long M,
+                                                  int lane, float* __restrict__ scratch, float (&in)[32]) {
+  const int n = lane & 15, g = lane >> 4;
+  const bool ok = row < M;
+  const long i = ok ? row : 0, ip = i / rep;
+  const float a[3] = {p[3 * ip], p[3 * ip + 1], p[3 * ip + 2]};
+  const float b[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+  float* frow = scratch + n * 128;
+  pe10_coop_write(frow, a, g);
+  pe10_coop_write(frow + 63, b, g);
+  if (g == 2) {
+    frow[126] = 0.f;
+    frow[127] = 0.f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb) {
+    const f4 v = fr4[kb * 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
+  }
+}
+
+template <bool JVP>
+__device__ __forceinline__ void load_features_pe10(const float* __restrict__ xyz, float scale, long row, long MR, int lane,
+                                                   float* __restrict__ scratch /* [16][64], private to this wave and tile */,
+                                                   float (&in)[16]) {
+  const int n = lane & 15, g = lane >> 4;
+  const bool ok = row < MR;
+  const long i = ok ? (JVP ? row >> 2 : row) : 0;
+  const float a[3] = {xyz[3 * i] * scale, xyz[3 * i + 1] * scale, xyz[3 * i + 2] * scale};
+  float* frow = scratch + n * 64;
+  if constexpr (!JVP) {
+    pe10_coop_write(frow, a, g);
+    if (g == 1) frow[63] = 0.f;
+  } else {
+    // rows 4q .. 4q+3 of the tile = (value, d/dx, d/dy, d/dz) of point q: tangent row c is zero except in the columns of axis c
+    const int tangent_of = (n & 3) - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) frow[16 * g + e] = 0.f;
+    if (g == 0) {
+      if (tangent_of < 0) {
+        frow[0] = a[0];
+        frow[1] = a[1];
+        frow[2] = a[2];
+      } else {
+        frow[tangent_of] = 1.f;
+      }
+    }
+    float* prow = scratch + (n & ~3) * 64;            // the value row of this lane's point; tangent row c is prow + 64 (c + 1)
+#pragma unroll 1
+    for (int j = (n & 3) * 4 + g; j < 30; j += 16) {
+      const int k = j / 3, c = j - 3 * k;
+      const float fr = (float)(1 << k);
+      float sn, cs;
+      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * fr, &sn, &cs);
+      prow[3 + 6 * k + c] = sn;
+      prow[3 + 6 * k + 3 + c] = cs;
+      prow[64 * (c + 1) + 3 + 6 * k + c] = fr * cs;
+      prow[64 * (c + 1) + 3 + 6 * k + 3 + c] = -fr * sn;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const f4 v = fr4[kb * 4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
+  }
+}
+
 // float4s of one packed layer (N/16 chunks)
 template <int K, int N>
 __host__ __device__ constexpr long layer_f4() { return (long)(N / 16) * chunk_f4(K); }

@@ -338,9 +338,12 @@ __global__ void k_feat_color_tail(const float* __restrict__ x, float x_scale, co
 // =====================================================================================================
 
 // ---- visibility MLP: X[M,128] -> logits[M,2]   126(128) -> 256 x4 ReLU -> 2(16)
+// FUSED: X = points p, Xd = directions d (rep directions per point): [PE10(p) | PE10(d)] encoded in the kernel (load_features_vis).
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void k_vis_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                     float* __restrict__ Y) {
+                                                     float* __restrict__ Y, const float* __restrict__ Xd, int rep) {
   __shared__ f4 lds[2 * chunk_f4(256)];
+  __shared__ float pe_scratch[FUSED ? 4 * 2 * 16 * 128 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<256> ws;
   ws.init(lds, tid);
@@ -351,8 +354,13 @@ __global__ __launch_bounds__(256, 1) void k_vis_mlp(const float* __restrict__ X,
   float h[2][64], z[2][64];
   {
     float in0[2][32];
-    load_features<128>(X, row0, M, lane, in0[0]);
-    load_features<128>(X, row0 + 16, M, lane, in0[1]);
+    if constexpr (FUSED) {
+      load_features_vis(X, Xd, rep, row0, M, lane, pe_scratch + (wave * 2 + 0) * 2048, in0[0]);
+      load_features_vis(X, Xd, rep, row0 + 16, M, lane, pe_scratch + (wave * 2 + 1) * 2048, in0[1]);
+    } else {
+      load_features<128>(X, row0, M, lane, in0[0]);
+      load_features<128>(X, row0 + 16, M, lane, in0[1]);
+    }
     ws.prime<chunk_f4(128)>(wl0);
     dense_layer<128, 256, 2, 256>(ws, wl0, wl1, in0, z, lane, true);
   }
@@ -379,16 +387,24 @@ __global__ __launch_bounds__(256, 1) void k_vis_mlp(const float* __restrict__ X,
 
 // ---- single linear layer X[M,64] -> Y[M,256] (no activation); used to split the visibility net's first layer
 //      into a per-point and a per-direction half for the fused diffuse-visibility kernel.
+// FUSED: X = points / directions [M,3], encoded in the kernel.
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restrict__ X, long M,
                                                            const f4* __restrict__ Wp, float* __restrict__ Y) {
   __shared__ f4 lds[2 * chunk_f4(64)];
+  __shared__ float pe_scratch[FUSED ? 4 * 2 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<64> ws;
   ws.init(lds, tid);
   const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
   float in0[2][16], z[2][64];
-  load_features<64>(X, row0, M, lane, in0[0]);
-  load_features<64>(X, row0 + 16, M, lane, in0[1]);
+  if constexpr (FUSED) {
+    load_features_pe10x(X, nullptr, row0, M, lane, pe_scratch + (wave * 2 + 0) * 1024, in0[0]);
+    load_features_pe10x(X, nullptr, row0 + 16, M, lane, pe_scratch + (wave * 2 + 1) * 1024, in0[1]);
+  } else {
+    load_features<64>(X, row0, M, lane, in0[0]);
+    load_features<64>(X, row0 + 16, M, lane, in0[1]);
+  }
   ws.prime<chunk_f4(64)>(Wp);
   dense_layer<64, 256, 2, 0>(ws, Wp, nullptr, in0, z, lane, true);
   const int g = lane >> 4;
@@ -408,72 +424,7 @@ __global__ __launch_bounds__(256, 1) void k_linear_64_256(const float* __restric
 // MODE 0: sdf only -> out0[M]          MODE 1: sdf+feat -> out0[M,257]
 // MODE 2: forward-mode jvp, sdf only: X[4M,64] (value row + 3 tangent rows per point); out0[M], grad[M,3]
 // MODE 3: forward-mode jvp, full:     X[4M,64]; out0[M,257], grad[M,3]
-// FUSED: rows are not read but ENCODED HERE from the points xyz[M,3] (x in_scale), cooperatively: the lanes that share a point
-// (four for value rows; sixteen when a tile holds the value row and the three tangent rows of four points) evaluate its 30
-// (frequency, axis) sincosf pairs between them -- the calls k_feat_pe10 fills the rows with, so the operands are bit-identical --
-// and exchange them through a 4 KB LDS scratch per tile (same wave, in-order LDS: no barrier).  8 resp. 2 sincosf per lane and
-// tile instead of a 256 B (1 KB with tangent rows) row per point and the encoding launch.
-template <bool JVP>
-__device__ __forceinline__ void load_features_pe10(const float* __restrict__ xyz, float scale, long row, long MR, int lane,
-                                                   float* __restrict__ scratch /* [16][64], private to this wave and tile */,
-                                                   float (&in)[16]) {
-  const int n = lane & 15, g = lane >> 4;
-  const bool ok = row < MR;
-  const long i = ok ? (JVP ? row >> 2 : row) : 0;
-  const float a[3] = {xyz[3 * i] * scale, xyz[3 * i + 1] * scale, xyz[3 * i + 2] * scale};
-  float* frow = scratch + n * 64;
-  if constexpr (!JVP) {
-    if (g == 0) {
-      frow[0] = a[0];
-      frow[1] = a[1];
-      frow[2] = a[2];
-      frow[63] = 0.f;
-    }
-#pragma unroll 1
-    for (int j = g; j < 30; j += 4) {                 // pair j = 3 k + c
-      const int k = j / 3, c = j - 3 * k;
-      float sn, cs;
-      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * (float)(1 << k), &sn, &cs);
-      frow[3 + 6 * k + c] = sn;
-      frow[3 + 6 * k + 3 + c] = cs;
-    }
-  } else {
-    // rows 4q .. 4q+3 of the tile = (value, d/dx, d/dy, d/dz) of point q: tangent row c is zero except in the columns of axis c
-    const int tangent_of = (n & 3) - 1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) frow[16 * g + e] = 0.f;
-    if (g == 0) {
-      if (tangent_of < 0) {
-        frow[0] = a[0];
-        frow[1] = a[1];
-        frow[2] = a[2];
-      } else {
-        frow[tangent_of] = 1.f;
-      }
-    }
-    float* prow = scratch + (n & ~3) * 64;            // the value row of this lane's point; tangent row c is prow + 64 (c + 1)
-#pragma unroll 1
-    for (int j = (n & 3) * 4 + g; j < 30; j += 16) {
-      const int k = j / 3, c = j - 3 * k;
-      const float fr = (float)(1 << k);
-      float sn, cs;
-      sincosf((c == 0 ? a[0] : (c == 1 ? a[1] : a[2])) * fr, &sn, &cs);
-      prow[3 + 6 * k + c] = sn;
-      prow[3 + 6 * k + 3 + c] = cs;
-      prow[64 * (c + 1) + 3 + 6 * k + c] = fr * cs;
-      prow[64 * (c + 1) + 3 + 6 * k + 3 + c] = -fr * sn;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const f4* fr4 = reinterpret_cast<const f4*>(frow) + g;
-#pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
-    const f4 v = fr4[kb * 4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) in[kb * 4 + r] = ok ? v[r] : 0.f;
-  }
-}
-
+// FUSED: the rows are not read but encoded in the kernel from the points (mlp_engine.h: load_features_pe10).
 template <int MODE, bool PRECISE = false, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
                                                      float out_scale, float grad_scale, float* __restrict__ out0,
@@ -655,12 +606,14 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp(const float* __restrict__ 
 // ---- 512-wide nets, one 16-sample tile per wave.
 // ENC = false: IndirctIllumNetwork.lobe_layer  64 -> 512 x4 ReLU -> 144            (raw outputs [M,144])
 // ENC = true : SparseAE encoder                64 -> 512 x4 LeakyReLU(0.2) -> 32   (raw latent  [M,32])
-template <bool ENC>
+// FUSED: X = points [M,3], extra [M] or NULL = column 63 (hdr_shift of the indirect-illumination net): [PE10(x) | extra] encoded here.
+template <bool ENC, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_wide_mlp(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                      float* __restrict__ Y) {
+                                                      float* __restrict__ Y, const float* __restrict__ extra = nullptr) {
   constexpr int NO = ENC ? 32 : 144;
   constexpr int ACT = ENC ? ACT_LEAKY02 : ACT_RELU;
   __shared__ f4 lds[2 * chunk_f4(512)];
+  __shared__ float pe_scratch[FUSED ? 4 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<512> ws;
   ws.init(lds, tid);
@@ -672,7 +625,11 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp(const float* __restrict__ X
   float h[1][128], z[1][128];
   {
     float in0[1][16];
-    load_features<64>(X, row, M, lane, in0[0]);
+    if constexpr (FUSED) {
+      load_features_pe10x(X, extra, row, M, lane, pe_scratch + wave * 1024, in0[0]);
+    } else {
+      load_features<64>(X, row, M, lane, in0[0]);
+    }
     ws.prime<chunk_f4(64)>(w0);
     dense_layer<64, 512, 1, 512>(ws, w0, w1, in0, z, lane, true);
   }
@@ -977,15 +934,30 @@ int rb_feat_color_tail(const float* x, float x_scale, const float* view, const f
 int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && logits, "null pointer");
-  hipLaunchKernelGGL(k_vis_mlp, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, logits);
+  hipLaunchKernelGGL(k_vis_mlp<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, logits, nullptr, 1);
   return check_launch("k_vis_mlp");
+}
+
+int rb_vis_mlp_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(p && d && Wp && logits, "null pointer");
+  RB_REQUIRE(rep >= 1, "rep must be >= 1");
+  hipLaunchKernelGGL(k_vis_mlp<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, p, M, (const f4*)Wp, logits, d, rep);
+  return check_launch("k_vis_mlp<points>");
 }
 
 int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && Y, "null pointer");
-  hipLaunchKernelGGL(k_linear_64_256, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, Y);
+  hipLaunchKernelGGL(k_linear_64_256<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, Y);
   return check_launch("k_linear_64_256");
+}
+
+int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Y, "null pointer");
+  hipLaunchKernelGGL(k_linear_64_256<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, Y);
+  return check_launch("k_linear_64_256<points>");
 }
 
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
@@ -1052,6 +1024,17 @@ int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_
   RB_REQUIRE(X && Wp && raw, "null pointer");
   hipLaunchKernelGGL(k_wide_mlp<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, raw);
   return check_launch("k_wide_mlp<illum>");
+}
+
+int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Y, "null pointer");
+  if (encoder) {
+    hipLaunchKernelGGL((k_wide_mlp<true, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, Y, extra);
+  } else {
+    hipLaunchKernelGGL((k_wide_mlp<false, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, Y, extra);
+  }
+  return check_launch("k_wide_mlp<points>");
 }
 
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream) {

@@ -10,9 +10,13 @@
 namespace rb {
 
 // Same network with split-precision (f16x3) layers: Wp from rb_pack_layer_h3 (all five layers, one scale), `unscale` = 2^-s.
+// FUSED: X = points p, Xd = directions d (rep per point): [PE10(p) | PE10(d)] encoded in the kernel (mlp_engine.h: load_features_vis).
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void k_vis_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                        float unscale, float* __restrict__ Y, unsigned* __restrict__ range_word) {
+                                                        float unscale, float* __restrict__ Y, unsigned* __restrict__ range_word,
+                                                        const float* __restrict__ Xd, int rep) {
   __shared__ f4 lds[2 * chunk_f4(256)];
+  __shared__ float pe_scratch[FUSED ? 4 * 2 * 16 * 128 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<256> ws;
   ws.init(lds, tid);
@@ -24,8 +28,13 @@ __global__ __launch_bounds__(256, 1) void k_vis_mlp_h3(const float* __restrict__
   unsigned xh[2][8][4], xl[2][8][4];
   {
     float in0[2][32];
-    load_features<128>(X, row0, M, lane, in0[0]);
-    load_features<128>(X, row0 + 16, M, lane, in0[1]);
+    if constexpr (FUSED) {
+      load_features_vis(X, Xd, rep, row0, M, lane, pe_scratch + (wave * 2 + 0) * 2048, in0[0]);
+      load_features_vis(X, Xd, rep, row0 + 16, M, lane, pe_scratch + (wave * 2 + 1) * 2048, in0[1]);
+    } else {
+      load_features<128>(X, row0, M, lane, in0[0]);
+      load_features<128>(X, row0 + 16, M, lane, in0[1]);
+    }
     unsigned ih[2][4][4], il[2][4][4];
     split_operands<128, 32, 2>(in0, ih, il);
     ws.prime<chunk_f4(128)>(wl0);
@@ -279,13 +288,15 @@ __global__ __launch_bounds__(256, 1) void k_color_mlp_h3(const float* __restrict
 
 // Split-precision (f16x3) form of the 512-wide nets: Wp from rb_pack_layer_h3 (64->512, 512->512 x3, 512->NO; output rows
 // padded to 16), operands lifted by 2^4 before the hi/lo split.
-template <bool ENC>
+template <bool ENC, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict__ X, long M, const f4* __restrict__ Wp,
-                                                         float us, float* __restrict__ Y, unsigned* __restrict__ range_word) {
+                                                         float us, float* __restrict__ Y, unsigned* __restrict__ range_word,
+                                                         const float* __restrict__ extra = nullptr) {
   constexpr int NO = ENC ? 32 : 144;
   constexpr int ACT = ENC ? ACT_LEAKY02 : ACT_RELU;
   constexpr float AS = 16.0f;
   __shared__ f4 lds[2 * chunk_f4(512)];
+  __shared__ float pe_scratch[FUSED ? 4 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WStream<512> ws;
   ws.init(lds, tid);
@@ -299,7 +310,11 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict_
   unsigned xh[1][16][4], xl[1][16][4];
   {
     float in0[1][16];
-    load_features<64>(X, row, M, lane, in0[0]);
+    if constexpr (FUSED) {
+      load_features_pe10x(X, extra, row, M, lane, pe_scratch + wave * 1024, in0[0]);
+    } else {
+      load_features<64>(X, row, M, lane, in0[0]);
+    }
     unsigned ih[1][2][4], il[1][2][4];
     split_operands<64, 16, 1>(in0, ih, il, AS);
     ws.prime<chunk_f4(64)>(w0);
@@ -419,9 +434,19 @@ extern "C" {
 int rb_vis_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* logits, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && logits, "null pointer");
-  hipLaunchKernelGGL(k_vis_mlp_h3, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
-                     ldexpf(1.0f, -scale_log2), logits, range_flags() ? range_flags() + RB_RANGE_VIS : nullptr);
+  hipLaunchKernelGGL(k_vis_mlp_h3<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp,
+                     ldexpf(1.0f, -scale_log2), logits, range_flags() ? range_flags() + RB_RANGE_VIS : nullptr, nullptr, 1);
   return check_launch("k_vis_mlp_h3");
+}
+
+int rb_vis_mlp_h3_points(const float* p, const float* d, long M, int rep, const float* Wp, int scale_log2, float* logits,
+                         rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(p && d && Wp && logits, "null pointer");
+  RB_REQUIRE(rep >= 1, "rep must be >= 1");
+  hipLaunchKernelGGL(k_vis_mlp_h3<true>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, p, M, (const f4*)Wp,
+                     ldexpf(1.0f, -scale_log2), logits, range_flags() ? range_flags() + RB_RANGE_VIS : nullptr, d, rep);
+  return check_launch("k_vis_mlp_h3<points>");
 }
 
 int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
@@ -483,6 +508,20 @@ int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int sca
     hipLaunchKernelGGL(k_wide_mlp_h3<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, us, Y, range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr);
   }
   return check_launch("k_wide_mlp_h3");
+}
+
+int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
+                          rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Y, "null pointer");
+  const float us = ldexpf(1.0f, -scale_log2);
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr;
+  if (encoder) {
+    hipLaunchKernelGGL((k_wide_mlp_h3<true, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, us, Y, rw, extra);
+  } else {
+    hipLaunchKernelGGL((k_wide_mlp_h3<false, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, us, Y, rw, extra);
+  }
+  return check_launch("k_wide_mlp_h3<points>");
 }
 
 int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,

@@ -91,11 +91,13 @@ struct SrAcc {
 // value + three tangent columns of point m), as rb_sdf_mlp_h3; bit 2 (with bit 0, without bit 1) = also store sigmoid(100 z) of
 // every hidden pre-activation for the reverse-mode gradient pass (sdf_back.hip): `sig` [rounds][125 chunks][2 tiles][256 lanes]
 // float4 -- lane-local, in the order the epilogue produces it, 16 B per lane and chunk.
-template <int MODE>
+// FUSED (forward-mode rows only; value rows take the eight-wave kernel): X = the points xyz[M,3], encoded at the top of every round
+// by load_features_pe10 (mlp_engine.h) -- the value row and the three tangent rows of a point by the sixteen lanes that hold them.
+template <int MODE, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X, long MR, const f4* __restrict__ Wp, float us,
                                                       float out_scale, float grad_scale, float* __restrict__ out0,
                                                       float* __restrict__ grad, unsigned* __restrict__ range_word,
-                                                      f4* __restrict__ sig) {
+                                                      f4* __restrict__ sig, float in_scale = 1.0f) {
   constexpr bool JVP = (MODE & 2) != 0;
   constexpr bool FULL = (MODE & 1) != 0;
   constexpr bool STORE = (MODE & 4) != 0;
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
   constexpr float AS = 64.0f, TS = 0.25f;             // operand lifts of value rows / tangent rows (powers of two)
   __shared__ f4 ring[4 * SR_SLOT_F4];                 // 80 KB
   __shared__ f4 bias_tab[NCHUNK * 4];
+  __shared__ float pe_scratch[FUSED ? 4 * 2 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long nrounds = (MR + 127) >> 7;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
   long rrow[2];                        // this lane's row in each tile of the current round
 
   auto fetch_features = [&](long round) {
+    if constexpr (FUSED) return;        // encoded at the top of the round instead
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const long row = round * 128 + wave * 32 + t * 16 + (lane & 15);
@@ -469,6 +473,15 @@ __global__ __launch_bounds__(256, 1) void k_sdf_ring(const float* __restrict__ X
     for (int t = 0; t < 2; ++t) rrow[t] = round * 128 + wave * 32 + t * 16 + (lane & 15);
     if constexpr (STORE) sig_round = sig + round * (125L * 2 * 256);
     // ---- input features -> operands of layer 0 and the skip operands of layer 4
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float enc[16];
+        load_features_pe10<JVP>(X, in_scale, rrow[t], MR, lane, pe_scratch + (wave * 2 + t) * 1024, enc);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) fraw[t][kb] = f4{enc[kb * 4], enc[kb * 4 + 1], enc[kb * 4 + 2], enc[kb * 4 + 3]};
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -618,6 +631,38 @@ extern "C" int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode
     default: hipLaunchKernelGGL(k_sdf_ring<3>, dim3(grid), dim3(256), 0, s, X, MR, W, us, out_scale, grad_scale, out0, grad, rw, nullptr); break;
   }
   return check_launch("k_sdf_ring");
+}
+
+// Forward-mode rows (value + three tangent rows per point) straight from the points: mode 2 = distance + gradient, 3 = all outputs +
+// gradient; bit-identical to rb_feat_pe10(jvp) + rb_sdf_mlp_ring.
+extern "C" int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
+                                      float grad_scale, float* out0, float* grad, int n_workgroups, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && out0 && grad, "null pointer");
+  RB_REQUIRE(mode == 2 || mode == 3, "mode: 2 = distance + gradient, 3 = all 257 outputs + gradient");
+  const long MR = 4 * M, rounds = (MR + 127) / 128;
+  if (n_workgroups <= 0) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
+      cus = prop.multiProcessorCount;
+    }
+    n_workgroups = cus;
+  }
+  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const float us = ldexpf(1.0f, -scale_log2);
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 2) {
+    hipLaunchKernelGGL((k_sdf_ring<2, true>), dim3(grid), dim3(256), 0, s, x, MR, (const f4*)Wp, us, out_scale, grad_scale, out0, grad, rw,
+                       nullptr, in_scale);
+  } else {
+    hipLaunchKernelGGL((k_sdf_ring<3, true>), dim3(grid), dim3(256), 0, s, x, MR, (const f4*)Wp, us, out_scale, grad_scale, out0, grad, rw,
+                       nullptr, in_scale);
+  }
+  return check_launch("k_sdf_ring<jvp, points>");
 }
 
 // Value rows straight from the points (positional encoding fused into k_sdf_ring8): x[M,3], evaluated at x * in_scale.

@@ -141,11 +141,21 @@ class VisNetwork(nn.Module):
             return ops.vis_mlp(X, self.packed_full())
         return ops.vis_mlp_h3(X, self.packed_full_h3(), packing.H3_SCALE_LOG2)
 
+    def logits_from_points(self, points, dirs, rep=1):
+        """points [M/rep,3], dirs [M,3] (rep consecutive directions per point) -> logits [M,2]: [PE10(p) | PE10(d)] is encoded
+        inside the MLP kernel (no feature rows)."""
+        forward_only_guard(self)
+        if not ops.SDF_FUSED_PE:
+            return self.logits_from_features(ops.feat_vis(points.float().contiguous(), dirs.float().contiguous(), rep=rep))
+        if mlp_precision() == "fp32":
+            return ops.vis_mlp_points(points, dirs, self.packed_full(), rep)
+        return ops.vis_mlp_points(points, dirs, self.packed_full_h3(), rep, packing.H3_SCALE_LOG2)
+
     def forward(self, points, view_dirs):
         forward_only_guard(self)
         if points.shape[0] == 0:
             return torch.zeros(0, 2, device=points.device)
-        return self.logits_from_features(ops.feat_vis(points.float().contiguous(), view_dirs.float().contiguous()))
+        return self.logits_from_points(points.float().contiguous(), view_dirs.float().contiguous())
 
 
 # ----------------------------------------------------------------------------------------- sparse auto-encoder
@@ -186,6 +196,27 @@ class SparseAE(nn.Module):
                 {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
             return ops.wide_mlp_h3(X, blob, True, packing.H3_SCALE_LOG2)
         return ops.ae_encode(X, self._blobs()[0])
+
+    def _encode_points(self, pts):
+        """_encode(feat_pe10(pts)) with the encoding fused into the encoder kernel."""
+        if not ops.SDF_FUSED_PE:
+            return self._encode(ops.feat_pe10(pts))
+        if mlp_precision() == "f16x3":
+            blob = self._packed.get("enc_h3", self, lambda sd: packing.pack_sparse_ae_encoder_h3(
+                {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
+            return ops.wide_mlp_points(pts, None, blob, True, packing.H3_SCALE_LOG2)
+        return ops.wide_mlp_points(pts, None, self._blobs()[0], True)
+
+    def run_points(self, pts, noise):
+        """run(feat_pe10(pts), noise=noise) for latent-smoothed auto-encoders, straight from the points."""
+        forward_only_guard(self)
+        assert self.smooth_on_latent
+        enc, dec = self._blobs()
+        sig_out = self.out_act is not None
+        if sig_out and getattr(self.out_act, "__name__", "") != "sigmoid":
+            raise NotImplementedError("out_act must be torch.sigmoid or None")
+        lat, lat2 = ops.ae_latent(self._encode_points(pts), self._var(pts.device), self._latent_act_code(), noise, 0.01)
+        return ops.ae_decode(lat, dec, self.out_dim, sig_out), ops.ae_decode(lat2, dec, self.out_dim, sig_out)
 
     def _latent_act_code(self):
         name = getattr(self.lc_act, "__name__", "")
@@ -278,10 +309,15 @@ class IndirctIllumNetwork(nn.Module):
         noise = noise.float().contiguous()
 
         def lobes():
+            hdr = hdr_shift.float().contiguous() if self.use_hdr else None
             if mlp_precision() == "f16x3":
                 blob3 = self._packed.get("lobe_h3", self.lobe_layer, lambda sd: packing.pack_illum_h3(
                     {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
+                if ops.SDF_FUSED_PE:        # [PE10(x) | hdr_shift] encoded inside the lobe net's kernel
+                    return ops.illum_decode(ops.wide_mlp_points(points, hdr, blob3, False, packing.H3_SCALE_LOG2))
                 return ops.illum_decode(ops.wide_mlp_h3(X, blob3, False, packing.H3_SCALE_LOG2))
+            if ops.SDF_FUSED_PE:
+                return ops.illum_decode(ops.wide_mlp_points(points, hdr, blob, False))
             return ops.illum_decode(ops.illum_mlp(X, blob))
 
         def integral():       # only the perturbed pass is used (implicit_differentiable_renderer.py:220)
@@ -346,7 +382,7 @@ class EnvmapMaterialNetwork(nn.Module):
         thunks = [lambda: ops.normalize3(self.normal_decoder_layer.run_pass(ops.feat_ipe(pts, 1e-5)), 1e-4, 1),
                   lambda: ops.normalize3(self.normal_decoder_layer.run_pass(ops.feat_ipe(pts, 1e-5, nz_n, 0.02)), 1e-4, 1)]
         if want_spec:
-            thunks.append(lambda: self.spec_brdf_encoder_layer.run(ops.feat_pe10(pts), noise=nz_s))
+            thunks.append(lambda: self.spec_brdf_encoder_layer.run_points(pts, nz_s))
         res = run_concurrently(thunks, n)
         normal_map, random_xi_normal = res[0], res[1]
         if want_spec:
@@ -455,6 +491,9 @@ class SDFNetwork(nn.Module):
                 and ops.sdf_ring_waves() == 8):
             # value rows straight from the points: positional encoding fused into the network kernel (csrc/sdf_ring8.hip)
             return ops.sdf_points_h3(x, M, self.packed_h3(full), full, packing.H3_SCALE_LOG2, in_scale, out_scale), None
+        if grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE:
+            return ops.sdf_points_jvp_h3(x, M, self.packed_h3(full), full, packing.H3_SCALE_LOG2, in_scale, out_scale,
+                                         out_scale * in_scale)
         if ops.SDF_FUSED_PE and (precise or mlp_precision() == "fp32"):
             # f32-input MFMA kernel with the encoding (tangent rows included) evaluated inside it
             return ops.sdf_mlp_points(x, M, self.packed(full), mode, in_scale, out_scale, out_scale * in_scale)

@@ -109,6 +109,44 @@ def vis_mlp_h3(X, blob, scale_log2):
     return Y
 
 
+def vis_mlp_points(p, d, blob, rep=1, scale_log2=None):
+    """Visibility MLP straight from points p [M/rep,3] and directions d [M,3] (encoding fused): scale_log2 None = f32-input MFMA
+    kernel (blob from pack_vis), else the split-precision kernel (blob from pack_vis_h3)."""
+    p, d = _f32(p), _f32(d)
+    M = d.shape[0]
+    assert p.shape[0] * rep == M
+    Y = torch.empty(M, 2, dtype=torch.float32, device=d.device)
+    if scale_log2 is None:
+        call("rb_vis_mlp_points", ptr(p), ptr(d), c_long(M), c_int(rep), ptr(blob), ptr(Y), stream_ptr())
+    else:
+        call("rb_vis_mlp_h3_points", ptr(p), ptr(d), c_long(M), c_int(rep), ptr(blob), c_int(scale_log2), ptr(Y), stream_ptr())
+    return Y
+
+
+def linear_pe10_256(x, blob):
+    """linear_64_256(feat_pe10(x)) with the encoding fused."""
+    x = _f32(x)
+    M = x.shape[0]
+    Y = torch.empty(M, 256, dtype=torch.float32, device=x.device)
+    call("rb_linear_pe10_256", ptr(x), c_long(M), ptr(blob), ptr(Y), stream_ptr())
+    return Y
+
+
+def wide_mlp_points(x, extra, blob, encoder, scale_log2=None):
+    """512-wide nets on [PE10(x) | extra] with the encoding fused: encoder=False -> raw SG outputs [M,144], True -> raw latent [M,32];
+    scale_log2 None = f32-input MFMA kernel, else split precision."""
+    x = _f32(x)
+    M = x.shape[0]
+    e = _f32(extra).reshape(-1) if extra is not None else None
+    Y = torch.empty(M, 32 if encoder else 144, dtype=torch.float32, device=x.device)
+    if scale_log2 is None:
+        call("rb_wide_mlp_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), ptr(Y), stream_ptr())
+    else:
+        call("rb_wide_mlp_h3_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), c_int(scale_log2), ptr(Y),
+             stream_ptr())
+    return Y
+
+
 def linear_64_256(X, blob):
     M = X.shape[0]
     Y = torch.empty(M, 256, dtype=torch.float32, device=X.device)
@@ -175,6 +213,16 @@ def sdf_points_h3(x, M, blob, full, scale_log2, in_scale=1.0, out_scale=1.0):
     call("rb_sdf_points_ring", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_int(scale_log2),
          c_float(out_scale), ptr(out0), c_int(0), stream_ptr())
     return out0
+
+
+def sdf_points_jvp_h3(x, M, blob, full, scale_log2, in_scale=1.0, out_scale=1.0, grad_scale=1.0):
+    """Forward-mode value + gradient rows straight from the points (k_sdf_ring<2|3, FUSED>): -> (out0, grad [M,3])."""
+    x = _f32(x)
+    out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
+    grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    call("rb_sdf_points_ring_jvp", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(3 if full else 2), c_int(scale_log2),
+         c_float(out_scale), c_float(grad_scale), ptr(out0), ptr(grad), c_int(0), stream_ptr())
+    return out0, grad
 
 
 SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)

@@ -137,8 +137,12 @@ def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis,
     dirs, wdir, wsum = ops.dvis_dirs(lgt, u_t.to(dev), u_p.to(dev), thr, direct=direct)
     if isinstance(VisModel, VisNetwork):
         sp = VisModel.packed_split()
-        A = ops.linear_64_256(ops.feat_pe10(points.float().contiguous()), sp["point"])
-        Bd = ops.linear_64_256(ops.feat_pe10(dirs), sp["dir"])
+        if ops.SDF_FUSED_PE:       # first-layer halves straight from the points / directions (encoding fused)
+            A = ops.linear_pe10_256(points.float().contiguous(), sp["point"])
+            Bd = ops.linear_pe10_256(dirs, sp["dir"])
+        else:
+            A = ops.linear_64_256(ops.feat_pe10(points.float().contiguous()), sp["point"])
+            Bd = ops.linear_64_256(ops.feat_pe10(dirs), sp["dir"])
         cnt = None
         if stats is not None:
             cnt = stats.setdefault("diffuse_vis_evals", torch.zeros(1, dtype=torch.int64, device=dev))
@@ -182,7 +186,7 @@ def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p,
     n, nsamp = u_t.shape
     dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
     if isinstance(VisModel, VisNetwork):
-        logits = VisModel.logits_from_features(ops.feat_vis(points.float().contiguous(), dirs, rep=nsamp))
+        logits = VisModel.logits_from_points(points.float().contiguous(), dirs, rep=nsamp)
     elif isinstance(VisModel, OctreeVisModel) and cid is not None and C > 1:
         # several chunks in one call: each chunk's n_c * nsamp rays are their own lock-step batch, as in the reference's
         # per-chunk calls (group boundaries from the ascending chunk ids, computed on the device)

@@ -474,6 +474,11 @@ def test_fused_positional_encoding_is_bit_identical_to_the_row_form(dev, synth_w
             f0 = ops.sdf_points_h3(x, n, dist, False, packing.H3_SCALE_LOG2, 2.0, 0.5)
             f1 = ops.sdf_points_h3(x, n, full, True, packing.H3_SCALE_LOG2, 2.0, 0.5)
             assert torch.equal(f0, r0) and torch.equal(f1, r1), n
+            X4 = ops.feat_pe10(x, scale=2.0, jvp=True)
+            for fullm, blob in ((False, dist), (True, full)):
+                ro, rg = ops.sdf_mlp_h3(X4, n, blob, 3 if fullm else 2, packing.H3_SCALE_LOG2, 0.5, 1.0)
+                fo, fg = ops.sdf_points_jvp_h3(x, n, blob, fullm, packing.H3_SCALE_LOG2, 2.0, 0.5, 1.0)
+                assert torch.equal(fo, ro) and torch.equal(fg, rg), (n, fullm)
         x = ((torch.rand(50000, 3, generator=g) - 0.5) * 1.9).to(dev)
         monkeypatch.setattr(ops, "SDF_FUSED_PE", True)
         of, gf = ops.sdf_value_grad(x, 50000, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)
@@ -524,3 +529,31 @@ def test_f32_kernels_with_fused_encoding_are_bit_identical(dev, synth_weights):
         a = ops.color_mlp(ops.feat_color(x, v, nr, out[:, 1:], x_scale=2.0, feat_scale=2.0), cb)
         b = ops.color_mlp_points(x, v, nr, out[:, 1:], cb, x_scale=2.0, feat_scale=2.0)
         assert torch.equal(a, b), n
+
+
+def test_small_nets_with_fused_encoding_are_bit_identical(dev, synth_weights):
+    """Visibility MLP (both arithmetics, rep directions per point), the 64 -> 256 first-layer halves of the light-visibility net, the
+    indirect-illumination lobe net ([PE10(x) | hdr_shift]) and a SparseAE encoder: straight from the points == the row forms."""
+    from robir_amd import ops, packing
+    g = torch.Generator().manual_seed(53)
+    vis32, vis16 = packing.pack_vis(synth_weights, dev), packing.pack_vis_h3(synth_weights, dev)
+    split = packing.pack_vis_split(synth_weights, dev)
+    ill32, ill16 = packing.pack_illum(synth_weights, dev), packing.pack_illum_h3(synth_weights, dev)
+    enc32, _ = packing.pack_sparse_ae(synth_weights, "envmap_material_network.spec_brdf_encoder_layer", dev)
+    enc16 = packing.pack_sparse_ae_encoder_h3(synth_weights, "envmap_material_network.spec_brdf_encoder_layer", dev)
+    for n, rep in ((1, 1), (17, 8), (130, 8), (700, 1), (4001, 3)):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(n * rep, 3, generator=g), dim=-1).to(dev)
+        X = ops.feat_vis(p, d, rep=rep)
+        assert torch.equal(ops.vis_mlp_points(p, d, vis32, rep), ops.vis_mlp(X, vis32)), (n, rep)
+        assert torch.equal(ops.vis_mlp_points(p, d, vis16, rep, packing.H3_SCALE_LOG2), ops.vis_mlp_h3(X, vis16, packing.H3_SCALE_LOG2)), (n, rep)
+        Xp = ops.feat_pe10(p)
+        assert torch.equal(ops.linear_pe10_256(p, split["point"]), ops.linear_64_256(Xp, split["point"]))
+        assert torch.equal(ops.linear_pe10_256(d, split["dir"]), ops.linear_64_256(ops.feat_pe10(d), split["dir"]))
+        hdr = torch.rand(n, 1, generator=g).to(dev)
+        Xh = ops.feat_pe10(p, extra=hdr)
+        assert torch.equal(ops.wide_mlp_points(p, hdr, ill32, False), ops.illum_mlp(Xh, ill32))
+        assert torch.equal(ops.wide_mlp_points(p, hdr, ill16, False, packing.H3_SCALE_LOG2), ops.wide_mlp_h3(Xh, ill16, False, packing.H3_SCALE_LOG2))
+        assert torch.equal(ops.wide_mlp_points(p, None, enc32, True), ops.ae_encode(Xp, enc32))
+        assert torch.equal(ops.wide_mlp_points(p, None, enc16, True, packing.H3_SCALE_LOG2), ops.wide_mlp_h3(Xp, enc16, True, packing.H3_SCALE_LOG2))
+    ops.range_check(sync=True)
