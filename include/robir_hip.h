@@ -154,6 +154,10 @@ int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_str
 int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, rb_stream_t stream);
 int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
                           rb_stream_t stream);
+/* CESR nets straight from the points (training/train_cesr.py:106-110,331-352): kind 0 = normal_net on PE10(x) [M rows], kind 2 =
+ * shadow_net on (point, one-hot label) rows [M = points * n_label rows]; = rb_feat_pe10 + rb_cesr_net[_h3]. */
+int rb_cesr_net_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
+int rb_cesr_net_h3_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);

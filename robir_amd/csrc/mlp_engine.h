@@ -621,10 +621,10 @@ __device__ __forceinline__ void pe10_coop_write(float* __restrict__ frow, const 
 // [PE10(p) | extra] rows of the 64-input nets (IndirctIllumNetwork: extra = hdr_shift; SparseAE encoders / light-visibility
 // first-layer halves: extra = 0), one 16-row tile: model/implicit_differentiable_renderer.py:199-222, model/sg_envmap_material.py:188-247
 __device__ __forceinline__ void load_features_pe10x(const float* __restrict__ xyz, const float* __restrict__ extra, long row, long M,
-                                                    int lane, float* __restrict__ scratch, float (&in)[16]) {
+                                                    int lane, float* __restrict__ scratch, float (&in)[16], long rows_per_point = 1) {
   const int n = lane & 15, g = lane >> 4;
   const bool ok = row < M;
-  const long i = ok ? row : 0;
+  const long i = ok ? row / rows_per_point : 0;      // rows_per_point > 1: consecutive rows share a point (CESR label rows)
   const float a[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
   float* frow = scratch + n * 64;
   pe10_coop_write(frow, a, g);

@@ -696,12 +696,14 @@ __global__ __launch_bounds__(256, 1) void k_ae_decode(const float* __restrict__ 
 // K0P = padded input width (192 / 64), N3P = padded width of lin3 (336 / 464), K4 = N3P + K0P = 528 for both.
 // ONEHOT: rows are (point, label) pairs, label = row % n_label; the kernel reads PE features of point row / n_label
 // from Xp[n,64] and synthesises the one-hot part in registers (never materialised: it would be 98 KB per point).
-template <int K0P, int N3P, bool ONEHOT>
+// FUSED: X = the points [.,3]: the 63 encoded columns (model/embedder.py:17-38) are computed in the kernel (mlp_engine.h).
+template <int K0P, int N3P, bool ONEHOT, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_softplus512(const float* __restrict__ X, long M, int n_label,
                                                          const f4* __restrict__ Wp, int n_out, float* __restrict__ Y) {
   constexpr int K4 = N3P + K0P;
   static_assert(K4 == 528, "both CESR nets give a 528-wide skip layer");
   __shared__ f4 lds[2 * chunk_f4(528)];
+  __shared__ float pe_scratch[FUSED ? 4 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   WStream<528> ws;
   ws.init(lds, tid);
@@ -719,10 +721,17 @@ __global__ __launch_bounds__(256, 1) void k_softplus512(const float* __restrict_
     const bool ok = row < M;
     const long pt = ok ? row / n_label : 0;
     const int label = ok ? (int)(row % n_label) : -1;
-    const f4* p = reinterpret_cast<const f4*>(X + pt * 64) + g;
+    float enc[16];
+    if constexpr (FUSED) load_features_pe10x(X, nullptr, row, M, lane, pe_scratch + wave * 1024, enc, n_label);
+    const f4* p = reinterpret_cast<const f4*>(X + (FUSED ? 0 : pt * 64)) + g;
 #pragma unroll
     for (int kb = 0; kb < K0P / 16; ++kb) {
-      f4 v = (kb < 4 && ok) ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+      f4 v = f4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FUSED) {
+        if (kb < 4) v = f4{enc[kb * 4], enc[kb * 4 + 1], enc[kb * 4 + 2], enc[kb * 4 + 3]};
+      } else {
+        if (kb < 4 && ok) v = p[kb * 4];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kb * 16 + 4 * g + r;
@@ -732,6 +741,8 @@ __global__ __launch_bounds__(256, 1) void k_softplus512(const float* __restrict_
         x0[0][kb * 4 + r] = e;
       }
     }
+  } else if constexpr (FUSED && K0P == 64) {
+    load_features_pe10x(X, nullptr, row, M, lane, pe_scratch + wave * 1024, x0[0]);
   } else {
     load_features<K0P>(X, row, M, lane, x0[0]);
   }
@@ -1035,6 +1046,23 @@ int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* 
     hipLaunchKernelGGL((k_wide_mlp<false, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, Y, extra);
   }
   return check_launch("k_wide_mlp<points>");
+}
+
+int rb_cesr_net_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Y, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid1d(M, 64), block(256);
+  const f4* W = (const f4*)Wp;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((k_softplus512<64, 464, false, true>), grid, block, 0, s, x, M, 1, W, 3, Y); break;
+    case 2:
+      RB_REQUIRE(n_label >= 1 && n_label <= 128, "n_label must be 1..128");
+      hipLaunchKernelGGL((k_softplus512<192, 336, true, true>), grid, block, 0, s, x, M, n_label, W, 2, Y);
+      break;
+    default: return rb::fail("rb_cesr_net_points", "kind: 0 normal_net on PE10(x), 2 shadow_net on (point, one-hot label) rows");
+  }
+  return check_launch("k_softplus512<points>");
 }
 
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream) {

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, 1) void k_wide_mlp_h3(const float* __restrict_
 
 // Split-precision (f16x3) form: Wp from rb_pack_layer_h3 (k_pad: K0P, 512, 512, 512, 544 = [N3P | K0P | 16 zero slots],
 // 512 x4), operands lifted by 2^6 before the hi/lo split (softplus outputs are small), `us` = 2^-s.
-template <int K0P, int N3P, bool ONEHOT>
+// FUSED: X = the points [.,3]: the 63 encoded columns (model/embedder.py:17-38) are computed in the kernel (mlp_engine.h).
+template <int K0P, int N3P, bool ONEHOT, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restrict__ X, long M, int n_label,
                                                             const f4* __restrict__ Wp, float us, int n_out,
                                                             float* __restrict__ Y, unsigned* __restrict__ range_word) {
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
   static_assert(K4 == 528 && K0P % 32 == 0, "both CESR nets give a 528-wide skip layer");
   constexpr float AS = 64.0f;
   __shared__ f4 lds[2 * chunk_f4(K4P)];
+  __shared__ float pe_scratch[FUSED ? 4 * 16 * 64 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   WStream<K4P> ws;
   ws.init(lds, tid);
@@ -367,10 +369,17 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
     const bool ok = row < M;
     const long pt = ok ? row / n_label : 0;
     const int label = ok ? (int)(row % n_label) : -1;
-    const f4* p = reinterpret_cast<const f4*>(X + pt * 64) + g;
+    float enc[16];
+    if constexpr (FUSED) load_features_pe10x(X, nullptr, row, M, lane, pe_scratch + wave * 1024, enc, n_label);
+    const f4* p = reinterpret_cast<const f4*>(X + (FUSED ? 0 : pt * 64)) + g;
 #pragma unroll
     for (int kb = 0; kb < K0P / 16; ++kb) {
-      f4 v = (kb < 4 && ok) ? p[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+      f4 v = f4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FUSED) {
+        if (kb < 4) v = f4{enc[kb * 4], enc[kb * 4 + 1], enc[kb * 4 + 2], enc[kb * 4 + 3]};
+      } else {
+        if (kb < 4 && ok) v = p[kb * 4];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = kb * 16 + 4 * g + r;
@@ -380,6 +389,8 @@ __global__ __launch_bounds__(256, 1) void k_softplus512_h3(const float* __restri
         x0[0][kb * 4 + r] = e;
       }
     }
+  } else if constexpr (FUSED && K0P == 64) {
+    load_features_pe10x(X, nullptr, row, M, lane, pe_scratch + wave * 1024, x0[0]);
   } else {
     load_features<K0P>(X, row, M, lane, x0[0]);
   }
@@ -522,6 +533,26 @@ int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const floa
     hipLaunchKernelGGL((k_wide_mlp_h3<false, true>), grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, x, M, (const f4*)Wp, us, Y, rw, extra);
   }
   return check_launch("k_wide_mlp_h3<points>");
+}
+
+int rb_cesr_net_h3_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,
+                          rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Y, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid = grid1d(M, 64), block(256);
+  const f4* W = (const f4*)Wp;
+  const float us = ldexpf(1.0f, -scale_log2);
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL((k_softplus512_h3<64, 464, false, true>), grid, block, 0, s, x, M, 1, W, us, 3, Y, rw); break;
+    case 2:
+      RB_REQUIRE(n_label >= 1 && n_label <= 128, "n_label must be 1..128");
+      hipLaunchKernelGGL((k_softplus512_h3<192, 336, true, true>), grid, block, 0, s, x, M, n_label, W, us, 2, Y, rw);
+      break;
+    default: return rb::fail("rb_cesr_net_h3_points", "kind: 0 normal_net on PE10(x), 2 shadow_net on (point, one-hot label) rows");
+  }
+  return check_launch("k_softplus512_h3<points>");
 }
 
 int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,

@@ -512,9 +512,18 @@ class SDFNetwork(nn.Module):
             return ops.cesr_net_h3(X, M, kind, self.packed_w512_h3(), packing.H3_SCALE_LOG2, n_label)
         return ops.cesr_net(X, M, kind, self.packed(), n_label)
 
+    def _cesr_points(self, pts, M, kind, n_label=1):
+        """_cesr on PE10(pts) with the encoding evaluated inside the kernel (kind 0 normal_net, 2 shadow_net x labels)."""
+        forward_only_guard(self)
+        if mlp_precision() == "f16x3":
+            return ops.cesr_net_points(pts, M, kind, self.packed_w512_h3(), n_label, packing.H3_SCALE_LOG2)
+        return ops.cesr_net_points(pts, M, kind, self.packed(), n_label)
+
     def eval_point_labels(self, Xp, n_label=128):
         """shadow_net on every (point, one-hot label) pair: Xp [n,64] PE10 features -> logits [n*n_label, 2]."""
         assert self.kind == "shadow"
+        if Xp.shape[1] == 3:            # points [n,3]: encoded inside the kernel
+            return self._cesr_points(Xp, Xp.shape[0] * n_label, 2, n_label)
         return self._cesr(Xp, Xp.shape[0] * n_label, 2, n_label)
 
     def forward(self, inputs, var=0.0001, chunk=1024):

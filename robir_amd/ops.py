@@ -711,6 +711,17 @@ def cesr_net_h3(X, M, kind, blob, scale_log2, n_label=1):
     return Y
 
 
+def cesr_net_points(x, M, kind, blob, n_label=1, scale_log2=None):
+    """cesr_net / cesr_net_h3 on PE10(x) with the encoding fused (kind 0: M = points; kind 2: M = points * n_label rows)."""
+    x = _f32(x)
+    Y = torch.empty(M, 3 if kind == 0 else 2, dtype=torch.float32, device=x.device)
+    if scale_log2 is None:
+        call("rb_cesr_net_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), stream_ptr())
+    else:
+        call("rb_cesr_net_h3_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), c_int(scale_log2), ptr(Y), stream_ptr())
+    return Y
+
+
 def material_decode(brdf, brdf_r):
     brdf, brdf_r = _f32(brdf), _f32(brdf_r)
     n, dev = brdf.shape[0], brdf.device

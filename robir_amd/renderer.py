@@ -381,10 +381,15 @@ class CESRHook:
         normals = ops.normalize3(m.get_idr_render(points, normal_only=True).contiguous(), 1e-4, 1)
         mat = m.envmap_material_network(points, train_spec=True,
                                         noise={"spec": draws.get("spec_randn"), "normal": draws.get("normal_randn")})
-        Xp = ops.feat_pe10(points.float().contiguous())
-        logits = self.shadow_net.eval_point_labels(Xp, 128)
+        if ops.SDF_FUSED_PE:        # shadow_net / normal_net straight from the points (encoding inside the kernels)
+            pts = points.float().contiguous()
+            logits = self.shadow_net.eval_point_labels(pts, 128)
+            normal_new = ops.normalize3(self.normal_net._cesr_points(pts, pts.shape[0], 0), 1e-4, 1)
+        else:
+            Xp = ops.feat_pe10(points.float().contiguous())
+            logits = self.shadow_net.eval_point_labels(Xp, 128)
+            normal_new = ops.normalize3(self.normal_net._cesr(Xp, Xp.shape[0], 0), 1e-4, 1)
         diffuse_vis = ops.softmax2(logits, 1)
-        normal_new = ops.normalize3(self.normal_net._cesr(Xp, Xp.shape[0], 0), 1e-4, 1)
         albedo = mat["sg_diffuse_albedo"]
         ret = sg_render.render_with_all_sg(points=points, normal=normal_new if self.cur_iter > 1000 else mat["sg_normal_map"],
                                            viewdirs=vd, lgtSGs=mat["sg_lgtSGs"], indir_integral=ops.abs_scale(indir_integral, 2 * np.pi, take_abs=False),

@@ -254,6 +254,62 @@ def test_config5_cesr_chunks_of_1600x1200(dev):
     assert n_hit_total > 15000         # the central chunks are on the object, the corner chunks are all-miss
 
 
+def test_config5_whole_view_with_trace_radiance_per_chunk(dev):
+    """BASELINE config 5 at full size: ALL 1875 chunks of the 1600x1200 view, chunk by chunk through forward() with the CESR hook,
+    each followed by trace_radiance(out, nsamp=8) -- the plot loop of training/train_cesr.py:319-326.  Properties: the per-chunk hit
+    masks are those of one batched pass over the whole view, every output finite with the reference's fill value on missed rays, the
+    secondary-ray statistics in range; the rate is recorded."""
+    import os
+    import sys
+    import time
+    from conftest import record_metric
+    from robir_amd import renderer, synth
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_configs
+    m = renderer.build_synthetic_model(dev)
+    uv, pose, K = synth.synth_camera(1200, 1600)
+    uv_d, pose_d, K_d = torch.from_numpy(uv).to(dev), torch.from_numpy(pose).to(dev), torch.from_numpy(K).to(dev)
+    hdr = torch.full((uv.shape[0], 1), 0.5, device=dev)
+    whole = torch.cat([m.render_chunks(uv_d[a:a + 375 * 1024], pose_d, K_d, hdr[a:a + 375 * 1024], chunk=1024, trainstage="Illum",
+                                       draws={})["network_object_mask"] for a in range(0, uv.shape[0], 375 * 1024)])
+    seen = {"hits": 0, "sec": 0, "sec_hit": 0, "chunks": 0}
+    real_forward, real_trace = type(m).forward, type(m).trace_radiance
+
+    def forward(self, inp, *a, **k):
+        o = real_forward(self, inp, *a, **k)
+        hit = o["network_object_mask"]
+        c = seen["chunks"]
+        assert torch.equal(hit, whole[c * 1024:(c + 1) * 1024]), c
+        if c % 25 == 0:                 # every 25th chunk in full (a host read per chunk would dominate the loop)
+            ok = ~torch.isnan(o["points"][:, 0])
+            for f in ("sg_rgb", "indir_rgb", "vis_shadow", "normal_map", "diffuse_albedo", "roughness"):
+                assert bool(torch.isfinite(o[f][ok]).all()), (c, f)
+                assert bool((o[f][~hit & ok] == 1.0).all()), (c, f)
+        seen["chunks"] += 1
+        return o
+
+    def trace(self, out, *a, **k):
+        tr = real_trace(self, out, *a, **k)
+        hit = out["network_object_mask"]
+        seen["hits"] += int(hit.sum()) if seen["chunks"] % 25 == 1 else 0
+        if seen["chunks"] % 25 == 1:
+            seen["sec"] += int(hit.sum()) * 8
+            seen["sec_hit"] += int(tr["gt_vis"].sum())
+            assert bool(torch.isfinite(tr["pred_vis"]).all()) and bool(torch.isfinite(tr["trace_radiance"]).all())
+        return tr
+
+    type(m).forward, type(m).trace_radiance = forward, trace
+    try:
+        t0 = time.time()
+        r = bench_configs.config5(m, reps=1, first=0, nch=1875)       # warm-up pass + one timed pass
+        dt = time.time() - t0
+    finally:
+        type(m).forward, type(m).trace_radiance = real_forward, real_trace
+    assert seen["chunks"] == 2 * 1875 and r["hit_rays"] == int(whole.sum())
+    assert seen["sec"] > 0 and 0.3 < seen["sec_hit"] / seen["sec"] < 0.7
+    record_metric("full_size/config5_whole_view", rays_per_s=r["value"], seconds=r["ms"] / 1e3, hit_rays=r["hit_rays"], wall_s=dt)
+
+
 def test_feature_kernels_beyond_the_block_limit(dev):
     """The encoding kernels use 16 / 32 threads per row and a grid-stride loop: 17.5 M points in forward-mode form are 70 M rows =
     4.4 M workgroups' worth of threads, more than one launch may have (common.h RB_MAX_BLOCKS) -- the tail must still be written.

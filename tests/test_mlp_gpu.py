@@ -557,3 +557,23 @@ def test_small_nets_with_fused_encoding_are_bit_identical(dev, synth_weights):
         assert torch.equal(ops.wide_mlp_points(p, None, enc32, True), ops.ae_encode(Xp, enc32))
         assert torch.equal(ops.wide_mlp_points(p, None, enc16, True, packing.H3_SCALE_LOG2), ops.wide_mlp_h3(Xp, enc16, True, packing.H3_SCALE_LOG2))
     ops.range_check(sync=True)
+
+
+def test_cesr_nets_with_fused_encoding_are_bit_identical(dev):
+    """shadow_net over one-hot labels and normal_net straight from the points == the same kernels on rb_feat_pe10 rows."""
+    from robir_amd import ops, packing, synth
+    c = synth.synth_cesr_nets(0)
+    g = torch.Generator().manual_seed(61)
+    sh = {"net." + k: v for k, v in c["shadow_net"].items()}
+    no = {"net." + k: v for k, v in c["normal_net"].items()}
+    sh32, sh16 = packing.pack_softplus512(sh, "net.", 191, dev), packing.pack_softplus512_h3(sh, "net.", 191, dev)
+    no32, no16 = packing.pack_softplus512(no, "net.", 63, dev), packing.pack_softplus512_h3(no, "net.", 63, dev)
+    for n in (1, 7, 100):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        Xp = ops.feat_pe10(p)
+        assert torch.equal(ops.cesr_net_points(p, n * 128, 2, sh32, 128), ops.cesr_net(Xp, n * 128, 2, sh32, 128))
+        assert torch.equal(ops.cesr_net_points(p, n * 128, 2, sh16, 128, packing.H3_SCALE_LOG2),
+                           ops.cesr_net_h3(Xp, n * 128, 2, sh16, packing.H3_SCALE_LOG2, 128))
+        assert torch.equal(ops.cesr_net_points(p, n, 0, no32), ops.cesr_net(Xp, n, 0, no32))
+        assert torch.equal(ops.cesr_net_points(p, n, 0, no16, 1, packing.H3_SCALE_LOG2), ops.cesr_net_h3(Xp, n, 0, no16, packing.H3_SCALE_LOG2))
+    ops.range_check(sync=True)
