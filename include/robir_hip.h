@@ -281,6 +281,17 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
                    int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
                    unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
                    long* layout, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* rb_dvis_octree with the rays still active compacted -- stably, by a prefix sum: list order = (point, direction) order -- between
+ * the lock-step iterations, so that an iteration reads and steps only live rays in full waves (the plain form walks every pair 33
+ * times).  Bit-identical vis_out.  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap + 8] (cap = size of pair_p,
+ * < 2^31), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2]. */
+int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
+                           const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
+                           const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
+                           int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
+                           unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
+                           long* layout, int* alive_a, int* alive_b, unsigned char* flags, int* blk_cnt, long* blk_off, long* n_alive,
+                           float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 int rb_octree_cast_grouped(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
                            const int* res, const float* origins, const float* dirs, long R, const long* group_start, int G,
                            int max_iter, float clamp_dt, long* gsize, int* grp, float* t_st, int* leaf_st,

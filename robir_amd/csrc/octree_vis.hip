@@ -277,6 +277,145 @@ __global__ __launch_bounds__(256) void k_ovis_iter(Oct T, Rays rays, const long*
   }
 }
 
+// ---- stable compaction of the rays still active (round 3).  k_ovis_iter above walks ALL pairs at every one of the 33 iterations and
+// half of what it reads belongs to rays that have finished; their lanes idle inside the waves of the others.  Here every iteration
+// walks a dense, ORDER-PRESERVING list of the active pairs (neighbours in the list are neighbours in (point, direction) order: their
+// octree walks stay coherent -- an unordered append by atomics was measured slower than no compaction at all): the
+// step kernel writes one flag per list entry, three small kernels turn (list, flags) into the next list: per-block counts, a
+// single-workgroup scan of the counts, an ordered scatter.  Sizes live in device memory (n_alive[2], ping-pong); grids are fixed.
+constexpr int OV_CB = 2048;     // list entries per compaction block (256 threads x 8)
+
+template <class Rays>
+__global__ __launch_bounds__(256) void k_ovis_iter_list(Oct T, Rays rays, const long* __restrict__ n_alive,
+                                                         const int* __restrict__ list_in, const long* __restrict__ gsize,
+                                                         const int* __restrict__ grp, int it, float* __restrict__ t_st,
+                                                         int* __restrict__ leaf_st, unsigned char* __restrict__ flag_out,
+                                                         int* __restrict__ counters, OvisLayout* __restrict__ stats) {
+  const long total = *n_alive;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long rounds = (total + stride - 1) / stride;
+  int nfetch = 0, nstep = 0;
+  for (long r = 0; r < rounds; ++r) {
+    const long k = r * stride + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    bool act = false;
+    int g = 0;
+    if (k < total) {
+      const long i = list_in[k];
+      g = grp[i];
+      const int n_act = counters[(long)g * OV_ITERS + it];
+      const long R = gsize[g];
+      float o[3], d[3];
+      rays.fetch(i, o, d);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = o[c] + d[c] * 0.005f;
+      RayState s;
+      s.t = t_st[i];
+      s.leaf = leaf_st[i];
+      s.active = true;
+      cast_step(T, o, d, s, multi_samp(R, n_act), R > 100000 ? 0.01 : 0.005, &nfetch);
+      nstep += 1;
+      t_st[i] = s.t;
+      leaf_st[i] = s.leaf;
+      flag_out[k] = s.active;
+      act = s.active;
+    }
+    count_active(act, g, counters, it + 1);
+  }
+  if (stats) {
+    for (int o = 32; o > 0; o >>= 1) {
+      nfetch += __shfl_xor(nfetch, o);
+      nstep += __shfl_xor(nstep, o);
+    }
+    if ((threadIdx.x & 63) == 0 && nstep) {
+      atomicAdd(&stats->node_fetches, (unsigned long long)nfetch);
+      atomicAdd(&stats->ray_steps, (unsigned long long)nstep);
+    }
+  }
+}
+
+// active entries per block of OV_CB list entries
+__global__ __launch_bounds__(256) void k_cmp_count(const long* __restrict__ n_ptr, const unsigned char* __restrict__ flags,
+                                                    int* __restrict__ blk_cnt) {
+  __shared__ int s_w[4];
+  const long n = *n_ptr;
+  const long nblk = (n + OV_CB - 1) / OV_CB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const long k0 = b * OV_CB + (long)tid * 8;
+    int c = 0;
+    if (k0 + 8 <= n) {
+      const unsigned long long v = *reinterpret_cast<const unsigned long long*>(flags + k0);     // eight 0/1 bytes
+      c = __popcll(v & 0x0101010101010101ull);
+    } else {
+      for (int e = 0; e < 8; ++e) c += (k0 + e < n && flags[k0 + e]) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) s_w[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) blk_cnt[b] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+}
+
+// exclusive scan of the block counts (one workgroup; strips of 1024 with a running carry); total -> *n_out
+__global__ __launch_bounds__(1024) void k_cmp_scan(const long* __restrict__ n_ptr, const int* __restrict__ blk_cnt,
+                                                    long* __restrict__ blk_off, long* __restrict__ n_out) {
+  __shared__ long s_wave[16];
+  __shared__ long s_carry;
+  const long nblk = (*n_ptr + OV_CB - 1) / OV_CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (long base = 0; base < nblk; base += 1024) {
+    const long b = base + tid;
+    const long v = b < nblk ? blk_cnt[b] : 0;
+    long incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const long u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    long off = 0;
+    for (int w = 0; w < wave; ++w) off += s_wave[w];
+    const long carry = s_carry;
+    if (b < nblk) blk_off[b] = carry + off + incl - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + off + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *n_out = s_carry;
+}
+
+// ordered scatter: list_out[rank of k among the active entries] = list_in[k]  (list_in == nullptr: the identity list)
+__global__ __launch_bounds__(256) void k_cmp_scatter(const long* __restrict__ n_ptr, const unsigned char* __restrict__ flags,
+                                                      const int* __restrict__ list_in, const long* __restrict__ blk_off,
+                                                      int* __restrict__ list_out) {
+  __shared__ int s_w[4];
+  const long n = *n_ptr;
+  const long nblk = (n + OV_CB - 1) / OV_CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const long k0 = b * OV_CB + (long)tid * 8;
+    unsigned m = 0;                                   // bit e: entry k0 + e is active
+    for (int e = 0; e < 8; ++e) m |= (k0 + e < n && flags[k0 + e]) ? (1u << e) : 0u;
+    const int c = __popc(m);
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    long dst = blk_off[b] + off + incl - c;
+    for (int e = 0; e < 8; ++e)
+      if (m >> e & 1u) list_out[dst++] = list_in ? list_in[k0 + e] : (int)(k0 + e);
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ovis_reduce(const int* __restrict__ cid, long n, const float* __restrict__ wdir,
                                                       const float* __restrict__ wsum, const unsigned short* __restrict__ pair_j,
                                                       const int* __restrict__ leaf_st, const long2* __restrict__ point_span,
@@ -411,6 +550,78 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
     hipLaunchKernelGGL(k_ovis_iter<PairRays>, dim3((unsigned)grid), dim3(256), 0, s, T, rays, &lay->total_pairs, 0L, gsize, grp, it,
                        t_st, leaf_st, act_st, counters, lay);
   if (int rc = check_launch("k_ovis_iter")) return rc;
+  hipLaunchKernelGGL(k_ovis_reduce, dim3((unsigned)n), dim3(256), 0, s, chunk_id, n, wdir, wsum, pair_j, leaf_st,
+                     reinterpret_cast<const long2*>(point_span), L, nsamp, argmax_vis, vis_out);
+  if (int rc = check_launch("k_ovis_reduce")) return rc;
+  return 0;
+}
+
+/* rb_dvis_octree with the active rays compacted between the lock-step iterations (same results bit for bit: a ray's state never
+ * depends on where it sits in a launch).  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap] (cap = the size of
+ * pair_p), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2]. */
+int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
+                           const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
+                           const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
+                           int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
+                           unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
+                           long* layout, int* alive_a, int* alive_b, unsigned char* flags, int* blk_cnt, long* blk_off, long* n_alive,
+                           float* vis_out, unsigned long long* eval_count, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(node && nrm && points && normals && dirs && wdir && wsum && vis_out, "null pointer");
+  RB_REQUIRE(pcount && prank && chunk_tab && group_tab && counters && pair_p && pair_j && t_st && leaf_st && act_st && grp &&
+                 point_span && layout && alive_a && alive_b && flags && blk_cnt && blk_off && n_alive,
+             "null scratch pointer");
+  RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch");
+  RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= OV_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
+  RB_REQUIRE(n_chunks >= 1 && (chunk_id || n_chunks == 1), "chunk_id is required for more than one chunk");
+  RB_REQUIRE(max_iter > 0 && max_iter + 2 <= OV_ITERS, "secondary cast: 0 < max_iter <= 32");
+  RB_REQUIRE(batch_pairs > 0 && max_groups >= 1, "bad batch size / group capacity");
+  RB_REQUIRE((long)n * L * nsamp < 2147483647L, "pair indices are 32-bit: call in groups of chunks");
+  hipStream_t s = (hipStream_t)stream;
+  const int LS = L * nsamp;
+  Oct T = make_oct(node, nrm, B, root_min, root_size, res);
+  long* cstart = chunk_tab;
+  long* ctotal = chunk_tab + (n_chunks + 1);
+  long* coff = ctotal + n_chunks;
+  int* goff = reinterpret_cast<int*>(coff + n_chunks);
+  long* gstart = group_tab;
+  long* gsize = group_tab + max_groups;
+  OvisLayout* lay = reinterpret_cast<OvisLayout*>(layout);
+  hipLaunchKernelGGL(k_ovis_count, dim3((unsigned)n), dim3(256), 0, s, normals, chunk_id, n, dirs, LS, pcount);
+  if (int rc = check_launch("k_ovis_count")) return rc;
+  hipLaunchKernelGGL(k_ovis_scan, dim3((unsigned)n_chunks), dim3(1024), 0, s, chunk_id, n, n_chunks, pcount, prank, cstart, ctotal);
+  if (int rc = check_launch("k_ovis_scan")) return rc;
+  hipLaunchKernelGGL(k_ovis_layout, dim3(1), dim3(256), 0, s, n_chunks, ctotal, batch_pairs, coff, goff, gstart, gsize, lay,
+                     counters, max_groups, eval_count);
+  if (int rc = check_launch("k_ovis_layout")) return rc;
+  hipLaunchKernelGGL(k_ovis_fill, dim3((unsigned)n), dim3(256), 0, s, T, points, normals, chunk_id, n, dirs, LS, prank, coff,
+                     goff, batch_pairs, max_groups, pair_p, pair_j, t_st, leaf_st, act_st, grp,
+                     reinterpret_cast<long2*>(point_span), counters);
+  if (int rc = check_launch("k_ovis_fill")) return rc;
+  PairRays rays{points, dirs, chunk_id, pair_p, pair_j, LS};
+  const int grid = ovis_grid();
+  // first list: the pairs the ray set-up left active (identity list, flags = act_st)
+  hipLaunchKernelGGL(k_cmp_count, dim3((unsigned)grid), dim3(256), 0, s, &lay->total_pairs, act_st, blk_cnt);
+  hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, s, &lay->total_pairs, blk_cnt, blk_off, n_alive);
+  hipLaunchKernelGGL(k_cmp_scatter, dim3((unsigned)grid), dim3(256), 0, s, &lay->total_pairs, act_st, (const int*)nullptr, blk_off, alive_a);
+  if (int rc = check_launch("k_cmp_*")) return rc;
+  int* lin = alive_a;
+  int* lout = alive_b;
+  for (int it = 0; it <= max_iter; ++it) {      // the reference leaves its loop when it > max_iter: max_iter + 1 iterations
+    long* n_in = n_alive + (it & 1);
+    long* n_out = n_alive + ((it + 1) & 1);
+    hipLaunchKernelGGL(k_ovis_iter_list<PairRays>, dim3((unsigned)grid), dim3(256), 0, s, T, rays, n_in, lin, gsize, grp, it, t_st,
+                       leaf_st, flags, counters, lay);
+    if (it < max_iter) {
+      hipLaunchKernelGGL(k_cmp_count, dim3((unsigned)grid), dim3(256), 0, s, n_in, flags, blk_cnt);
+      hipLaunchKernelGGL(k_cmp_scan, dim3(1), dim3(1024), 0, s, n_in, blk_cnt, blk_off, n_out);
+      hipLaunchKernelGGL(k_cmp_scatter, dim3((unsigned)grid), dim3(256), 0, s, n_in, flags, lin, blk_off, lout);
+      int* t = lin;
+      lin = lout;
+      lout = t;
+    }
+  }
+  if (int rc = check_launch("k_ovis_iter_list")) return rc;
   hipLaunchKernelGGL(k_ovis_reduce, dim3((unsigned)n), dim3(256), 0, s, chunk_id, n, wdir, wsum, pair_j, leaf_st,
                      reinterpret_cast<const long2*>(point_span), L, nsamp, argmax_vis, vis_out);
   if (int rc = check_launch("k_ovis_reduce")) return rc;

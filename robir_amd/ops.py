@@ -532,17 +532,37 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
 
 
 LAST_OCTREE_VIS_LAYOUT = None
+OVIS_COMPACT = _os.environ.get("ROBIR_OVIS_COMPACT", "1") == "1"   # stable compaction of the active rays between iterations
+OVIS_CHUNKS_PER_CALL = 48       # chunks per traced-visibility launch group: bounds the scratch (28 B per pair slot) to ~5.6 GB
 
 
 def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsamp, argmax_vis=False, eval_count=None,
                 batch_pairs=2000000, max_iter=32, max_points_per_chunk=1024):
-    """Traced light visibility (OctreeVisModel as the VisModel, csrc/octree_vis.hip) -> vis [n, L].  chunk_id ascending."""
+    """Traced light visibility (OctreeVisModel as the VisModel, csrc/octree_vis.hip) -> vis [n, L].  chunk_id ascending.
+    Many chunks are walked in groups of OVIS_CHUNKS_PER_CALL (every chunk is its own set of lock-step groups, so the split
+    changes nothing): the scratch is sized for the largest group instead of the whole view."""
+    global LAST_OCTREE_VIS_LAYOUT
     points, normals = _f32(points), _f32(normals)
     n = points.shape[0]
     dev = points.device
     LS = L * nsamp
     out = torch.empty(n, L, dtype=torch.float32, device=dev)
     if n == 0:
+        return out
+    if chunk_id is not None and n_chunks > OVIS_CHUNKS_PER_CALL:
+        # first row of every chunk (chunk_id ascending): one small device -> host read per view
+        bounds = torch.searchsorted(chunk_id, torch.arange(0, n_chunks + 1, OVIS_CHUNKS_PER_CALL, device=dev, dtype=chunk_id.dtype)
+                                    ).tolist() + [n]
+        total = None
+        for k, c0 in enumerate(range(0, n_chunks, OVIS_CHUNKS_PER_CALL)):
+            a, b = bounds[k], bounds[k + 1] if c0 + OVIS_CHUNKS_PER_CALL < n_chunks else n
+            nc = min(OVIS_CHUNKS_PER_CALL, n_chunks - c0)
+            if b > a:
+                out[a:b] = dvis_octree(T, points[a:b], normals[a:b], (chunk_id[a:b] - c0).contiguous(), nc, dirs[c0 * LS:(c0 + nc) * LS],
+                                       wdir[c0 * LS:(c0 + nc) * LS], wsum[c0 * L:(c0 + nc) * L], L, nsamp, argmax_vis, eval_count,
+                                       batch_pairs, max_iter, max_points_per_chunk)
+                total = LAST_OCTREE_VIS_LAYOUT.clone() if total is None else total + LAST_OCTREE_VIS_LAYOUT
+        LAST_OCTREE_VIS_LAYOUT = total
         return out
     cap = n * LS
     # group table size: groups per chunk from the largest chunk population (k_ovis_layout would truncate the table otherwise).
@@ -560,11 +580,19 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
     pair_j = torch.empty(cap, dtype=torch.int16, device=dev)
     t_st = torch.empty(cap, dtype=torch.float32, device=dev)
     act_st = torch.empty(cap, dtype=torch.uint8, device=dev)
-    call("rb_dvis_octree", *T.args(), ptr(points), ptr(normals), ptr(chunk_id), c_long(n), c_int(n_chunks), ptr(dirs), ptr(wdir),
-         ptr(wsum), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_long(batch_pairs), c_int(max_iter), ptr(pcount),
-         ptr(prank), ptr(chunk_tab), ptr(group_tab), c_int(max_groups), ptr(counters), ptr(pair_p), ptr(pair_j), ptr(t_st),
-         ptr(leaf_st), ptr(act_st), ptr(grp), ptr(point_span), ptr(layout), ptr(out), ptr(eval_count), stream_ptr())
-    global LAST_OCTREE_VIS_LAYOUT
+    common = (*T.args(), ptr(points), ptr(normals), ptr(chunk_id), c_long(n), c_int(n_chunks), ptr(dirs), ptr(wdir),
+              ptr(wsum), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_long(batch_pairs), c_int(max_iter), ptr(pcount),
+              ptr(prank), ptr(chunk_tab), ptr(group_tab), c_int(max_groups), ptr(counters), ptr(pair_p), ptr(pair_j), ptr(t_st),
+              ptr(leaf_st), ptr(act_st), ptr(grp), ptr(point_span), ptr(layout))
+    if OVIS_COMPACT and cap < 2 ** 31 - 1:
+        nblk = cap // 2048 + 2
+        alive_a, alive_b, blk_cnt = i32(cap), i32(cap), i32(nblk)
+        flags = torch.empty(cap + 8, dtype=torch.uint8, device=dev)
+        blk_off, n_alive = i64(nblk), i64(2)
+        call("rb_dvis_octree_compact", *common, ptr(alive_a), ptr(alive_b), ptr(flags), ptr(blk_cnt), ptr(blk_off), ptr(n_alive),
+             ptr(out), ptr(eval_count), stream_ptr())
+    else:
+        call("rb_dvis_octree", *common, ptr(out), ptr(eval_count), stream_ptr())
     LAST_OCTREE_VIS_LAYOUT = layout      # device tensor [pairs, groups, node records read, ray-iterations] of the last call
     return out
 

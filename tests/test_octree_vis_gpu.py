@@ -140,3 +140,29 @@ def test_traced_visibility_through_the_renderer(dev):
     assert torch.equal(hitm, mlp["network_object_mask"])
     assert float((big["vis_shadow"][hitm] - mlp["vis_shadow"][hitm]).abs().mean()) > 1e-2
     assert rel_err(big["diffuse_albedo"].cpu(), mlp["diffuse_albedo"].cpu()) == 0.0
+
+
+def test_compacted_iterations_and_chunk_groups_change_nothing(dev, tracer, monkeypatch):
+    """Round 3: the lock-step iterations walk a stably compacted list of the rays still active (csrc/octree_vis.hip,
+    rb_dvis_octree_compact) and a view's chunks are traced in groups that bound the scratch.  Neither may move a bit: the plain
+    walk over all pairs, the compacted walk, and the compacted walk with the seven chunks cut into groups of 1 / 2 / 3 chunks."""
+    from robir_amd import ops, sg_render, synth
+    g = load_golden("octree_vis")
+    gen = torch.Generator().manual_seed(17)
+    C, n = 7, 64
+    pts, nrm = torch.from_numpy(g["points"])[:n].to(dev), torch.from_numpy(g["normal"])[:n].to(dev)
+    cid = (torch.arange(n) * C // n).to(torch.int32).to(dev)
+    lgt = torch.from_numpy(synth.synth_light_sgs(0, 128)).to(dev)
+    u = torch.rand(2, C, 128, 32, generator=gen).to(dev)
+    outs = {}
+    for name, compact, per_call in (("plain", False, 48), ("compact", True, 48), ("groups1", True, 1), ("groups2", True, 2), ("groups3", False, 3)):
+        monkeypatch.setattr(ops, "OVIS_COMPACT", compact)
+        monkeypatch.setattr(ops, "OVIS_CHUNKS_PER_CALL", per_call)
+        stats = {}
+        outs[name] = (sg_render._diffuse_vis_core(pts, nrm, tracer, lgt, u[0], u[1], 1.0, False, cid, C, stats), int(stats["diffuse_vis_evals"]),
+                      [int(v) for v in ops.LAST_OCTREE_VIS_LAYOUT.cpu()])
+    ref, evals, lay = outs["plain"]
+    assert evals > 100000 and bool(torch.isfinite(ref).all()) and 0.0 < float(ref.mean()) < 1.0
+    for name, (v, e, l) in outs.items():
+        assert e == evals and torch.equal(v, ref), name
+        assert l[0] == lay[0] and l[2] == lay[2] and l[3] == lay[3], (name, l, lay)       # pairs, node records read, ray-iterations
