@@ -268,7 +268,7 @@ int rb_dvis_stream(const float* normals, const int* chunk_id, long n, const floa
  *   chunk_id must be ascending (points of a chunk contiguous).  No host synchronisation.  Scratch (device, caller-provided):
  *   pcount[n] i32, prank[n] i32, chunk_tab[4*n_chunks+4] i64, group_tab[2*max_groups] i64, counters[34*max_groups] i32,
  *   pair_p[cap] i32, pair_j[cap] u16, t_st[cap] f32, leaf_st[cap] i32, act_st[cap] u8, grp[cap] i32 (cap = n*L*nsamp),
- *   point_span[2n] i64, layout[4] i64 (out: [0] pairs traced, [2] 32-byte octree records read, [3] ray-iterations).  max_groups >= sum over chunks of
+ *   point_span[2n] i64, layout[4 + 8192] i64 (out: [0] pairs traced; [4 + 2 b], [5 + 2 b] = 32-byte octree records read / ray-iterations counted by workgroup b mod 4096 -- per-workgroup slots instead of device-wide atomics, the caller adds them up).  max_groups >= sum over chunks of
  *   ceil(pairs / batch_pairs) (<= n_chunks * ceil(points per chunk * L*nsamp / batch_pairs)).
  * rb_octree_cast_grouped: the grouped lock-step secondary cast for explicit rays: group g = rays group_start[g] ..
  *   group_start[g+1]-1 (device array of G+1 offsets) advances on its own schedule, exactly as if each group were a
@@ -284,7 +284,7 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
 /* rb_dvis_octree with the rays still active compacted -- stably, by a prefix sum: list order = (point, direction) order -- between
  * the lock-step iterations, so that an iteration reads and steps only live rays in full waves (the plain form walks every pair 33
  * times).  Bit-identical vis_out.  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap + 8] (cap = size of pair_p,
- * < 2^31), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2]. */
+ * < 2^31), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2] (the two list sizes, ping-pong). */
 int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
                            const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
                            const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,

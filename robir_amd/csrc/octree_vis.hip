@@ -35,6 +35,28 @@ struct OvisLayout {                 // device scalars written by k_ovis_layout /
   unsigned long long ray_steps;     // (ray, iteration) pairs advanced
 };
 
+// Statistics of the iteration kernels: one (records read, ray steps) slot per workgroup behind the OvisLayout struct, updated by
+// plain read-modify-write (a slot belongs to one blockIdx, launches of a call are ordered on their stream); the host adds them up.
+// Device-wide atomics on two addresses cost ~0.6 us each, serialised: 16 k of them per launch were a 10 ms floor per iteration.
+constexpr int OV_STAT_SLOTS = 4096;
+__device__ __forceinline__ void ovis_stats_add(OvisLayout* stats, int nfetch, int nstep) {
+  __shared__ int s_f[4], s_s[4];
+  for (int o = 32; o > 0; o >>= 1) {
+    nfetch += __shfl_xor(nfetch, o);
+    nstep += __shfl_xor(nstep, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_f[threadIdx.x >> 6] = nfetch;
+    s_s[threadIdx.x >> 6] = nstep;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(stats + 1) + 2 * (blockIdx.x % OV_STAT_SLOTS);
+    slot[0] += (unsigned long long)(s_f[0] + s_f[1] + s_f[2] + s_f[3]);
+    slot[1] += (unsigned long long)(s_s[0] + s_s[1] + s_s[2] + s_s[3]);
+  }
+}
+
 // points of chunk c are the contiguous range [lower_bound(cid, c), lower_bound(cid, c + 1))  (cid ascending)
 __device__ __forceinline__ long lower_bound_i32(const int* __restrict__ a, long n, int v) {
   long lo = 0, hi = n;
@@ -123,11 +145,13 @@ __global__ __launch_bounds__(256) void k_ovis_layout(int n_chunks, const long* _
     }
     lay->total_pairs = po;
     lay->total_groups = go < max_groups ? go : max_groups;
-    lay->node_fetches = 0ull;
+    lay->node_fetches = 0ull;      // (the iteration kernels count in the per-workgroup slots behind the struct)
     lay->ray_steps = 0ull;
     if (eval_count) atomicAdd(eval_count, (unsigned long long)po);     // statistics: secondary rays traced
   }
   for (long i = threadIdx.x; i < (long)max_groups * OV_ITERS; i += 256) counters[i] = 0;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(lay + 1);
+  for (int i = threadIdx.x; i < 2 * OV_STAT_SLOTS; i += 256) slots[i] = 0ull;
 }
 
 struct PairRays {                   // rays of the light-visibility pairs: origin = surface point, direction from the table
@@ -188,6 +212,11 @@ __global__ __launch_bounds__(256) void k_ovis_fill(Oct T, const float* __restric
   const float ox = points[3 * p], oy = points[3 * p + 1], oz = points[3 * p + 2];
   if (tid == 0) s_base = 0;
   __syncthreads();
+  // a point's pairs are consecutive in its chunk's order: they fall into at most two consecutive lock-step groups; the active
+  // counts go to the groups' counters once per point (one device-wide atomic per step and wave serialised on the counter)
+  int gfirst = goff[c] + (int)((long)prank[p] / batch);
+  if (gfirst >= max_groups) gfirst = max_groups - 1;
+  int a0 = 0, a1 = 0;
   for (int j0 = 0; j0 < LS; j0 += 256) {
     const int j = j0 + tid;
     bool front = false;
@@ -221,12 +250,29 @@ __global__ __launch_bounds__(256) void k_ovis_fill(Oct T, const float* __restric
       act_st[i] = s.active;
       act = s.active;
     }
-    count_active(act, g, counters, 0);
+    if (act) {
+      if (g == gfirst) ++a0; else ++a1;
+    }
     __syncthreads();
     if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
     __syncthreads();
   }
-  if (tid == 0) point_span[p] = make_long2(first, (long)s_base);
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o);
+    a1 += __shfl_xor(a1, o);
+  }
+  __shared__ int s_a[4][2];
+  if (lane == 0) {
+    s_a[wave][0] = a0;
+    s_a[wave][1] = a1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int t0 = s_a[0][0] + s_a[1][0] + s_a[2][0] + s_a[3][0], t1 = s_a[0][1] + s_a[1][1] + s_a[2][1] + s_a[3][1];
+    if (t0) atomicAdd(&counters[(long)gfirst * OV_ITERS], t0);
+    if (t1) atomicAdd(&counters[(long)(gfirst + 1 < max_groups ? gfirst + 1 : max_groups - 1) * OV_ITERS], t1);
+    point_span[p] = make_long2(first, (long)s_base);
+  }
 }
 
 // one lock-step iteration `it` of every group (octree.py:528-573): rays [0, total) in a grid-stride loop
@@ -265,16 +311,7 @@ __global__ __launch_bounds__(256) void k_ovis_iter(Oct T, Rays rays, const long*
     }
     count_active(act, g, counters, it + 1);
   }
-  if (stats) {
-    for (int o = 32; o > 0; o >>= 1) {
-      nfetch += __shfl_xor(nfetch, o);
-      nstep += __shfl_xor(nstep, o);
-    }
-    if ((threadIdx.x & 63) == 0 && nstep) {
-      atomicAdd(&stats->node_fetches, (unsigned long long)nfetch);
-      atomicAdd(&stats->ray_steps, (unsigned long long)nstep);
-    }
-  }
+  if (stats) ovis_stats_add(stats, nfetch, nstep);
 }
 
 // ---- stable compaction of the rays still active (round 3).  k_ovis_iter above walks ALL pairs at every one of the 33 iterations and
@@ -291,15 +328,22 @@ __global__ __launch_bounds__(256) void k_ovis_iter_list(Oct T, Rays rays, const 
                                                          const int* __restrict__ grp, int it, float* __restrict__ t_st,
                                                          int* __restrict__ leaf_st, unsigned char* __restrict__ flag_out,
                                                          int* __restrict__ counters, OvisLayout* __restrict__ stats) {
+  // Every workgroup walks ONE contiguous stretch of the list (waves still read 64 consecutive entries per step), so a wave meets
+  // one or two lock-step groups per launch and adds its active count to a group's counter once per group, not once per step:
+  // the counters are device-wide atomics on one address per (group, iteration), ~0.6 us each and serialised -- with a grid-stride
+  // walk (a new group every other step) they put a floor of ~6 ms under every iteration launch whatever its size, which made a
+  // view traced in chunk groups 3x slower than in one piece.  (A dynamic hand-out of the list through one device-wide cursor was
+  // measured 4x slower still, for the same reason.)
   const long total = *n_alive;
-  const long stride = (long)gridDim.x * blockDim.x;
-  const long rounds = (total + stride - 1) / stride;
+  const long per_block = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const long k_begin = blockIdx.x * per_block, k_end = k_begin + per_block < total ? k_begin + per_block : total;
   int nfetch = 0, nstep = 0;
-  for (long r = 0; r < rounds; ++r) {
-    const long k = r * stride + blockIdx.x * (long)blockDim.x + threadIdx.x;
+  int pend_g = -1, pend_n = 0;            // wave-uniform: active rays of group pend_g not yet added to its counter
+  for (long kb = k_begin; kb < k_end; kb += 256) {
+    const long k = kb + threadIdx.x;
     bool act = false;
     int g = 0;
-    if (k < total) {
+    if (k < k_end) {
       const long i = list_in[k];
       g = grp[i];
       const int n_act = counters[(long)g * OV_ITERS + it];
@@ -319,18 +363,21 @@ __global__ __launch_bounds__(256) void k_ovis_iter_list(Oct T, Rays rays, const 
       flag_out[k] = s.active;
       act = s.active;
     }
-    count_active(act, g, counters, it + 1);
-  }
-  if (stats) {
-    for (int o = 32; o > 0; o >>= 1) {
-      nfetch += __shfl_xor(nfetch, o);
-      nstep += __shfl_xor(nstep, o);
+    const unsigned long long am = __ballot(act);
+    if (am) {
+      const int g0 = __shfl(g, __ffsll((long long)am) - 1);
+      const unsigned long long same = __ballot(act && g == g0);
+      if (act && g != g0) atomicAdd(&counters[(long)g * OV_ITERS + it + 1], 1);       // a wave across a group boundary: rare
+      if (g0 != pend_g) {
+        if (pend_n && (threadIdx.x & 63) == 0) atomicAdd(&counters[(long)pend_g * OV_ITERS + it + 1], pend_n);
+        pend_g = g0;
+        pend_n = 0;
+      }
+      pend_n += __popcll(same);
     }
-    if ((threadIdx.x & 63) == 0 && nstep) {
-      atomicAdd(&stats->node_fetches, (unsigned long long)nfetch);
-      atomicAdd(&stats->ray_steps, (unsigned long long)nstep);
-    }
   }
+  if (pend_n && (threadIdx.x & 63) == 0) atomicAdd(&counters[(long)pend_g * OV_ITERS + it + 1], pend_n);
+  if (stats) ovis_stats_add(stats, nfetch, nstep);
 }
 
 // active entries per block of OV_CB list entries
@@ -558,7 +605,7 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
 
 /* rb_dvis_octree with the active rays compacted between the lock-step iterations (same results bit for bit: a ray's state never
  * depends on where it sits in a launch).  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap] (cap = the size of
- * pair_p), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2]. */
+ * pair_p), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[40] (list sizes + per-iteration cursors). */
 int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
                            const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
                            const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,

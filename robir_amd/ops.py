@@ -558,7 +558,7 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
             a, b = bounds[k], bounds[k + 1] if c0 + OVIS_CHUNKS_PER_CALL < n_chunks else n
             nc = min(OVIS_CHUNKS_PER_CALL, n_chunks - c0)
             if b > a:
-                out[a:b] = dvis_octree(T, points[a:b], normals[a:b], (chunk_id[a:b] - c0).contiguous(), nc, dirs[c0 * LS:(c0 + nc) * LS],
+                out[a:b] = _dvis_octree_impl(T, points[a:b], normals[a:b], (chunk_id[a:b] - c0).contiguous(), nc, dirs[c0 * LS:(c0 + nc) * LS],
                                        wdir[c0 * LS:(c0 + nc) * LS], wsum[c0 * L:(c0 + nc) * L], L, nsamp, argmax_vis, eval_count,
                                        batch_pairs, max_iter, max_points_per_chunk)
                 total = LAST_OCTREE_VIS_LAYOUT.clone() if total is None else total + LAST_OCTREE_VIS_LAYOUT
@@ -575,7 +575,8 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
     i32 = lambda m: torch.empty(m, dtype=torch.int32, device=dev)
     i64 = lambda m: torch.empty(m, dtype=torch.int64, device=dev)
     pcount, prank, counters = i32(n), i32(n), i32(34 * max_groups)
-    chunk_tab, group_tab, point_span, layout = i64(4 * n_chunks + 4), i64(2 * max_groups), i64(2 * n), i64(4)
+    # layout: 4 scalars + 4096 per-workgroup (records read, ray steps) statistics slots (no device-wide atomics)
+    chunk_tab, group_tab, point_span, layout = i64(4 * n_chunks + 4), i64(2 * max_groups), i64(2 * n), i64(4 + 2 * 4096)
     pair_p, leaf_st, grp = i32(cap), i32(cap), i32(cap)
     pair_j = torch.empty(cap, dtype=torch.int16, device=dev)
     t_st = torch.empty(cap, dtype=torch.float32, device=dev)
@@ -593,8 +594,13 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
              ptr(out), ptr(eval_count), stream_ptr())
     else:
         call("rb_dvis_octree", *common, ptr(out), ptr(eval_count), stream_ptr())
-    LAST_OCTREE_VIS_LAYOUT = layout      # device tensor [pairs, groups, node records read, ray-iterations] of the last call
+    lay4 = layout[:4].clone()            # device tensor [pairs, groups, node records read, ray-iterations] of the last call
+    lay4[2:4] = layout[4:].view(4096, 2).sum(0)
+    LAST_OCTREE_VIS_LAYOUT = lay4
     return out
+
+
+_dvis_octree_impl = dvis_octree      # the chunk groups recurse through this name: a wrapper of ops.dvis_octree sees one call per view
 
 
 def octree_cast_grouped(T, origins, dirs, group_start, max_iter=32):

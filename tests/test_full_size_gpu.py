@@ -278,7 +278,7 @@ def test_config5_whole_view_with_trace_radiance_per_chunk(dev):
     def forward(self, inp, *a, **k):
         o = real_forward(self, inp, *a, **k)
         hit = o["network_object_mask"]
-        c = seen["chunks"]
+        c = seen["chunks"] % 1875             # warm-up pass, then the timed pass
         assert torch.equal(hit, whole[c * 1024:(c + 1) * 1024]), c
         if c % 25 == 0:                 # every 25th chunk in full (a host read per chunk would dominate the loop)
             ok = ~torch.isnan(o["points"][:, 0])
