@@ -261,12 +261,19 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
         // the three stages of the previous chunk's two register pairs.
 #define X6_RUN(ACC, WP, XP, K0) \
   _Pragma("unroll") for (int kb = (K0); kb < (K0) + 4; ++kb) X6_MFMA(ACC, WP[kb], XP[kb])
-#if X6_VOFF
+#if defined(X6_ABL_NODMA)            // timing ablation (wrong results): no weight copies
+#define X6_COPY(I) (void)0
+#elif X6_VOFF
 #define X6_COPY(I) x6_dma16(dsrc, row_off[I], ddst + (unsigned)(I) * 4096u)
 #else
 #define X6_COPY(I) x6_dma16(dsrc + (I) * 256, lane_off, ddst + (unsigned)(I) * 4096u)
 #endif
 #define X6_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifdef X6_ABL_NOLDS                   // timing ablation (wrong results): no fragment reads
+#define X6_FRAG(DST, KB, PIECE) asm volatile("" : "+v"(DST))
+#else
+#define X6_FRAG(DST, KB, PIECE) DST = nring[((KB) * 3 + (PIECE)) * 64]
+#endif
         X6_RUN(acc.c2, wl, xh, 0);      // run A: wl.xh -> class 2
         X6_COPY(0);
         X6_FENCE;
@@ -276,18 +283,18 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
         X6_FENCE;
         X6_RUN(acc.c2, wm, xm, 0);      // run B: wm.xm -> class 2
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) wl[kb] = nring[(kb * 3 + 2) * 64];
+        for (int kb = 0; kb < 4; ++kb) X6_FRAG(wl[kb], kb, 2);
         X6_FENCE;
         X6_RUN(acc.c2, wm, xm, 4);
         if (jb > 0) ep_stage2(0);
-        wl[4] = nring[(4 * 3 + 2) * 64];
-        wl[5] = nring[(5 * 3 + 2) * 64];
+        X6_FRAG(wl[4], 4, 2);
+        X6_FRAG(wl[5], 5, 2);
         X6_FENCE;
         X6_RUN(acc.c2, wh, xl, 0);      // run C: wh.xl -> class 2
         X6_COPY(2);
         if (jb > 0) ep_stage3(jb - 1, 0);
-        wl[6] = nring[(6 * 3 + 2) * 64];
-        wl[7] = nring[(7 * 3 + 2) * 64];
+        X6_FRAG(wl[6], 6, 2);
+        X6_FRAG(wl[7], 7, 2);
         X6_FENCE;
         X6_RUN(acc.c2, wh, xl, 4);
         X6_COPY(3);
@@ -303,22 +310,23 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
         X6_FENCE;
         X6_RUN(acc.c1, wh, xm, 0);      // run E: wh.xm -> class 1
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) wm[kb] = nring[(kb * 3 + 1) * 64];
+        for (int kb = 0; kb < 4; ++kb) X6_FRAG(wm[kb], kb, 1);
         X6_FENCE;
         X6_RUN(acc.c1, wh, xm, 4);
 #pragma unroll
-        for (int kb = 4; kb < 8; ++kb) wm[kb] = nring[(kb * 3 + 1) * 64];
+        for (int kb = 4; kb < 8; ++kb) X6_FRAG(wm[kb], kb, 1);
         X6_FENCE;
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {   // run F: wh.xh -> class 0, each fragment refilled right behind its MFMA
           X6_MFMA(acc.c0, wh[kb], xh[kb]);
-          wh[kb] = nring[(kb * 3 + 0) * 64];
+          X6_FRAG(wh[kb], kb, 0);
           if (kb == 3) X6_FENCE;
         }
         X6_FENCE;
 #undef X6_RUN
 #undef X6_COPY
 #undef X6_FENCE
+#undef X6_FRAG
         prev = acc;
         bias = nbias;
       }

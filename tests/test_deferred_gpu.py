@@ -49,25 +49,28 @@ def _view(dev, h, w):
     return mi, total
 
 
-def split_input(model_input, total_pixels, n_pixels=1024):          # utils/general.py:27-38
-    split = []
-    for indx in torch.split(torch.arange(total_pixels, device=model_input["uv"].device), n_pixels, dim=0):
-        data = model_input.copy()
-        data["uv"] = torch.index_select(model_input["uv"], 1, indx)
-        data["object_mask"] = torch.index_select(model_input["object_mask"], 1, indx)
-        split.append(data)
-    return split
+def split_input(model_input, total_pixels, n_pixels=1024):
+    """A view cut into per-chunk input dicts the way the runners' helper does (utils/general.py:27-38): the per-pixel entries
+    (uv, object_mask) are gathered per chunk with index_select -- the op the deferred placeholders have to cope with --, the
+    camera entries are shared."""
+    dev = model_input["uv"].device
+    per_pixel = ("uv", "object_mask")
+    chunks = []
+    for first in range(0, total_pixels, n_pixels):
+        rows = torch.arange(first, min(first + n_pixels, total_pixels), device=dev)
+        chunks.append({k: (torch.index_select(v, 1, rows) if k in per_pixel else v) for k, v in model_input.items()})
+    return chunks
 
 
-def merge_output(res, total_pixels, batch_size=1):                   # utils/general.py:55-69
-    out = {}
-    for entry in res[0]:
-        if len(res[0][entry].shape) == 1:
-            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, 1) for r in res], 1).reshape(batch_size * total_pixels)
-        else:
-            out[entry] = torch.cat([r[entry].reshape(batch_size, -1, r[entry].shape[-1]) for r in res],
-                                   1).reshape(batch_size * total_pixels, -1)
-    return out
+def merge_output(res, total_pixels, batch_size=1):
+    """Per-chunk result dicts -> whole-view tensors, with the tensor ops of utils/general.py:55-69 (reshape to [batch, pixels, width],
+    cat along the pixel axis, flatten): 1-D entries come out [batch * pixels], the others [batch * pixels, width]."""
+    def whole(key):
+        flat = res[0][key].dim() == 1
+        parts = [r[key].reshape(batch_size, -1, 1 if flat else r[key].shape[-1]) for r in res]
+        joined = torch.cat(parts, 1)
+        return joined.reshape(batch_size * total_pixels) if flat else joined.reshape(batch_size * total_pixels, -1)
+    return {key: whole(key) for key in res[0]}
 
 
 def plot_loop(model, split, total):

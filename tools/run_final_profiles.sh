@@ -1,33 +1,44 @@
-# Round-end measurement session -> gpurun_out/final/ (copied to profiles/ by hand): bench lines, rocprofv3 kernel traces of the
-# bench, of BASELINE configs 2/3/5, of the per-chunk forward loop and of the SDF value+gradient op, PMC passes of the SDF ring
-# (value pass) and backward kernels, the deferred runner loop.
+# Round-end measurement session -> gpurun_out/final/ (copied to profiles/ by hand): bench lines (headline = exact operands, split
+# precision, traced visibility, 2 ranks on one GPU), rocprofv3 kernel traces of the bench and of BASELINE configs 2/3/5, PMC passes
+# of the dominant kernels, per-chunk / deferred rates.  usage: bash tools/run_final_profiles.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/final
 mkdir -p $O
-python bench.py > $O/${TAG}_bench_f16x3.json 2> $O/bench.err
-python bench.py --vis-precision fp32 --no-cpu-baseline --steps 2 > $O/${TAG}_bench_fp32.json 2>> $O/bench.err
-python bench.py --vis octree --steps 2 --no-cpu-baseline > $O/${TAG}_bench_octree_vis.json 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/p -o trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact > $O/p.log 2>&1
-python tools/rocpd_summary.py $(find $O/p -name '*.db' | head -1) > $O/${TAG}_bench_f16x3_kernel_stats.md; rm -rf $O/p
-rocprofv3 --kernel-trace --stats -d $O/p -o trace -- python bench.py --vis octree --steps 2 --warmup 1 --no-cpu-baseline > $O/p.log 2>&1
-python tools/rocpd_summary.py $(find $O/p -name '*.db' | head -1) > $O/${TAG}_bench_octree_vis_kernel_stats.md; rm -rf $O/p
-python tools/bench_configs.py 1 2 3 5 2>/dev/null | grep "^config" > $O/${TAG}_config_rates.txt
-for C in 2 3 5; do
-  RB_CONFIG_REPS=1 rocprofv3 --kernel-trace --stats -d $O/p -o trace -- python tools/bench_configs.py $C > $O/p.log 2>&1
-  python tools/rocpd_summary.py $(find $O/p -name "*.db" | head -1) > $O/${TAG}_config${C}_kernel_stats.md; rm -rf $O/p
-done
-rocprofv3 --kernel-trace --stats -d $O/p -o trace -- python tools/prof_perchunk.py > $O/${TAG}_perchunk.log 2>&1
-python tools/rocpd_summary.py $(find $O/p -name '*.db' | head -1) > $O/${TAG}_perchunk_kernel_stats.md; rm -rf $O/p
+prof() {  # name, command...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $O/p -o trace -- "$@" > $O/p.log 2>&1
+  python tools/rocpd_summary.py $(find $O/p -name '*.db' | head -1) > $O/${TAG}_${name}_kernel_stats.md; rm -rf $O/p
+}
+pmc() {   # name, grep pattern, command... (two SQ passes + FETCH_SIZE + WRITE_SIZE)
+  local name=$1 pat=$2; shift 2
+  : > $O/${TAG}_${name}_pmc.md
+  for CS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
+    rocprofv3 --pmc $CS --kernel-trace -d $O/p -o p -- "$@" > $O/p.log 2>&1
+    python tools/rocpd_summary.py $(find $O/p -name "*.db" | head -1) | grep -i "$pat" >> $O/${TAG}_${name}_pmc.md; rm -rf $O/p
+  done
+}
+python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/bench.err
+python bench.py --precision split --steps 5 --warmup 2 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_split.json 2>> $O/bench.err
+python bench.py --vis octree --steps 3 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_octree_vis.json 2>> $O/bench.err
+python bench.py --scene nonconvex --steps 3 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_nonconvex.json 2>> $O/bench.err
+python bench.py --gpus 2 --steps 2 --warmup 1 --precision split > $O/${TAG}_bench_2rank_shared_gpu.json 2>> $O/bench.err
+for C in 2 3 5; do python bench.py --config $C --precision split --steps 2 > $O/${TAG}_config${C}_split.json 2>> $O/bench.err; done
+prof bench python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-configs
+prof bench_split python bench.py --precision split --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-configs
+prof bench_octree_vis python bench.py --vis octree --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-configs
+export ROBIR_PRECISION=split
+for C in 2 3 5; do RB_CONFIG_REPS=1 prof config$C python tools/bench_configs.py $C; done
+prof perchunk python tools/prof_perchunk.py
 python tools/prof_perchunk.py 2>/dev/null | grep per-chunk > $O/${TAG}_perchunk_rate.txt
 python tools/prof_deferred.py 1024 128 2>/dev/null | grep -v "BOX\|boxes" > $O/${TAG}_deferred_rates.txt
-rocprofv3 --kernel-trace --stats -d $O/p -o trace -- python tools/prof_sdf_grad.py > $O/${TAG}_sdf_grad_rate.txt 2>/dev/null
-python tools/rocpd_summary.py $(find $O/p -name '*.db' | head -1) > $O/${TAG}_sdf_grad_kernel_stats.md; rm -rf $O/p
-: > $O/${TAG}_sdf_ring_pmc.md
-for CS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
-  RB_CONFIG_REPS=1 rocprofv3 --pmc $CS --kernel-trace -d $O/p -o p -- python tools/bench_configs.py 2 > $O/p.log 2>&1
-  python tools/rocpd_summary.py $(find $O/p -name "*.db" | head -1) | grep -i "sdf_ring<5>\|sdf_back" >> $O/${TAG}_sdf_ring_pmc.md; rm -rf $O/p
-done
+unset ROBIR_PRECISION
+python tools/prof_perchunk.py 2>/dev/null | grep per-chunk | sed 's/^/exact policy: /' >> $O/${TAG}_perchunk_rate.txt
+pmc dvis_x6 "dvis_x6" python tools/prof_dvis.py f16x6 32
+pmc dvis_v2 "dvis_v2" python tools/prof_dvis.py f16x3-v2 32
+export ROBIR_PRECISION=split RB_CONFIG_REPS=1
+pmc config2 "sdf_ring8\|sdf_back\|color_mlp" python tools/bench_configs.py 2
+pmc config5 "softplus512\|wide_mlp\|dvis" python tools/bench_configs.py 5
 rm -f $O/p.log
-cat $O/${TAG}_config_rates.txt $O/${TAG}_perchunk_rate.txt $O/${TAG}_deferred_rates.txt; grep "mode:" $O/${TAG}_sdf_grad_rate.txt; tail -c 400 $O/${TAG}_bench_f16x3.json
+cat $O/${TAG}_perchunk_rate.txt $O/${TAG}_deferred_rates.txt; tail -c 300 $O/${TAG}_bench.json; echo; grep -c . $O/bench.err
