@@ -41,7 +41,8 @@ sys.path.insert(0, ROOT)
 VIS_MACS_PER_EVAL = 229376          # 126*256 + 3*256*256 + 256*2
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
-TRAFFIC_B_PER_PAIR = 24.0          # profiles/r02_dvis_pmc.md: (2 x FETCH_SIZE + WRITE_SIZE) / pairs of k_dvis_v2 at 32 chunks per launch (r01: 28-31)
+# HBM bytes per (point, direction) pair: (2 x FETCH_SIZE + WRITE_SIZE) / pairs at 32 chunks per launch, profiles/r03_pmc_summary.md
+TRAFFIC_B_PER_PAIR = {"f16x6": 39.3, "default": 22.1}
 H = W = 800
 CHUNK = 1024
 
@@ -239,7 +240,12 @@ def self_launch(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    # stdout carries ONE JSON line: anything else the ranks' libraries print there (gloo announces its peers on stdout) goes to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
 
 
 def set_precision(name, vis_override=None):
@@ -368,7 +374,8 @@ def main():
                 # HBM bytes per launch: B per (point, direction) pair measured with rocprofv3 --pmc FETCH_SIZE (x2 gfx950
                 # correction) + WRITE_SIZE on this kernel family (profiles/), scaled to this launch's pair count: well under
                 # 1 % of the HBM roofline -- the bound is the matrix pipe
-                "traffic": TRAFFIC_B_PER_PAIR * evals / max(k_n, 1), "traffic_unit": "B/launch (scaled from the PMC profile)",
+                "traffic": TRAFFIC_B_PER_PAIR.get(vis, TRAFFIC_B_PER_PAIR["default"]) * evals / max(k_n, 1),
+                "traffic_unit": "B/launch (scaled from the PMC profile)",
                 "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                 "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
@@ -411,7 +418,7 @@ def main():
         # per-pair state written once and read once (pair 6 B, t 4, leaf 4, active 1, group 4) and the active flag re-read by
         # every one of the 33 iterations
         bytes_launch = 32.0 * fetches + pairs * (2 * 19.0 + 33.0)
-        octree_line = {"bound": "hbm", "kernel": "k_ovis_iter x33 + cull / fill / reduce (traced light visibility)",
+        octree_line = {"bound": "hbm", "kernel": "k_ovis_iter_list x33 + compaction / cull / fill / reduce (traced light visibility)",
                        "achieved": bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
                        "traffic": None, "launches": k_n, "avg_launch_ms": k_ms, "pairs_per_launch": pairs,
                        "octree_records_read_per_ray": fetches / max(pairs, 1), "iterations_per_ray": ray_steps / max(pairs, 1),
