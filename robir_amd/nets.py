@@ -636,9 +636,16 @@ class NeuSModel(nn.Module):
         v = self.deviation_network.variance
         key = (v.data_ptr(), v._version, v.device)
         if getattr(self, "_inv_s_key", None) != key:
-            self._inv_s_val = float(torch.exp(v.detach() * 10.0).clip(1e-6, 1e6))
+            raw = float(torch.exp(v.detach() * 10.0))
+            self._inv_s_raw = raw
+            self._inv_s_val = min(max(raw, 1e-6), 1e6)
             self._inv_s_key = key
         return self._inv_s_val
+
+    def inv_s_unclipped(self):
+        """exp(10 * variance) as NormalTrainRunner.get_neus_surface uses it (no clip), from the same cache (no host read per call)."""
+        self.inv_s()
+        return self._inv_s_raw
 
     def refresh_inv_s(self):
         self._inv_s_key = None

@@ -129,7 +129,7 @@ def get_neus_surface(implicit_network, points, view_dirs, pred_normals, n_samp=3
     xs = torch.empty(m * n_samp, 3, device=dev)
     call("rb_surface_points", ptr(p), ptr(v), ptr(tk), c_long(m), c_int(n_samp), ptr(xs), stream_ptr())
     sdf, grad = implicit_network.neus_model.sdf_network.eval_points(xs, 2.0, 0.5, full=False, grad=True)
-    s = float(torch.exp(implicit_network.neus_model.deviation_network.variance.detach() * 10.0))   # unclipped here
+    s = implicit_network.neus_model.inv_s_unclipped()     # cached on the parameter's version: no device read per call
     x_out, n_out = torch.empty(m, 3, device=dev), torch.empty(m, 3, device=dev)
     gerr = torch.zeros(2, device=dev)
     call("rb_surface_finish", ptr(sdf), ptr(grad), ptr(xs), ptr(p), ptr(pn), c_long(m), c_int(n_samp), c_float(s),
