@@ -41,13 +41,20 @@ def gather_image(local_tiles, n_chunks, chunk, interleave=True):
     F = local_tiles.shape[1]
     pad = torch.zeros(per * chunk, F, dtype=local_tiles.dtype, device=local_tiles.device)
     pad[: local_tiles.shape[0]] = local_tiles
-    allt = all_gather_tiles(pad).reshape(world, per, chunk, F)
-    img = torch.empty(n_chunks, chunk, F, dtype=local_tiles.dtype, device=local_tiles.device)
-    for r in range(world):
-        ids = shard_chunks(n_chunks, r, world, interleave)
-        img[ids] = allt[r, : len(ids)]
-    return img.reshape(n_chunks * chunk, F)
+    allt = all_gather_tiles(pad).reshape(world * per, chunk, F)
+    # chunk c sits at slot (rank, position in the rank's list): one gather through an index built once per (layout, device)
+    key = (n_chunks, world, bool(interleave), str(local_tiles.device))
+    src = _GATHER_INDEX.get(key)
+    if src is None:
+        slot = [0] * n_chunks
+        for r in range(world):
+            for k, c in enumerate(shard_chunks(n_chunks, r, world, interleave)):
+                slot[c] = r * per + k
+        src = _GATHER_INDEX[key] = torch.tensor(slot, dtype=torch.int64, device=local_tiles.device)
+    return allt.index_select(0, src).reshape(n_chunks * chunk, F)
 
+
+_GATHER_INDEX = {}
 
 TILE_FIELDS = ("sg_rgb", "indir_rgb", "diffuse_albedo", "roughness", "vis_shadow", "normal_map", "network_object_mask")
 
