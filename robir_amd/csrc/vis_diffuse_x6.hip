@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6(
         } else {
           asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         }
+#ifndef X6_ABL_NOBAR                  // timing ablation (wrong results): no per-chunk barrier
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         const int nx3 = jb + X6_DIST;
         const f4* dsrc = nx3 < 16 ? Wl + (long)nx3 * X6_CF4 : Wn + (long)(nx3 - 16) * X6_CF4;

@@ -177,7 +177,7 @@ def test_visibility_point_without_front_facing_directions(dev, oracle_sd):
     nrm[2] = 0.0
     u = torch.rand(2, 128, 32, generator=g)
     old_default = sg_render.VIS_PRECISION
-    for prec in ("f16x3-v3", "f16x3-v2", "f16x3", "fp32"):
+    for prec in ("f16x6", "f16x3-v3", "f16x3-v2", "f16x3", "fp32"):
         sg_render.VIS_PRECISION = prec
         try:
             v = sg_render._diffuse_vis_core(pts.to(dev), nrm.to(dev), m.visibility_network, lgt.to(dev), u[0].to(dev),
@@ -188,3 +188,54 @@ def test_visibility_point_without_front_facing_directions(dev, oracle_sd):
         lobe = lgt[:, :3] / (lgt[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
         ref = osg.diffuse_visibility(pts, nrm, lambda p, d: on.vis_logits(oracle_sd, p, d), lobe, lgt[:, 3:4].abs(), u[0], u[1]).t()
         assert rel_err(v, ref) <= 1e-4, prec
+
+
+def test_round3_entry_points_on_empty_and_tiny_inputs(dev, synth_weights):
+    """Zero rows / one row through the fused-encoding entry points, the exact-operand visibility kernel with argmax and a
+    small lobe table, and the traced visibility without chunk ids: no launch on empty input, shapes kept, finite results."""
+    from robir_amd import ops, packing, renderer, sg_render, synth
+    from robir_amd.octree_tracing import OctreeVisModel
+    full = packing.pack_sdf_h3(synth_weights, dev, full=True)
+    full32 = packing.pack_sdf(synth_weights, dev, full=True)
+    e3 = torch.zeros(0, 3, device=dev)
+    assert ops.sdf_points_h3(e3, 0, full, True, packing.H3_SCALE_LOG2).shape == (0, 257)
+    o, g = ops.sdf_points_jvp_h3(e3, 0, full, True, packing.H3_SCALE_LOG2)
+    assert o.shape == (0, 257) and g.shape == (0, 3)
+    o, g = ops.sdf_mlp_points(e3, 0, full32, 3)
+    assert o.shape == (0, 257) and g.shape == (0, 3)
+    assert ops.vis_mlp_points(e3, e3, packing.pack_vis(synth_weights, dev)).shape == (0, 2)
+    assert ops.linear_pe10_256(e3, packing.pack_vis_split(synth_weights, dev)["point"]).shape == (0, 256)
+    one = torch.tensor([[0.05, -0.1, 0.2]], device=dev)
+    assert bool(torch.isfinite(ops.sdf_points_h3(one, 1, full, True, packing.H3_SCALE_LOG2)).all())
+    # exact-operand visibility: 8 lobes x 4 samples, argmax and softmax, a single point
+    m = renderer.build_synthetic_model(dev)
+    lgt = torch.from_numpy(synth.synth_light_sgs(0, 128))[:8].to(dev)
+    gen = torch.Generator().manual_seed(2)
+    u = torch.rand(2, 8, 4, generator=gen).to(dev)
+    nrm = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+    old = sg_render.VIS_PRECISION
+    try:
+        outs = {}
+        for prec in ("f16x6", "fp32"):
+            sg_render.VIS_PRECISION = prec
+            outs[prec] = [sg_render._diffuse_vis_core(one, nrm, m.visibility_network, lgt, u[0], u[1], 1.0, am, None, 1, None) for am in (False, True)]
+        for a, b in zip(outs["f16x6"], outs["fp32"]):
+            assert a.shape == (1, 8) and float((a - b).abs().max()) <= 2e-6
+        assert sg_render._diffuse_vis_core(e3, e3, m.visibility_network, lgt, u[0], u[1], 1.0, False, None, 1, None).shape == (0, 8)
+    finally:
+        sg_render.VIS_PRECISION = old
+    # traced visibility: one chunk without chunk ids, compacted and plain
+    tr = OctreeVisModel(m.octree_ray_tracer)
+    pts = torch.tensor([[0.0, 0.0, 0.26], [0.1, 0.0, 0.24]], device=dev)
+    nr = torch.nn.functional.normalize(pts, dim=-1)
+    lg = torch.from_numpy(synth.synth_light_sgs(0, 128)).to(dev)
+    uu = torch.rand(2, 128, 32, generator=gen).to(dev)
+    a = sg_render._diffuse_vis_core(pts, nr, tr, lg, uu[0], uu[1], 1.0, False, None, 1, None)
+    old_c = ops.OVIS_COMPACT
+    try:
+        ops.OVIS_COMPACT = False
+        b = sg_render._diffuse_vis_core(pts, nr, tr, lg, uu[0], uu[1], 1.0, False, None, 1, None)
+    finally:
+        ops.OVIS_COMPACT = old_c
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    ops.range_check(sync=True)
