@@ -173,6 +173,12 @@ int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, c
  * model/neus_model.py:535-545): no tail rows, no rb_feat_color_tail launch; bit-identical rgb. */
 int rb_color_mlp_h3_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                            const float* normal, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
+/* The same network on the eight-wave chunk-stream machine of rb_sdf_points_ring (csrc/color_ring8.hip: persistent workgroups, the
+ * five layers as one cyclic stream of 65 chunks through an LDS-DMA ring, two waves per SIMD): bit-identical rgb, the default for
+ * batches that fill the chip (n_workgroups <= 0: one workgroup per compute unit). */
+int rb_color_ring_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                         const float* normal, long M, const float* Wp, int scale_log2, float* rgb, int n_workgroups,
+                         rb_stream_t stream);
 /* f32-input-MFMA form of the same (rb_feat_color + rb_color_mlp without the assembled [M,304] rows). */
 int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                         const float* normal, long M, const float* Wp, float* rgb, rb_stream_t stream);

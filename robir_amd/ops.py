@@ -84,12 +84,22 @@ def color_mlp_h3_two(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_
     return rgb
 
 
-def color_mlp_h3_points(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_scale=1.0):
-    """The colour net with its encoding fused: feature columns read in place, [x | PE4(view) | normal] encoded inside the kernel."""
+COLOR_RING_MIN_ROWS = 8192        # below this the persistent eight-wave kernel cannot fill the chip: first-generation kernel
+
+
+def color_mlp_h3_points(x, view, normal, feat, blob, scale_log2, x_scale=1.0, feat_scale=1.0, ring=None):
+    """The colour net with its encoding fused: feature columns read in place, [x | PE4(view) | normal] encoded inside the kernel.
+    ring (default: by batch size): the eight-wave chunk-stream kernel (csrc/color_ring8.hip) -- bit-identical rgb."""
     x, view, normal = _f32(x), _f32(view), _f32(normal)
     assert feat.dtype == torch.float32 and feat.stride(-1) == 1
     M = x.shape[0]
     rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    if ring is None:
+        ring = M >= COLOR_RING_MIN_ROWS
+    if ring:
+        call("rb_color_ring_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x),
+             c_float(x_scale), ptr(view), ptr(normal), c_long(M), ptr(blob), c_int(scale_log2), ptr(rgb), c_int(0), stream_ptr())
+        return rgb
     call("rb_color_mlp_h3_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
          ptr(view), ptr(normal), c_long(M), ptr(blob), c_int(scale_log2), ptr(rgb), stream_ptr())
     return rgb

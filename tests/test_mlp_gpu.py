@@ -493,14 +493,25 @@ def test_colour_net_with_fused_encoding_is_bit_identical(dev, synth_weights):
     from robir_amd import ops, packing
     blob = packing.pack_color_h3(synth_weights, dev)
     g = torch.Generator().manual_seed(77)
-    for n in (1, 31, 128, 129, 5000):
+    for n in (1, 31, 128, 129, 5000, 33000):
         x = ((torch.rand(n, 3, generator=g) - 0.5)).to(dev)
         v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         out = torch.randn(n, 257, generator=g).to(dev)          # SDF-net rows: the 256 feature columns are read in place
         a = ops.color_mlp_h3_two(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0)
-        b = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0)
-        assert torch.equal(a, b), n
+        b = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0, ring=False)
+        c = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0, ring=True)
+        assert torch.equal(a, b) and torch.equal(a, c), n
+    # the chunk-stream kernel over many rounds per workgroup (persistent grid), run to run
+    n = 300001
+    x = ((torch.rand(n, 3, generator=g) - 0.5)).to(dev)
+    v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    out = torch.randn(n, 257, generator=g).to(dev)
+    a = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0, ring=False)
+    for _ in range(3):
+        c = ops.color_mlp_h3_points(x, v, nr, out[:, 1:], blob, packing.H3_SCALE_LOG2, x_scale=2.0, feat_scale=2.0, ring=True)
+        assert torch.equal(a, c)
     ops.range_check(sync=True)
 
 
