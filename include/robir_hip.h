@@ -158,6 +158,14 @@ int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const floa
  * shadow_net on (point, one-hot label) rows [M = points * n_label rows]; = rb_feat_pe10 + rb_cesr_net[_h3]. */
 int rb_cesr_net_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
 int rb_cesr_net_h3_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y, rb_stream_t stream);
+/* The split-precision 512-wide nets on the chunk-stream machine (csrc/wide_ring.h: persistent workgroups of four waves, the net as one
+ * cyclic stream of 16-neuron chunks through an LDS-DMA ring, activation + hi/lo split between the next chunk's MFMAs): the same
+ * arguments and bit-identical outputs as rb_cesr_net_h3_points / rb_wide_mlp_h3_points, the default for batches that fill the chip.
+ * n_workgroups <= 0: one workgroup per compute unit. */
+int rb_cesr_net_ring_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y, int n_workgroups,
+                            rb_stream_t stream);
+int rb_wide_mlp_ring_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
+                            int n_workgroups, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);

@@ -142,15 +142,24 @@ def linear_pe10_256(x, blob):
     return Y
 
 
-def wide_mlp_points(x, extra, blob, encoder, scale_log2=None):
+WIDE_RING_MIN_ROWS = 4096         # below this the persistent four-wave kernels cannot fill the chip: first-generation kernels
+
+
+def wide_mlp_points(x, extra, blob, encoder, scale_log2=None, ring=None):
     """512-wide nets on [PE10(x) | extra] with the encoding fused: encoder=False -> raw SG outputs [M,144], True -> raw latent [M,32];
-    scale_log2 None = f32-input MFMA kernel, else split precision."""
+    scale_log2 None = f32-input MFMA kernel, else split precision; ring (split precision; default: by batch size): the chunk-stream
+    kernel (csrc/wide_ring.h) -- bit-identical outputs."""
     x = _f32(x)
     M = x.shape[0]
     e = _f32(extra).reshape(-1) if extra is not None else None
     Y = torch.empty(M, 32 if encoder else 144, dtype=torch.float32, device=x.device)
+    if ring is None:
+        ring = M >= WIDE_RING_MIN_ROWS
     if scale_log2 is None:
         call("rb_wide_mlp_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), ptr(Y), stream_ptr())
+    elif ring:
+        call("rb_wide_mlp_ring_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), c_int(scale_log2), ptr(Y),
+             c_int(0), stream_ptr())
     else:
         call("rb_wide_mlp_h3_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), c_int(scale_log2), ptr(Y),
              stream_ptr())
@@ -755,12 +764,18 @@ def cesr_net_h3(X, M, kind, blob, scale_log2, n_label=1):
     return Y
 
 
-def cesr_net_points(x, M, kind, blob, n_label=1, scale_log2=None):
-    """cesr_net / cesr_net_h3 on PE10(x) with the encoding fused (kind 0: M = points; kind 2: M = points * n_label rows)."""
+def cesr_net_points(x, M, kind, blob, n_label=1, scale_log2=None, ring=None):
+    """cesr_net / cesr_net_h3 on PE10(x) with the encoding fused (kind 0: M = points; kind 2: M = points * n_label rows).
+    ring (split precision; default: by batch size): the chunk-stream kernel (csrc/wide_ring.h) -- bit-identical outputs."""
     x = _f32(x)
     Y = torch.empty(M, 3 if kind == 0 else 2, dtype=torch.float32, device=x.device)
+    if ring is None:
+        ring = M >= WIDE_RING_MIN_ROWS
     if scale_log2 is None:
         call("rb_cesr_net_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), stream_ptr())
+    elif ring:
+        call("rb_cesr_net_ring_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), c_int(scale_log2), ptr(Y), c_int(0),
+             stream_ptr())
     else:
         call("rb_cesr_net_h3_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), c_int(scale_log2), ptr(Y), stream_ptr())
     return Y

@@ -588,3 +588,35 @@ def test_cesr_nets_with_fused_encoding_are_bit_identical(dev):
         assert torch.equal(ops.cesr_net_points(p, n, 0, no32), ops.cesr_net(Xp, n, 0, no32))
         assert torch.equal(ops.cesr_net_points(p, n, 0, no16, 1, packing.H3_SCALE_LOG2), ops.cesr_net_h3(Xp, n, 0, no16, packing.H3_SCALE_LOG2))
     ops.range_check(sync=True)
+
+
+def test_wide_ring_kernels_are_bit_identical_to_the_first_generation(dev, synth_weights):
+    """The 512-wide nets on the chunk-stream machine (csrc/wide_ring.h): same products, same order, same epilogue arithmetic as
+    k_softplus512_h3 / k_wide_mlp_h3 -- identical bits at ragged sizes, over many rounds per workgroup and run to run."""
+    from robir_amd import ops, packing, synth
+    c = synth.synth_cesr_nets(0)
+    g = torch.Generator().manual_seed(67)
+    s = packing.H3_SCALE_LOG2
+    sh16 = packing.pack_softplus512_h3({"net." + k: v for k, v in c["shadow_net"].items()}, "net.", 191, dev)
+    no16 = packing.pack_softplus512_h3({"net." + k: v for k, v in c["normal_net"].items()}, "net.", 63, dev)
+    ill16 = packing.pack_illum_h3(synth_weights, dev)
+    enc16 = packing.pack_sparse_ae_encoder_h3(synth_weights, "envmap_material_network.spec_brdf_encoder_layer", dev)
+    for n in (1, 15, 64, 65, 1000, 40000):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        hdr = torch.rand(n, 1, generator=g).to(dev)
+        for nl in ((128,) if n > 1000 else (1, 3, 128)):
+            if n * nl > 600000:
+                continue
+            a = ops.cesr_net_points(p, n * nl, 2, sh16, nl, s, ring=False)
+            b = ops.cesr_net_points(p, n * nl, 2, sh16, nl, s, ring=True)
+            assert torch.equal(a, b), ("shadow_net", n, nl)
+        a = ops.cesr_net_points(p, n, 0, no16, 1, s, ring=False)
+        for _ in range(2):
+            assert torch.equal(a, ops.cesr_net_points(p, n, 0, no16, 1, s, ring=True)), ("normal_net", n)
+        assert torch.equal(ops.wide_mlp_points(p, hdr, ill16, False, s, ring=False), ops.wide_mlp_points(p, hdr, ill16, False, s, ring=True)), n
+        assert torch.equal(ops.wide_mlp_points(p, None, enc16, True, s, ring=False), ops.wide_mlp_points(p, None, enc16, True, s, ring=True)), n
+    p = ((torch.rand(3000, 3, generator=g) - 0.5) * 0.6).to(dev)
+    a = ops.cesr_net_points(p, 3000 * 128, 2, sh16, 128, s, ring=False)
+    for _ in range(3):
+        assert torch.equal(a, ops.cesr_net_points(p, 3000 * 128, 2, sh16, 128, s, ring=True))
+    ops.range_check(sync=True)
