@@ -165,6 +165,9 @@ __global__ __launch_bounds__(512, 1) void k_color_ring8(const float* __restrict_
       const f4* src3 = src_of(jb + 3) + 4 + wave * 64;
       const unsigned dst3 = ring_b + slot_b[(cb + jb + 3) & 3] + (unsigned)wave * 1024u;
       u4 wfa[3], wfb[3];
+#ifdef C8_ACC2
+      f4 acc2;
+#endif
       wfa[0] = frag[0];
       wfb[0] = frag[64];
       wfa[1] = frag[2 * 64];
@@ -177,9 +180,21 @@ __global__ __launch_bounds__(512, 1) void k_color_ring8(const float* __restrict_
           wfb[(kb + 2) % 3] = frag[(2 * kb + 5) * 64];
         }
         const h8 a = __builtin_bit_cast(h8, xh[kb]), b = __builtin_bit_cast(h8, xl[kb]);
+#ifdef C8_ACC2
+        f4& ak = (kb & 1) ? acc2 : acc;
+        if (kb == 1) {
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+          ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, ak, 0, 0, 0);
+        }
+        ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a, ak, 0, 0, 0);
+        ak = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a, ak, 0, 0, 0);
+        if (kb == KB - 1) acc = acc + acc2;
+#else
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a, acc, 0, 0, 0);
+#endif
         if (jb > 0 && !LAST) {
           if (kb == 1) hidden_piece(accs[(jb - 1) & 1], jb - 1, 0);
           if (kb == 4) hidden_piece(accs[(jb - 1) & 1], jb - 1, 1);

@@ -20,7 +20,15 @@
 namespace rb {
 
 constexpr int WR_SLOT_B = 34 * 1024;          // K = 544: 34 KB of fragments
-constexpr int WR_MAXL = 9;
+#ifndef WR_FD
+#define WR_FD 3
+#endif
+#ifndef WR_BS
+#define WR_BS 2          // k-blocks per batch of fragment reads
+#endif
+#ifndef WR_DB
+#define WR_DB 2          // batches the fragment reads run ahead of the MFMAs
+#endif
 
 // ---- net descriptions: K (padded inputs) and chunks (16 output neurons each) per layer
 template <int K0P, int N3P>
@@ -81,7 +89,7 @@ __host__ __device__ constexpr long wr_coff(int c) {            // float4 offset 
 }
 // 1 KB fragment copies per wave and chunk: K / 64 (K = 544: 8.5 -> 9, the ninth of waves 2, 3 repeats that of waves 0, 1), + 1 for
 // the bias
-__host__ __device__ constexpr int wr_np(int K) { return (K / 16 + 3) / 4 + 1; }
+__host__ __device__ constexpr int wr_np(int K) { return K / 64 + 1 + (K == 544 ? 1 : 0); }
 
 __device__ __forceinline__ void wr_dma16(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_uniform), "v"(lane_byte_off),
@@ -97,17 +105,41 @@ template <int N>
 __device__ __forceinline__ void wr_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// all copies of one chunk by one wave: the bias head first, then its fragment slices; slice d of wave v = KB (4 d + v) of the chunk
+// Copies of one chunk by one wave, in UNITS of one LDS-DMA block each (one M0 write, then 1-4 instructions whose immediate offsets
+// advance the global and the LDS address together): unit 0 = the bias head (256 B), then the wave's contiguous span of the chunk's
+// 1 KB fragment slices (K/64 per wave: wave v copies slices v K/64 ...) four at a time, and for K = 544 (34 slices) one more: slice
+// 32 + (v & 1), twice over.  Instructions per chunk and wave (the counted waits): wr_np(K).
+__host__ __device__ constexpr int wr_nsw(int K) { return K / 64; }                       // slices per wave (K = 544: 8, + the extra unit)
+__host__ __device__ constexpr int wr_units(int K) { return 1 + (wr_nsw(K) + 3) / 4 + (K == 544 ? 1 : 0); }
+template <int NPC>
+__device__ __forceinline__ void wr_dma_block(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
+  static_assert(NPC >= 1 && NPC <= 4, "");
+  if constexpr (NPC == 1)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_uniform), "v"(lane_byte_off), "s"(gbase_uniform) : "memory");
+  else if constexpr (NPC == 2)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" ::"s"(lds_byte_uniform), "v"(lane_byte_off), "s"(gbase_uniform) : "memory");
+  else if constexpr (NPC == 3)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048" ::"s"(lds_byte_uniform), "v"(lane_byte_off), "s"(gbase_uniform) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" ::"s"(lds_byte_uniform), "v"(lane_byte_off), "s"(gbase_uniform) : "memory");
+}
+// per-lane global byte offsets of the units (from the chunk's first byte), set up once per kernel
 template <int K>
-__device__ __forceinline__ void wr_copy_piece(int d, const f4* src_chunk, unsigned lane4, unsigned lane16, unsigned bias_dst,
-                                              unsigned slot_dst, int wave) {
-  constexpr int NS = K / 16;           // 1 KB slices of the chunk's fragments
-  if (d == 0) {
+__device__ __forceinline__ void wr_copy_unit(int u, const f4* src_chunk, unsigned lane4, unsigned lane16, unsigned bias_dst,
+                                             unsigned slot_dst, int wave) {
+  constexpr int NSW = wr_nsw(K);
+  if (u == 0) {
     wr_dma4(src_chunk, lane4, bias_dst);
+  } else if (K == 544 && u == 3) {
+    const unsigned sb = (32u + (unsigned)(wave & 1)) * 1024u;
+    wr_dma_block<1>(src_chunk + 4 + sb / 16, lane16, slot_dst + sb);
   } else {
-    int s = 4 * (d - 1) + wave;
-    if (4 * (d - 1) + 3 >= NS) s = 4 * (d - 1) + (wave & (NS - 4 * (d - 1) - 1));   // partial last group (two slices): repeat
-    wr_dma16(src_chunk + 4 + s * 64, lane16, slot_dst + (unsigned)s * 1024u);
+    const unsigned sb = ((unsigned)wave * NSW + 4u * (u - 1)) * 1024u;      // first slice of this block
+    const f4* src = src_chunk + 4 + sb / 16;
+    if (NSW - 4 * (u - 1) >= 4) wr_dma_block<4>(src, lane16, slot_dst + sb);
+    else if (NSW - 4 * (u - 1) == 3) wr_dma_block<3>(src, lane16, slot_dst + sb);
+    else if (NSW - 4 * (u - 1) == 2) wr_dma_block<2>(src, lane16, slot_dst + sb);
+    else wr_dma_block<1>(src, lane16, slot_dst + sb);
   }
 }
 
@@ -143,6 +175,11 @@ __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ 
   u4 skh[17 - SK0], skl[17 - SK0];     // skip net: the input part [x0 | 0] / sqrt 2 of the skip layer's operands, once per round
   long rrow = 0;
 
+  // hidden activation of an MFMA result -> lifted operand value.  zs and AS are powers of two: relu(z zs) AS = relu(z us) bit for bit.
+  auto hidden_val = [&](float z) {
+    if constexpr (Net::ACT == ACT_RELU) return fmaxf(z * us, 0.f);
+    else return act_fn<Net::ACT>(z * zs) * AS;
+  };
   auto put_pair = [&](float v0, float v1, u4& dh, u4& dl, int q) {
     unsigned hi, lo;
     split_pair_mix(v0, v1, hi, lo);
@@ -203,90 +240,125 @@ __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ 
     constexpr int LI = decltype(LI_tag)::value;
     constexpr int K = Net::K(LI), KB = K / 32, NCH = Net::NCH(LI), NP = wr_np(K), CB = wr_cbase<Net>(LI);
     constexpr bool LAST = LI == L - 1, SKIPOUT = LI == Net::SKIP;
+    // Per chunk jb (stream position cb + jb): 3 KB MFMAs on one accumulator; at k-block KB/2 this wave's copies of chunk jb+1 are
+    // waited for (those of jb+2 stay in flight) and ONE s_barrier makes the whole chunk visible -- and certifies that every wave is
+    // done with chunk jb-1, whose slot the copies of chunk jb+3 (issued in the k-blocks after the barrier) overwrite.  The fragment
+    // reads run D k-blocks ahead of the MFMAs ACROSS the chunk boundary (the barrier is behind them by then), and so does the bias:
+    // the matrix pipe does not drain between chunks.  Step s = jb * KB + kb; fragment buffers are indexed s mod (D + 1).
+    // Fragment reads go in batches of BS k-blocks, DB batches ahead, the first-used fragment of a batch LAST (LDS returns in order:
+    // one lgkmcnt wait per batch instead of one per fragment).
+    constexpr int BS = KB >= 8 ? WR_BS : 1, DB = KB >= 8 ? WR_DB : (KB >= 6 ? 3 : 1), D = BS * DB, NB = BS * (DB + 1);
+    constexpr int HB = KB / 2, NSTEP = NCH * KB;
+    static_assert(D + BS - 1 <= KB - HB, "reads of the next chunk start after the barrier");
     f4 accs[2];
+    f4 bnext = f4{0.f, 0.f, 0.f, 0.f};
+    u4 wfa[NB], wfb[NB];
     const f4* wl = Wp + wr_coff<Net>(cb);                     // run time for shared instances
     const f4* wnext[3];                                       // the three chunks after the layer (compile-time distance, run-time base)
 #pragma unroll
     for (int i = 0; i < 3; ++i) wnext[i] = Wp + wr_coff<Net>(cb + NCH + i);
     asm volatile("" : "+s"(wl));
+    auto frag_of = [&](int c) { return reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + slot_b[c & 3]) + lane; };
+    auto bias_of = [&](int c) { return *(reinterpret_cast<const f4*>(reinterpret_cast<const char*>(bias_ring) + bslot_b[c & 3]) + g); };
+    // the layer's first chunk is visible (prologue, or the barrier inside the previous layer's last chunk)
+    accs[0] = bias_of(0) * AS;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < NSTEP) {
+        wfa[i % NB] = frag_of(i / KB)[(2 * (i % KB)) * 64];
+        wfb[i % NB] = frag_of(i / KB)[(2 * (i % KB) + 1) * 64];
+      }
 #pragma unroll
     for (int jb = 0; jb < NCH; ++jb) {
       f4& acc = accs[jb & 1];
-      {   // chunk jb (fragments and bias) must have landed: this wave's copies of chunks jb+1 and jb+2 may still be in flight
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int n1 = jb + 1 < NCH ? NP : wr_np(Net::K(wr_layer_of<Net>(CB + jb + 1)));
-        const int n2 = jb + 2 < NCH ? NP : wr_np(Net::K(wr_layer_of<Net>(CB + jb + 2)));
-        const int allowed = n1 + n2;
-        // the largest constant not above `allowed` (sums of 2, 4, 9, 10 copies per chunk)
-        if (allowed >= 20) wr_wait<20>();
-        else if (allowed >= 19) wr_wait<19>();
-        else if (allowed >= 18) wr_wait<18>();
-        else if (allowed >= 13) wr_wait<13>();
-        else if (allowed >= 11) wr_wait<11>();
-        else if (allowed >= 8) wr_wait<8>();
-        else if (allowed >= 6) wr_wait<6>();
-        else wr_wait<4>();
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      constexpr int dsl = 0;
-      (void)dsl;
-      const int sl = jb & 3;
-      const u4* frag = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + slot_b[sl]) + lane;
-      acc = *(reinterpret_cast<const f4*>(reinterpret_cast<const char*>(bias_ring) + bslot_b[sl]) + g) * AS;
+      if (jb > 0) acc = bnext * AS;
       // copies of chunk jb + 3
       constexpr int dummy2 = 0;
       (void)dummy2;
       const int K3 = jb + 3 < NCH ? K : Net::K(wr_layer_of<Net>(CB + jb + 3));
-      const int n3 = wr_np(K3);
+      const int nu3 = wr_units(K3);
       const f4* src3 = jb + 3 < NCH ? wl + (long)(jb + 3) * chunk_f4(K) : wnext[jb + 3 - NCH < 3 ? jb + 3 - NCH : 0];
       const int sl3 = (jb + 3) & 3;
       const unsigned dst3 = ring_b + slot_b[sl3], bdst3 = bias_b + bslot_b[sl3];
-      u4 wfa[4], wfb[4];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (i < KB) {
-          wfa[i] = frag[(2 * i) * 64];
-          wfb[i] = frag[(2 * i + 1) * 64];
-        }
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        const h8 wh = __builtin_bit_cast(h8, wfa[kb & 3]), wlo = __builtin_bit_cast(h8, wfb[kb & 3]);
-        if (kb + 3 < KB) {
-          wfa[(kb + 3) & 3] = frag[(2 * kb + 6) * 64];
-          wfb[(kb + 3) & 3] = frag[(2 * kb + 7) * 64];
+        const int st = jb * KB + kb;
+        if (kb == HB) {   // chunk jb+1 must have landed: this wave's copies of chunk jb+2 may still be in flight
+          const int allowed = jb + 2 < NCH ? NP : wr_np(Net::K(wr_layer_of<Net>(CB + jb + 2)));
+          if (allowed >= 10) wr_wait<10>();
+          else if (allowed >= 9) wr_wait<9>();
+          else if (allowed >= 4) wr_wait<4>();
+          else wr_wait<2>();
+#ifndef WR_ABL_NOBAR
+          __builtin_amdgcn_s_barrier();
+#endif
+          asm volatile("" ::: "memory");
+          bnext = bias_of(jb + 1);
+        }
+        const h8 wh = __builtin_bit_cast(h8, wfa[st % NB]), wlo = __builtin_bit_cast(h8, wfb[st % NB]);
+        if (st % BS == 0) {
+#pragma unroll
+          for (int i = BS - 1; i >= 0; --i) {
+            const int s2 = st + D + i;
+            if (s2 < NSTEP) {
+#ifdef WR_ABL_NOLDS
+              wfa[s2 % NB] = wfa[st % NB];
+              wfb[s2 % NB] = wfb[st % NB];
+#else
+              wfb[s2 % NB] = frag_of(s2 / KB)[(2 * (s2 % KB) + 1) * 64];
+              wfa[s2 % NB] = frag_of(s2 / KB)[(2 * (s2 % KB)) * 64];
+#endif
+            }
+          }
         }
         const h8 a = __builtin_bit_cast(h8, xh[kb]), b = __builtin_bit_cast(h8, xl[kb]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, b, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, a, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, a, acc, 0, 0, 0);
+#ifdef WR_ABL_NOVAL
+        if (jb > 0 && !LAST && kb == 0) {      // timing ablation: keep the data dependence, drop the arithmetic
+          const f4& pa = accs[(jb - 1) & 1];
+          yh[(jb - 1) >> 1][((jb - 1) & 1) * 2] = __builtin_bit_cast(unsigned, pa[0]) & 0x3c003c00u;
+          yl[(jb - 1) >> 1][((jb - 1) & 1) * 2] = __builtin_bit_cast(unsigned, pa[1]) & 0x3c003c00u;
+          yh[(jb - 1) >> 1][((jb - 1) & 1) * 2 + 1] = __builtin_bit_cast(unsigned, pa[2]) & 0x3c003c00u;
+          yl[(jb - 1) >> 1][((jb - 1) & 1) * 2 + 1] = __builtin_bit_cast(unsigned, pa[3]) & 0x3c003c00u;
+        }
+        if (false) {
+#else
         if (jb > 0 && !LAST) {                 // activation + split of chunk jb-1, a value pair at a time
+#endif
           constexpr int dummy3 = 0;
           (void)dummy3;
           if (kb == 0 || kb == (KB >= 8 ? 3 : 1)) {
             const int q = kb == 0 ? 0 : 1, pj = jb - 1;
             const f4& pa = accs[pj & 1];
-            float v0 = act_fn<Net::ACT>(pa[2 * q] * zs), v1 = act_fn<Net::ACT>(pa[2 * q + 1] * zs);
-            if (SKIPOUT) {
-              v0 *= inv_sqrt2;
-              v1 *= inv_sqrt2;
+            float v0, v1;
+            if constexpr (SKIPOUT) {
+              v0 = act_fn<Net::ACT>(pa[2 * q] * zs) * inv_sqrt2 * AS;
+              v1 = act_fn<Net::ACT>(pa[2 * q + 1] * zs) * inv_sqrt2 * AS;
+            } else {
+              v0 = hidden_val(pa[2 * q]);
+              v1 = hidden_val(pa[2 * q + 1]);
             }
-            put_pair(v0 * AS, v1 * AS, yh[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+            put_pair(v0, v1, yh[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
           }
         }
         if (LAST && jb > 0 && kb == 0) {       // output chunk jb-1 (nets with more than 16 outputs)
           const f4& pa = accs[(jb - 1) & 1];
           if (rrow < M) *(reinterpret_cast<f4*>(Y + rrow * (long)(NCH * 16) + (jb - 1) * 16) + g) = f4{pa[0] * zs, pa[1] * zs, pa[2] * zs, pa[3] * zs};
         }
+#ifndef WR_ABL_NODMA
+        if (kb >= HB) {
 #pragma unroll
-        for (int d = 0; d < 10; ++d)
-          if (d < n3 && (d * KB) / n3 == kb) {
-            if (K3 == 64) wr_copy_piece<64>(d, src3, lane4, lane16, bdst3, dst3, wave);
-            else if (K3 == 192) wr_copy_piece<192>(d, src3, lane4, lane16, bdst3, dst3, wave);
-            else if (K3 == 512) wr_copy_piece<512>(d, src3, lane4, lane16, bdst3, dst3, wave);
-            else wr_copy_piece<544>(d, src3, lane4, lane16, bdst3, dst3, wave);
-          }
+          for (int u = 0; u < 4; ++u)
+            if (u < nu3 && (u * (KB - HB)) / nu3 == kb - HB) {
+              if (K3 == 64) wr_copy_unit<64>(u, src3, lane4, lane16, bdst3, dst3, wave);
+              else if (K3 == 192) wr_copy_unit<192>(u, src3, lane4, lane16, bdst3, dst3, wave);
+              else if (K3 == 512) wr_copy_unit<512>(u, src3, lane4, lane16, bdst3, dst3, wave);
+              else wr_copy_unit<544>(u, src3, lane4, lane16, bdst3, dst3, wave);
+            }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -319,12 +391,15 @@ __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ 
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         constexpr int pj = NCH - 1;
-        float v0 = act_fn<Net::ACT>(last[2 * q] * zs), v1 = act_fn<Net::ACT>(last[2 * q + 1] * zs);
-        if (SKIPOUT) {
-          v0 *= inv_sqrt2;
-          v1 *= inv_sqrt2;
+        float v0, v1;
+        if constexpr (SKIPOUT) {
+          v0 = act_fn<Net::ACT>(last[2 * q] * zs) * inv_sqrt2 * AS;
+          v1 = act_fn<Net::ACT>(last[2 * q + 1] * zs) * inv_sqrt2 * AS;
+        } else {
+          v0 = hidden_val(last[2 * q]);
+          v1 = hidden_val(last[2 * q + 1]);
         }
-        put_pair(v0 * AS, v1 * AS, yh[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+        put_pair(v0, v1, yh[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
       }
       // the next layer's operands are complete
       if constexpr (SKIPOUT) {
@@ -360,12 +435,15 @@ __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ 
     (void)dummy;
     const int Kc = Net::K(wr_layer_of<Net>(c));
 #pragma unroll
-    for (int d = 0; d < 10; ++d)
-      if (d < wr_np(Kc)) {
-        if (Kc == 64) wr_copy_piece<64>(d, Wp + wr_coff<Net>(c), lane4, lane16, bias_b + bslot_b[c], ring_b + slot_b[c], wave);
-        else wr_copy_piece<192>(d, Wp + wr_coff<Net>(c), lane4, lane16, bias_b + bslot_b[c], ring_b + slot_b[c], wave);
+    for (int u = 0; u < 4; ++u)
+      if (u < wr_units(Kc)) {
+        if (Kc == 64) wr_copy_unit<64>(u, Wp + wr_coff<Net>(c), lane4, lane16, bias_b + bslot_b[c], ring_b + slot_b[c], wave);
+        else wr_copy_unit<192>(u, Wp + wr_coff<Net>(c), lane4, lane16, bias_b + bslot_b[c], ring_b + slot_b[c], wave);
       }
   }
+  wr_wait<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   static_assert(K0 == 64 || K0 == 192, "first-layer widths");
   static_assert(Net::NCH(0) >= 3, "the prologue assumes three chunks in layer 0");
 
