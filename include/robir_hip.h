@@ -379,6 +379,14 @@ int rb_octree_cast_finish(const float* node, const float* nrm, long B, const flo
                           const int* res, const float* origins, const float* dirs, long R, int max_iter, float clamp_dt,
                           const float* t, const int* leaf, float* x_out, unsigned char* hit_out, float* t_out,
                           rb_stream_t stream);
+/* init + every iteration + finish of one lock-step batch of any size in ONE launch (persistent grid, grid-wide arrival counters
+ * instead of one launch per iteration): counters[it_limit + 1] int32 (output: rays active at the start of each iteration) and
+ * arrive[1024] 64-bit words zeroed by the caller (passed as int*, 8-byte aligned: one slot per workgroup of the grid barrier) (it_limit =
+ * max_iter + 1, or max_total when max_iter <= 0: iterate until no ray is active); the same results bit for bit. */
+int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                        const int* res, const float* origins, const float* dirs, long R, int max_iter, double step, int max_total,
+                        float clamp_dt, float* t, int* leaf, unsigned char* active, int* counters, int* arrive, float* x_out,
+                        unsigned char* hit_out, float* t_out, rb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Ray generation / points / tone mapping.

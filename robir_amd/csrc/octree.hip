@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include "octree_dev.h"
+#include <cstdlib>
 
 namespace rb {
 
@@ -209,6 +210,126 @@ __global__ void k_cast_finish(Oct T, const float* __restrict__ origins, const fl
   s.leaf = leaf[i];
   s.active = false;
   cast_finish(T, oc, o, d, s, clamp_dt, x_out + 3 * i, hit_out + i, t_out + i);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same lock-step batch in ONE launch (round 3): a persistent grid (every workgroup resident: the host caps it at two per compute
+// unit) walks its rays through init / all iterations / finish; the per-iteration count of active rays -- the only thing the rays of a
+// batch share (multi_samp, octree.py:545-549) -- is the device-side counter of the per-iteration launches, completed by a grid-wide
+// arrival counter (release / acquire at agent scope).  33 launches of ~33 us each per trace_radiance call (16 % of BASELINE config 5,
+// profiles/r03_config5_kernel_stats.md) become one.  A thread owns rays i = tid + k * threads for the whole cast; their state lives
+// in t / leaf / active as before (any batch size), results are those of the per-iteration kernels bit for bit.
+// counters: [max_it + 2] active counts (output), arrive: one 64-bit word per workgroup (<= 1024, zeroed).
+// ---------------------------------------------------------------------------------------------------------
+// Grid barrier + sum without same-address atomics (those serialise at the L2 at ~0.4 us each: 118 workgroups = 40 us per iteration):
+// workgroup g publishes ONE 64-bit word {epoch, its active count} in its own slot; thread k of every workgroup polls slot k until it
+// carries the epoch, and the counts are summed in the workgroup.  words[n_groups], zeroed before the launch; epochs start at 1.
+__device__ __forceinline__ int grid_sum_and_wait(unsigned long long* words, int epoch, int my_active, int n_groups, int* lds_sum) {
+  __threadfence();          // every thread: its own stores (ray state) are visible device-wide before the workgroup publishes
+  if (threadIdx.x == 0) *lds_sum = 0;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&words[blockIdx.x], ((unsigned long long)(unsigned)epoch << 32) | (unsigned)my_active, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  int c = 0;
+  if ((int)threadIdx.x < n_groups) {
+    unsigned long long v;
+    while ((int)((v = __hip_atomic_load(&words[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch)
+      __builtin_amdgcn_s_sleep(1);
+    c = (int)(v & 0xffffffffull);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(lds_sum, c);
+  __syncthreads();
+  __threadfence();          // ... and it sees the others' (a ray changes hands between the init / iteration / finish phases)
+  return *lds_sum;
+}
+
+// CC_LPR lanes per ray: the fine march (10..100 samples, each a chain of dependent node reads) runs CC_LPR samples at a time
+template <int CC_LPR>
+__global__ __launch_bounds__(1024) void k_cast_coop(Oct T, const float* __restrict__ origins, const float* __restrict__ dirs, long R,
+                                                  int max_iter, double step, int it_limit, float clamp_dt, float* __restrict__ t,
+                                                  int* __restrict__ leaf, unsigned char* __restrict__ active,
+                                                  int* __restrict__ counters, unsigned long long* __restrict__ arrive, float* __restrict__ x_out,
+                                                  unsigned char* __restrict__ hit_out, float* __restrict__ t_out) {
+  const long nthreads = (long)gridDim.x * blockDim.x, tid = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const long ngrp = nthreads / CC_LPR, grp = tid / CC_LPR;          // ray groups of CC_LPR lanes
+  const int sub = (int)(tid % CC_LPR);
+  const int ngroups = (int)gridDim.x;
+  __shared__ int wg_count, wg_total;
+  auto load_ray = [&](long i, float (&o)[3], float (&d)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      d[c] = dirs[3 * i + c];
+      o[c] = origins[3 * i + c];
+      if (max_iter > 0) o[c] = o[c] + d[c] * 0.005f;
+    }
+  };
+  // active rays of this workgroup -> the grid-wide count (also recorded in counters[slot] by workgroup 0, for the caller)
+  auto count_and_sync = [&](int n_mine, int slot) {
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
+    int total = n_mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(&wg_count, total);
+    __syncthreads();
+    const int mine_wg = wg_count;
+    const int n = grid_sum_and_wait(arrive, slot + 1, mine_wg, ngroups, &wg_total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[slot] = n;
+    return n;
+  };
+  int n_act = 0;
+  {   // init (k_cast_init): one ray per thread
+    int mine = 0;
+    for (long i = tid; i < R; i += nthreads) {
+      float o[3], d[3];
+      load_ray(i, o, d);
+      RayState s = cast_init(T, o, d);
+      t[i] = s.t;
+      leaf[i] = s.leaf;
+      active[i] = s.active;
+      mine += s.active ? 1 : 0;
+    }
+    n_act = count_and_sync(mine, 0);
+  }
+  for (int it = 0; it < it_limit; ++it) {      // k_cast_iter: CC_LPR lanes per ray (ray i is always walked by group i mod ngrp)
+    if (n_act == 0) break;
+    const int ms = multi_samp(R, n_act);
+    int mine = 0;
+    for (long i = grp; i < R; i += ngrp) {
+      if (!__hip_atomic_load(&active[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+      float o[3], d[3];
+      load_ray(i, o, d);
+      RayState s;
+      s.t = __hip_atomic_load(&t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s.leaf = __hip_atomic_load(&leaf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s.active = true;
+      cast_step_group<CC_LPR>(T, o, d, s, ms, step, sub);
+      if (sub == 0) {
+        __hip_atomic_store(&t[i], s.t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&leaf[i], s.leaf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&active[i], (unsigned char)(s.active ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mine += s.active ? 1 : 0;
+      }
+    }
+    n_act = count_and_sync(mine, it + 1);
+  }
+  for (long i = tid; i < R; i += nthreads) {   // k_cast_finish: one ray per thread
+    float o[3], oc[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      d[c] = dirs[3 * i + c];
+      o[c] = origins[3 * i + c];
+      oc[c] = max_iter > 0 ? o[c] + d[c] * 0.005f : o[c];
+    }
+    RayState s;
+    s.t = __hip_atomic_load(&t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s.leaf = __hip_atomic_load(&leaf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s.active = false;
+    cast_finish(T, oc, o, d, s, clamp_dt, x_out + 3 * i, hit_out + i, t_out + i);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -412,6 +533,40 @@ int rb_octree_cast_finish(const float* node, const float* nrm, long B, const flo
   hipLaunchKernelGGL(k_cast_finish, grid1d(R, 256), dim3(256), 0, (hipStream_t)stream, T, origins, dirs, R, max_iter,
                      clamp_dt, t, leaf, x_out, hit_out, t_out);
   return check_launch("k_cast_finish");
+}
+
+int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
+                        const int* res, const float* origins, const float* dirs, long R, int max_iter, double step, int max_total,
+                        float clamp_dt, float* t, int* leaf, unsigned char* active, int* counters, int* arrive, float* x_out,
+                        unsigned char* hit_out, float* t_out, rb_stream_t stream) {
+  if (R <= 0) return 0;
+  RB_REQUIRE(node && nrm && origins && dirs && t && leaf && active && counters && arrive && x_out && hit_out && t_out, "null pointer");
+  RB_REQUIRE(max_total >= 1, "max_total >= 1");
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
+    cus = prop.multiProcessorCount;
+  }
+  Oct T = make_oct(node, nrm, B, root_min, root_size, res);
+  static int lpr = 0;
+  if (!lpr) {
+    const char* e = getenv("ROBIR_CAST_LPR");
+    lpr = e ? atoi(e) : 4;       // measured (tools/ab_cast.py, 7500 secondary rays): 1.13 / 0.82 / 2.0 ms at 1 / 4 / 16 lanes per ray
+    if (lpr != 1 && lpr != 4 && lpr != 16) lpr = 4;
+  }
+  const long want = (R * lpr + 1023) / 1024;
+  const unsigned grid = (unsigned)(want < cus ? want : cus);                // every workgroup resident: the grid barrier spins
+  const int it_limit = max_iter > 0 ? max_iter + 1 : max_total;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, T, origins, dirs, R, max_iter, step, it_limit, clamp_dt, t,
+                       leaf, active, counters, (unsigned long long*)arrive, x_out, hit_out, t_out);
+  };
+  if (lpr == 1) go(k_cast_coop<1>);
+  else if (lpr == 4) go(k_cast_coop<4>);
+  else go(k_cast_coop<16>);
+  return check_launch("k_cast_coop");
 }
 
 }  // extern "C"

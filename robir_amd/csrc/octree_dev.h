@@ -193,6 +193,62 @@ __device__ __forceinline__ void cast_step(const Oct& T, const float o[3], const 
   }
 }
 
+// cast_step with the fine march spread over the LPR consecutive lanes that share the ray (all of them call this with the same ray and
+// state; sub = lane % LPR): lane `sub` walks samples sub, sub + LPR, ... (a round of LPR samples at a time, stopping after the first
+// round that contains a cell with sdf <= step), the first such sample is a min over the group.  Same t, leaf, active as cast_step:
+// the sample positions and the comparison are the same expressions, only evaluated side by side.
+template <int LPR>
+__device__ __forceinline__ void cast_step_group(const Oct& T, const float o[3], const float d[3], RayState& s, int m, double step,
+                                                int sub) {
+  float pos[3] = {o[0] + s.t * d[0], o[1] + s.t * d[1], o[2] + s.t * d[2]};
+  const f4 a = T.node[2 * (long)s.leaf], b = T.node[2 * (long)s.leaf + 1];
+  const float mn[3] = {a[0], a[1], a[2]}, sz[3] = {b[0], b[1], b[2]};
+  float near;
+  float far = slab(mn, sz, pos, d, near);
+  if (far < (float)((double)m * step)) {
+    const float stepf = (float)step;
+    int j = m;
+    for (int i0 = 0; i0 < m && j == m; i0 += LPR) {     // uniform over the group: j is the group's min after every round
+      const int i = i0 + sub;
+      const float tm = lin01(i + 1, m) * (float)m * stepf + stepf;
+      float q[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) q[c] = pos[c] + d[c] * tm;
+      const bool inside = (i < m) && in_root(T.root, q);
+      int ptr = inside ? base_cell(T, q) : (int)(T.B - 1);   // outside: sdf_val[-1] (octree.py:465-466)
+      float sv = 0.f;
+      bool done = !inside;
+      while (true) {
+        const f4 na = T.node[2 * (long)ptr], nb = T.node[2 * (long)ptr + 1];
+        const int fc = __float_as_int(na[3]);
+        sv = nb[3];
+        if (done || fc < 0) break;
+        ptr = child_of(na, nb, fc, q);
+      }
+      int mine = (i < m && sv <= stepf) ? i : m;
+#pragma unroll
+      for (int off = LPR / 2; off > 0; off >>= 1) {
+        const int other = __shfl_xor(mine, off);
+        mine = other < mine ? other : mine;
+      }
+      j = mine;
+    }
+    far = lin01(j, m) * (float)m * stepf + stepf;
+  }
+  s.t = s.t + (far + 1e-3f);
+  pos[0] = o[0] + s.t * d[0];
+  pos[1] = o[1] + s.t * d[1];
+  pos[2] = o[2] + s.t * d[2];
+  if (!in_root(T.root, pos)) {
+    s.leaf = -1;
+    s.active = false;
+  } else {
+    float sv;
+    s.leaf = descend(T, pos, sv, nullptr);
+    s.active = !(sv <= 1e-4f);
+  }
+}
+
 // ---- pieces of cast_step for the workgroup-cooperative form of k_cast_batched
 // first half: exit distance of the current cell; `need` = the fine march applies (octree.py:540-546)
 __device__ __forceinline__ float step_begin(const Oct& T, const float o[3], const float d[3], const RayState& s, int m,

@@ -519,16 +519,32 @@ def octree_cast_batched(T, origins, per_ray_origin, dirs, batch, max_iter, step,
     return x, hit.bool(), t, sched
 
 
-def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_total=4096):
-    """One lock-step batch of any size: origins/dirs [R,3]."""
+CAST_ONE_LAUNCH = _os.environ.get("ROBIR_CAST_ONE_LAUNCH", "1") == "1"    # the persistent-grid form of the general lock-step cast
+CAST_ONE_LAUNCH_MAX_RAYS = 16384   # above this the per-iteration launches fill the chip and win (tools/ab_cast.py: 60 k rays 1.3 vs 2.1 ms)
+
+
+def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_total=4096, one_launch=None):
+    """One lock-step batch of any size: origins/dirs [R,3].  one_launch (default CAST_ONE_LAUNCH): init, every iteration and finish
+    in one persistent launch (k_cast_coop) instead of one launch per iteration -- the same results bit for bit, no host sync."""
     dirs, origins = _f32(dirs), _f32(origins)
     R = dirs.shape[0]
     dev = dirs.device
     t = torch.empty(R, dtype=torch.float32, device=dev)
     leaf = torch.empty(R, dtype=torch.int32, device=dev)
     active = torch.empty(R, dtype=torch.uint8, device=dev)
-    counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
     a = T.args()
+    if (CAST_ONE_LAUNCH and R <= CAST_ONE_LAUNCH_MAX_RAYS) if one_launch is None else one_launch:
+        counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
+        arrive = torch.zeros(1024, dtype=torch.int64, device=dev)                # one 64-bit slot per workgroup of the grid barrier
+        x = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        hit = torch.empty(R, dtype=torch.uint8, device=dev)
+        t_out = torch.empty(R, dtype=torch.float32, device=dev)
+        if R > 0:
+            call("rb_octree_cast_coop", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step), c_int(max_total),
+                 c_float(T.clamp_dt), ptr(t), ptr(leaf), ptr(active), ptr(counters), ptr(arrive), ptr(x), ptr(hit), ptr(t_out),
+                 stream_ptr())
+        return x, hit.bool(), t_out, counters
+    counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
     call("rb_octree_cast_init", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ptr(t), ptr(leaf), ptr(active),
          ptr(counters), stream_ptr())
     if max_iter > 0:

@@ -111,6 +111,32 @@ def test_secondary_and_general_path(dev, oracle_octree):
     assert rel_err(t.cpu(), to) <= 1e-6
 
 
+def test_one_launch_cast_equals_per_iteration_launches(dev, oracle_octree):
+    """k_cast_coop (persistent grid, grid-wide arrival counters) == k_cast_init / k_cast_iter / k_cast_finish bit for bit, in both
+    modes, below and above one ray per thread of the capped grid, and the per-iteration active counts with it."""
+    from robir_amd import ops
+    g = np.random.Generator(np.random.PCG64(12))
+    for max_iter, n in ((32, 1500), (32, 40000), (32, 300001), (-1, 5000), (0, 5000)):
+        od = _oracle_dev(oracle_octree, dev, max_iter=max_iter)
+        o = g.standard_normal((n, 3)).astype(np.float32)
+        o = (0.26 if max_iter > 0 else 0.9) * o / np.linalg.norm(o, axis=1, keepdims=True)
+        d = g.standard_normal((n, 3)).astype(np.float32)
+        if max_iter <= 0:
+            d = -o + 0.3 * d
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o_t, d_t = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+        step = od.step_size(n)
+        a = ops.octree_cast_general(od.tables, o_t, d_t, od.max_iter, step, one_launch=False)
+        for _ in range(2):
+            b = ops.octree_cast_general(od.tables, o_t, d_t, od.max_iter, step, one_launch=True)
+            for u, v in zip(a[:3], b[:3]):
+                assert torch.equal(u, v), (max_iter, n)
+            m = min(a[3].numel(), b[3].numel())
+            ca, cb = a[3][:m].cpu(), b[3][:m].cpu()
+            last = int((cb > 0).nonzero().max()) + 2 if bool((cb > 0).any()) else 1
+            assert torch.equal(ca[:last], cb[:last]), (max_iter, n)
+
+
 def test_camera_rays(dev):
     from robir_amd import ops, synth
     from robir_oracle import renderer

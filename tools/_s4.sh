@@ -1,3 +1,2 @@
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-ROBIR_PRECISION=split timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for C in 2 3 5; do python bench.py --config $C --precision split --steps 2 2>/dev/null | tail -1 | cut -c1-400; done
+timeout 600 python -m pytest tests/test_octree_gpu.py -m gpu -x -q 2>&1 | tail -2
+for l in 1 4 16; do echo LPR $l; ROBIR_CAST_LPR=$l python tools/ab_cast.py 2>&1 | grep "True"; done

@@ -38,7 +38,7 @@ python tools/prof_perchunk.py 2>/dev/null | grep per-chunk | sed 's/^/exact poli
 pmc dvis_x6 "dvis_x6" python tools/prof_dvis.py f16x6 32
 pmc dvis_v2 "dvis_v2" python tools/prof_dvis.py f16x3-v2 32
 export ROBIR_PRECISION=split RB_CONFIG_REPS=1
-pmc config2 "sdf_ring8\|sdf_back\|color_mlp" python tools/bench_configs.py 2
-pmc config5 "softplus512\|wide_mlp\|dvis" python tools/bench_configs.py 5
+pmc config2 "sdf_ring8\|sdf_back\|color_mlp\|color_ring" python tools/bench_configs.py 2
+pmc config5 "softplus512\|wide_mlp\|wide_ring\|dvis" python tools/bench_configs.py 5
 rm -f $O/p.log
 cat $O/${TAG}_perchunk_rate.txt $O/${TAG}_deferred_rates.txt; tail -c 300 $O/${TAG}_bench.json; echo; grep -c . $O/bench.err
