@@ -40,7 +40,7 @@ def timed(fn, reps=5):
 t0 = timed(lambda: ops.sdf_mlp_h3(X, n, dist, 0, packing.H3_SCALE_LOG2, 0.5, 1.0))
 t1 = timed(lambda: ops.sdf_mlp_h3(X, n, full, 1, packing.H3_SCALE_LOG2, 0.5, 1.0))
 # (the backward kernel detects sigmoid rows by their content: never run it behind an ablated value pass)
-t5 = timed(lambda: ops.sdf_value_grad(x, n, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)) if tag == "base" else float("nan")
+t5 = timed(lambda: ops.sdf_value_grad(x, n, full, back, packing.H3_SCALE_LOG2, in_scale=2.0, out_scale=0.5)) if (tag == "base" or tag.startswith("ok")) else float("nan")
 o0 = ops.sdf_mlp_h3(X, n, dist, 0, packing.H3_SCALE_LOG2, 0.5, 1.0)[0]
 o1 = ops.sdf_mlp_h3(X, n, full, 1, packing.H3_SCALE_LOG2, 0.5, 1.0)[0]
 print(f"{tag}: checksums {float(o0.double().sum()):.9e} {float(o1.double().abs().sum()):.9e}")
