@@ -166,6 +166,8 @@ int rb_cesr_net_ring_points(const float* x, long M, int kind, int n_label, const
                             rb_stream_t stream);
 int rb_wide_mlp_ring_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
                             int n_workgroups, rb_stream_t stream);
+/* ... on feature rows X[M,64] (rb_feat_pe10 / rb_feat_ipe): the arguments and bits of rb_wide_mlp_h3 */
+int rb_wide_mlp_ring(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, int n_workgroups, rb_stream_t stream);
 /* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
  * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);

@@ -145,6 +145,7 @@ __device__ __forceinline__ void wr_copy_unit(int u, const f4* src_chunk, unsigne
 
 // INPUT: 0 = PE10(x) (CESR normal_net), 1 = [PE10(x) | one-hot label] rows (CESR shadow_net: row = point * n_label + label),
 //        2 = [PE10(x) | extra] (SparseAE encoders: extra = 0; indirect illumination: extra = hdr_shift)
+//        3 = feature rows X[M,64] as rb_feat_pe10 writes them (the auto-encoders whose embedded vector is perturbed)
 template <class Net, int INPUT>
 __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ X, const float* __restrict__ extra, long M, int n_label,
                                                        const f4* __restrict__ Wp, float us, int n_out, float* __restrict__ Y,
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(256, 1) void k_wide_ring(const float* __restrict__ 
           if (k >= 63 && k - 63 == label) e = 1.f;
           x0[kb * 4 + r] = e;
         }
+    } else if constexpr (INPUT == 3) {
+      static_assert(K0 == 64, "feature rows are 64 wide");
+      load_features<64>(X, row, M, lane, x0);
     } else {
       static_assert(K0 == 64, "encoded inputs are 64 wide");
       load_features_pe10x(X, INPUT == 2 ? extra : nullptr, row, M, lane, pe_scratch + wave * 1024, x0);
@@ -485,5 +489,7 @@ int launch_cesr_ring_normal(const float* x, long M, const f4* W, float us, float
 int launch_cesr_ring_shadow(const float* x, long M, int n_label, const f4* W, float us, float* Y, unsigned* rw, int grid, hipStream_t s);
 int launch_wide_ring_encoder(const float* x, const float* extra, long M, const f4* W, float us, float* Y, unsigned* rw, int grid, hipStream_t s);
 int launch_wide_ring_decoder(const float* x, const float* extra, long M, const f4* W, float us, float* Y, unsigned* rw, int grid, hipStream_t s);
+int launch_wide_ring_encoder_rows(const float* X, long M, const f4* W, float us, float* Y, unsigned* rw, int grid, hipStream_t s);
+int launch_wide_ring_decoder_rows(const float* X, long M, const f4* W, float us, float* Y, unsigned* rw, int grid, hipStream_t s);
 
 }  // namespace rb

@@ -51,4 +51,15 @@ int rb_wide_mlp_ring_points(const float* x, const float* extra, long M, const fl
                  : launch_wide_ring_decoder(x, extra, M, (const f4*)Wp, us, Y, rw, grid, (hipStream_t)stream);
 }
 
+int rb_wide_mlp_ring(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, int n_workgroups, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(X && Wp && Y, "null pointer");
+  const int grid = wr_grid(M, n_workgroups);
+  if (grid <= 0) return rb::fail(__func__, "device query failed");
+  const float us = ldexpf(1.0f, -scale_log2);
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr;
+  return encoder ? launch_wide_ring_encoder_rows(X, M, (const f4*)Wp, us, Y, rw, grid, (hipStream_t)stream)
+                 : launch_wide_ring_decoder_rows(X, M, (const f4*)Wp, us, Y, rw, grid, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -615,6 +615,9 @@ def test_wide_ring_kernels_are_bit_identical_to_the_first_generation(dev, synth_
             assert torch.equal(a, ops.cesr_net_points(p, n, 0, no16, 1, s, ring=True)), ("normal_net", n)
         assert torch.equal(ops.wide_mlp_points(p, hdr, ill16, False, s, ring=False), ops.wide_mlp_points(p, hdr, ill16, False, s, ring=True)), n
         assert torch.equal(ops.wide_mlp_points(p, None, enc16, True, s, ring=False), ops.wide_mlp_points(p, None, enc16, True, s, ring=True)), n
+        Xh, Xp = ops.feat_pe10(p, extra=hdr), ops.feat_pe10(p)
+        assert torch.equal(ops.wide_mlp_h3(Xh, ill16, False, s, ring=False), ops.wide_mlp_h3(Xh, ill16, False, s, ring=True)), n
+        assert torch.equal(ops.wide_mlp_h3(Xp, enc16, True, s, ring=False), ops.wide_mlp_h3(Xp, enc16, True, s, ring=True)), n
     p = ((torch.rand(3000, 3, generator=g) - 0.5) * 0.6).to(dev)
     a = ops.cesr_net_points(p, 3000 * 128, 2, sh16, 128, s, ring=False)
     for _ in range(3):
