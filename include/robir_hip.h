@@ -406,6 +406,12 @@ int rb_points_along(const float* origins, int per_ray_origin, long batch, const 
                     float* pts, rb_stream_t stream);
 /* ACESToneMapping (model/color_correction.py:31-73,116-134): mode = op + 16 * curve; op 0 hdr2ldr, 1 ldr2hdr, 2 ldr2hdr(x^2.2);
  * curve 0 = hdr_mode 0 (scale_aces, every shipped conf), 1 = hdr_mode 1 (warp_aces), 2 = hdr_mode 2 (ln_space), 3 = identity. */
+/* K row sets src[k] [n, src_width[k]] of the hit pixels idx[n] (int64, ascending or not) -> K consecutive blocks [N, dst_width[k]] of
+ * `flat` (block k starts at N * sum of the widths before it; the caller pre-fills the defaults), one launch: the per-pixel outputs of
+ * IDRNetwork.forward (implicit_differentiable_renderer.py:420-470, `x[mask] = values` per output).  src_width 1 broadcasts over the
+ * destination's columns.  src / src_width / dst_width are HOST arrays. */
+int rb_scatter_rows(const float* const* src, const int* src_width, const int* dst_width, int K, const long* idx, long n, long N,
+                    float* flat, rb_stream_t stream);
 int rb_tonemap(const float* x, long n, const float* shift, int shift_stride, int mode, float* y, rb_stream_t stream);
 /* Element-wise heads of the hooks / networks:
  * rb_material_decode: EnvmapMaterialNetwork outputs from the spec-AE's [n,5] (model/sg_envmap_material.py:205-211);

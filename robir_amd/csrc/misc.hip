@@ -250,7 +250,52 @@ __global__ void k_lin_diff_combine(const float* __restrict__ diffuse, const floa
 
 using namespace rb;
 
+// ---- the per-pixel outputs of a forward(): K row sets [n, 1 or 3] of the hit pixels scattered into K consecutive [N, 1 or 3] blocks
+// of one flat buffer (pre-filled with the defaults) in ONE launch, instead of one index_put per output
+struct ScatterArgs {
+  const float* src[32];
+  long dst_off[32];          // first float of block k in the flat buffer
+  unsigned char src_w[32], dst_w[32];
+  unsigned char col_k[96], col_c[96];      // destination column (all blocks side by side) -> block, column in block
+  int total_cols;
+};
+__global__ void k_scatter_rows(ScatterArgs a, const long* __restrict__ idx, long n, float* __restrict__ flat) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= n * a.total_cols) return;
+  const long j = t / a.total_cols;
+  const int col = (int)(t - j * a.total_cols), k = a.col_k[col], c = a.col_c[col];
+  const int sw = a.src_w[k];
+  flat[a.dst_off[k] + idx[j] * a.dst_w[k] + c] = a.src[k][j * sw + (sw == 1 ? 0 : c)];
+}
+
 extern "C" {
+
+int rb_scatter_rows(const float* const* src, const int* src_width, const int* dst_width, int K, const long* idx, long n, long N,
+                    float* flat, rb_stream_t stream) {
+  if (n <= 0 || K <= 0) return 0;
+  RB_REQUIRE(src && src_width && dst_width && idx && flat, "null pointer");
+  RB_REQUIRE(K <= 32, "at most 32 row sets");
+  ScatterArgs a;
+  long off = 0;
+  int cols = 0;
+  for (int k = 0; k < K; ++k) {
+    RB_REQUIRE(src[k] && (src_width[k] == dst_width[k] || src_width[k] == 1) && dst_width[k] >= 1 && dst_width[k] <= 4, "row widths: source = destination or 1 (broadcast), destination 1..4");
+    a.src[k] = src[k];
+    a.src_w[k] = (unsigned char)src_width[k];
+    a.dst_w[k] = (unsigned char)dst_width[k];
+    a.dst_off[k] = off;
+    off += N * dst_width[k];
+    for (int c = 0; c < dst_width[k]; ++c) {
+      RB_REQUIRE(cols < 96, "at most 96 destination columns");
+      a.col_k[cols] = (unsigned char)k;
+      a.col_c[cols] = (unsigned char)c;
+      ++cols;
+    }
+  }
+  a.total_cols = cols;
+  hipLaunchKernelGGL(k_scatter_rows, grid1d(n * cols, 256), dim3(256), 0, (hipStream_t)stream, a, idx, n, flat);
+  return check_launch("k_scatter_rows");
+}
 
 int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv, long N, float* dirs,
                    rb_stream_t stream) {

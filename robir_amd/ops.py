@@ -803,6 +803,30 @@ def cesr_net_points(x, M, kind, blob, n_label=1, scale_log2=None, ring=None):
     return Y
 
 
+def scatter_rows(srcs, dst_widths, idx, N, fill=1.0):
+    """Per-pixel outputs in one launch: srcs[k] [n, 1 or w_k] rows of the pixels idx -> list of K tensors [N, w_k] (other rows =
+    fill); entries of srcs may be None (a block that only holds the default).  One allocation, one fill, one scatter."""
+    dev = idx.device
+    total = sum(dst_widths)
+    flat = torch.full((N * total,), fill, dtype=torch.float32, device=dev)
+    outs, off = [], 0
+    for w in dst_widths:
+        outs.append(flat[off:off + N * w].view(N, w))
+        off += N * w
+    n = idx.shape[0]
+    live = [k for k, s in enumerate(srcs) if s is not None]
+    if n > 0 and live:
+        # blocks without a source must come last in the scatter's view of the buffer: keep the order, skip by offset instead
+        assert live == list(range(len(live))), "sources first, default-only blocks last"
+        keep = [_f32(srcs[k]) for k in live]
+        K = len(keep)
+        src_arr = (ctypes.c_void_p * K)(*[t.data_ptr() for t in keep])
+        sw = (ctypes.c_int * K)(*[int(t.shape[-1]) for t in keep])
+        dw = (ctypes.c_int * K)(*[int(dst_widths[k]) for k in live])
+        call("rb_scatter_rows", src_arr, sw, dw, c_int(K), ptr(idx), c_long(n), c_long(N), ptr(flat), stream_ptr())
+    return outs
+
+
 def material_decode(brdf, brdf_r):
     brdf, brdf_r = _f32(brdf), _f32(brdf_r)
     n, dev = brdf.shape[0], brdf.device

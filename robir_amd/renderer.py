@@ -261,13 +261,12 @@ class IDRNetwork(nn.Module):
             ret.update({"indirect_sgs": indirect_sgs, "indir_integral": indirect_integral, "normals": normals})
             return ret
 
-        ones3 = lambda: torch.ones(N, 3, device=dev)
-        ones1 = lambda: torch.ones(N, 1, device=dev)
-        out3 = {k: ones3() for k in ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb",
-                                     "indir_specular_rgb", "normals", "diffuse_albedo", "roughness", "normal_map",
-                                     "vis_shadow", "random_xi_roughness", "random_xi_diffuse_albedo")}
-        out1 = {k: ones1() for k in ("metallic", "random_xi_metallic", "acc", "final_t")}
-        bg = ones3()
+        keys3 = ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb", "indir_specular_rgb", "normals",
+                 "diffuse_albedo", "roughness", "normal_map", "vis_shadow", "random_xi_roughness", "random_xi_diffuse_albedo")
+        keys1 = ("metallic", "random_xi_metallic", "acc", "final_t")          # the last two only hold the default
+        widths = [3] * len(keys3) + [1] * len(keys1)
+        r = None
+        bg = None
         gerr = torch.zeros((), device=dev)          # (torch.tensor(0.0, device=...) is a blocking host-to-device copy)
         if self.envmap_material_network.envmap is not None:
             bg = sg_render.render_envmap(self.envmap_material_network.envmap, dirs)
@@ -286,16 +285,15 @@ class IDRNetwork(nn.Module):
                                        tex_uv=None, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
             finally:
                 sg_render._BATCH_CTX = None
-            for k in out3:
-                v = r[k]
-                out3[k][idx] = v.expand(-1, 3) if v.shape[-1] == 1 else v
-            out1["metallic"][idx] = r["metallic"]
-            out1["random_xi_metallic"][idx] = r["random_xi_metallic"]
             if "gradient_error" in r:
                 gerr = gerr + r["gradient_error"]
+        # every output: ones, the hit rows scattered in -- one buffer, one fill, one scatter launch for the seventeen of them
+        srcs = [r[k] for k in keys3] + [r["metallic"], r["random_xi_metallic"], None, None] if r is not None else [None] * len(widths)
+        outs = ops.scatter_rows(srcs + ([None] if bg is None else []), widths + ([3] if bg is None else []), idx, N)
+        if bg is None:
+            bg = outs.pop()
         ret.update({"gradient_error": gerr, "bg_rgb": bg, "surface_mask": hit})
-        ret.update(out3)
-        ret.update(out1)
+        ret.update(dict(zip(keys3 + keys1, outs)))
         return ret
 
     # ------------------------------------------------------------------ secondary rays
