@@ -132,6 +132,13 @@ int rb_sdf_points_ring(const float* x, long M, float in_scale, const float* Wp, 
                        float* out0, int n_workgroups, rb_stream_t stream);
 int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
                            float grad_scale, float* out0, float* grad, int n_workgroups, rb_stream_t stream);
+/* The same op at the reference's precision (the default policy): value rows on the f32-input MFMA with the sigmoid of every hidden
+ * pre-activation kept (k_sdf_mlp<5>), one pass over the transposed layers (k_sdf_back_f32; Wt / w8row from the host mirror's
+ * packing.pack_sdf_back), the encoding's Jacobian (k_pe_grad_points) -- 2 x the value pass's MACs instead of the 4 x of the three
+ * tangent rows per point of rb_sdf_mlp_points mode 3.  scratch: rb_sdf_value_grad_f32_scratch_floats(M) floats. */
+long rb_sdf_value_grad_f32_scratch_floats(long M);
+int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 int rb_sdf_value_grad_points(const float* x, long M, float in_scale, const float* Wp, const float* Wb, const float* w8row,
                              int scale_log2, float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
                              int n_workgroups, rb_stream_t stream);

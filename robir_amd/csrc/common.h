@@ -28,6 +28,12 @@ inline dim3 grid1d(long n, int per_block) {
 enum { RB_RANGE_DVIS = 0, RB_RANGE_VIS, RB_RANGE_SDF, RB_RANGE_COLOR, RB_RANGE_WIDE, RB_RANGE_SOFTPLUS512, RB_RANGE_WORDS = 8 };
 unsigned* range_flags();
 
+// reverse-mode SDF gradient on the f32-input MFMA: the two kernels live with the first-generation engine (mlp_kernels.hip), the
+// entry point with the other gradient paths (sdf_back.hip)
+int launch_sdf_f32_store(const float* xyz, long M, float in_scale, const float* Wp, float out_scale, float* out0, float* sig,
+                         hipStream_t s);
+int launch_sdf_back_f32(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s);
+
 }  // namespace rb
 
 #define RB_REQUIRE(cond, msg)                     \

@@ -3,6 +3,7 @@
 #include "../../include/robir_hip.h"
 #include "common.h"
 #include "mlp_engine.h"
+#include <type_traits>
 
 namespace rb {
 
@@ -429,8 +430,11 @@ template <int MODE, bool PRECISE = false, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X, long MR, const f4* __restrict__ Wp,
                                                      float out_scale, float grad_scale, float* __restrict__ out0,
                                                      float* __restrict__ grad, float in_scale) {
-  constexpr bool JVP = MODE >= 2;
-  constexpr bool FULL = (MODE == 1 || MODE == 3);
+  // MODE 5 (value rows, all 257 outputs): also stores sigmoid(100 z) of every hidden pre-activation for the reverse-mode gradient
+  // pass k_sdf_back_f32 (below) through `grad` -- [tile][layer 8][k-block 16][lane 64] float4, in the register order of this engine.
+  constexpr bool JVP = MODE == 2 || MODE == 3;
+  constexpr bool FULL = (MODE == 1 || MODE == 3 || MODE == 5);
+  constexpr bool STORE = MODE == 5;
   constexpr int NL = FULL ? 272 : 16;
   __shared__ f4 lds[2 * chunk_f4(272)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -455,20 +459,46 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
     load_features<64>(X, row0, MR, lane, x0[0]);
     load_features<64>(X, row0 + 16, MR, lane, x0[1]);
   }
+  // activation of one hidden layer (softplus_into), in MODE 5 with the sigmoid store
+  f4* sig_tile = nullptr;
+  if constexpr (STORE) sig_tile = reinterpret_cast<f4*>(grad) + (((long)blockIdx.x * 4 + wave) * 2) * (8L * 16 * 64) + lane;
+  auto act = [&](auto nreg_tag, auto hreg_tag, const auto& zz, auto& hh, float scale, int layer) {
+    constexpr int NREG = decltype(nreg_tag)::value, HREG = decltype(hreg_tag)::value;
+    if constexpr (STORE) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kb = 0; kb < NREG / 4; ++kb) {
+          f4 sg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s1;
+            hh[t][kb * 4 + r] = softplus100<PRECISE>(zz[t][kb * 4 + r], &s1) * scale;
+            sg[r] = s1;
+          }
+          sig_tile[((long)t * 8 + layer) * (16 * 64) + kb * 64] = sg;
+        }
+    } else {
+      softplus_into<NREG, HREG, JVP, PRECISE>(zz, hh, lane, scale);
+    }
+  };
+  using I52 = std::integral_constant<int, 52>;
+  using I64 = std::integral_constant<int, 64>;
+  using I68 = std::integral_constant<int, 68>;
   ws.prime<chunk_f4(64)>(w0);
   dense_layer<64, 256, 2, 256>(ws, w0, w1, x0, z, lane, bias_on);
-  softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
+  act(I64{}, I64{}, z, ha, 1.0f, 0);
 #pragma unroll 1
   for (int l = 0; l < 2; ++l) {
     dense_layer<256, 256, 2, 256>(ws, w1 + l * LF, w1 + (l + 1) * LF, ha, z, lane, bias_on);
-    softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
+    act(I64{}, I64{}, z, ha, 1.0f, 1 + l);
   }
   {
     float hs[2][68];
     {
       float z3[2][52];
       dense_layer<256, 208, 2, 272>(ws, w3, w4, ha, z3, lane, bias_on);
-      softplus_into<52, 68, JVP, PRECISE>(z3, hs, lane, inv_sqrt2);   // neurons 193..207 are padding: zero weights downstream
+      act(I52{}, I68{}, z3, hs, inv_sqrt2, 3);   // neurons 193..207 are padding: zero weights downstream
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -476,11 +506,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
       for (int i = 0; i < 16; ++i) hs[t][52 + i] = x0[t][i] * inv_sqrt2;
     dense_layer<272, 256, 2, 256>(ws, w4, w5, hs, z, lane, bias_on);
   }
-  softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
+  act(I64{}, I64{}, z, ha, 1.0f, 4);
 #pragma unroll 1
   for (int l = 0; l < 3; ++l) {
     dense_layer<256, 256, 2, 256>(ws, w5 + l * LF, w5 + (l + 1) * LF, ha, z, lane, bias_on);
-    softplus_into<64, 64, JVP, PRECISE>(z, ha, lane, 1.0f);
+    act(I64{}, I64{}, z, ha, 1.0f, 5 + l);
   }
   float zo[2][NL / 4];
   dense_layer<256, NL, 2, 0>(ws, w8, nullptr, ha, zo, lane, bias_on);
@@ -522,6 +552,103 @@ __global__ __launch_bounds__(256, 1) void k_sdf_mlp(const float* __restrict__ X,
       }
     }
   }
+}
+
+// ---- d sdf / d (encoded input) by reverse mode on the f32-input MFMA (the exact policy's counterpart of sdf_back.hip): the sigmoid
+// tiles of k_sdf_mlp<5> in, two 64-wide gradient rows per point out (layer 0's and the skip connection's share: k_pe_grad_points
+// contracts them with the encoding's Jacobian).  One pass over the transposed layers instead of the three tangent rows per point of
+// the forward-mode kernels (modes 2 / 3): 2 x the value pass's MACs instead of 4 x.
+// Wt (packing.pack_sdf_back): W7^T, W6^T, W5^T, [W4^T: 193 -> 208 rows | 63 -> 64 skip rows] (N = 272), W3^T (K = 208), W2^T, W1^T,
+// W0^T (N = 64), no biases; w8row = row 0 of layer 8 (d sdf / d h7).
+__global__ __launch_bounds__(256, 1) void k_sdf_back_f32(const f4* __restrict__ sig, long M, const f4* __restrict__ Wt,
+                                                          const float* __restrict__ w8row, float* __restrict__ gfeat) {
+  __shared__ f4 lds[2 * chunk_f4(272)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  WStream<272> ws;
+  ws.init(lds, tid);
+  constexpr long LF = layer_f4<256, 256>();
+  const f4* b7 = Wt;
+  const f4* b4 = b7 + 3 * LF;
+  const f4* b3 = b4 + layer_f4<256, 272>();
+  const f4* b2 = b3 + layer_f4<208, 256>();
+  const f4* b0 = b2 + 2 * LF;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 32 + (lane & 15);
+  const f4* sig_tile = sig + (((long)blockIdx.x * 4 + wave) * 2) * (8L * 16 * 64) + lane;
+  const float inv_sqrt2 = 0.70710678118654752440f;
+  float dh[2][64], dz[2][64];
+  // dz = dh (.) sigmoid(100 z) of `layer`, NB k-blocks
+  auto gate = [&](auto nb_tag, const auto& hh, auto& zz, int layer) {
+    constexpr int NB = decltype(nb_tag)::value;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) {
+        const f4 sg = sig_tile[((long)t * 8 + layer) * (16 * 64) + kb * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zz[t][kb * 4 + r] = hh[t][kb * 4 + r] * sg[r];
+      }
+  };
+  using I13 = std::integral_constant<int, 13>;
+  using I16 = std::integral_constant<int, 16>;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      const f4 v = *reinterpret_cast<const f4*>(w8row + kb * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[t][kb * 4 + r] = v[r];
+    }
+  ws.prime<chunk_f4(256)>(b7);
+#pragma unroll 1
+  for (int l = 0; l < 3; ++l) {                 // layers 7, 6, 5
+    gate(I16{}, dh, dz, 7 - l);
+    dense_layer<256, 256, 2, 256>(ws, b7 + l * LF, l < 2 ? b7 + (l + 1) * LF : b4, dz, dh, lane, false);
+  }
+  gate(I16{}, dh, dz, 4);
+  float skip[2][16];
+  {
+    float dhs[2][68];
+    dense_layer<256, 272, 2, 208>(ws, b4, b3, dz, dhs, lane, false);
+    float dz3[2][52];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 52; ++i) dh[t][i] = dhs[t][i] * inv_sqrt2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) skip[t][i] = dhs[t][52 + i] * inv_sqrt2;
+    }
+    gate(I13{}, dh, dz3, 3);
+    dense_layer<208, 256, 2, 256>(ws, b3, b2, dz3, dh, lane, false);
+  }
+  gate(I16{}, dh, dz, 2);
+  dense_layer<256, 256, 2, 256>(ws, b2, b2 + LF, dz, dh, lane, false);
+  gate(I16{}, dh, dz, 1);
+  dense_layer<256, 256, 2, 256>(ws, b2 + LF, b0, dz, dh, lane, false);
+  gate(I16{}, dh, dz, 0);
+  float dx[2][16];
+  dense_layer<256, 64, 2, 0>(ws, b0, nullptr, dz, dx, lane, false);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const long row = row0 + 16 * t;
+    if (row >= M) continue;
+    f4* dst = reinterpret_cast<f4*>(gfeat + row * 128) + g;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      dst[kb * 4] = f4{dx[t][kb * 4], dx[t][kb * 4 + 1], dx[t][kb * 4 + 2], dx[t][kb * 4 + 3]};
+      dst[16 + kb * 4] = f4{skip[t][kb * 4], skip[t][kb * 4 + 1], skip[t][kb * 4 + 2], skip[t][kb * 4 + 3]};
+    }
+  }
+}
+
+// host-side launchers for sdf_back.hip (rb_sdf_value_grad_f32_points)
+int launch_sdf_f32_store(const float* xyz, long M, float in_scale, const float* Wp, float out_scale, float* out0, float* sig,
+                         hipStream_t s) {
+  hipLaunchKernelGGL((k_sdf_mlp<5, false, true>), grid1d(M, 128), dim3(256), 0, s, xyz, M, (const f4*)Wp, out_scale, 1.0f, out0, sig, in_scale);
+  return check_launch("k_sdf_mlp<5>");
+}
+int launch_sdf_back_f32(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s) {
+  hipLaunchKernelGGL(k_sdf_back_f32, grid1d(M, 128), dim3(256), 0, s, (const f4*)sig, M, (const f4*)Wt, w8row, gfeat);
+  return check_launch("k_sdf_back_f32");
 }
 
 // ---- NeuS colour network (model/neus_model.py:535-560): 289(304) -> 256 x4 ReLU -> 3(16) -> sigmoid

@@ -589,6 +589,30 @@ static int sdf_value_grad_impl(const float* X, const float* xyz, float in_scale,
   return check_launch("k_pe_grad");
 }
 
+// The same op at the reference's precision (exact policy): k_sdf_mlp<5> (f32-input MFMA, sigmoid tiles out), k_sdf_back_f32,
+// k_pe_grad_points.  scratch: rb_sdf_value_grad_f32_scratch_floats(M) floats.
+extern "C" long rb_sdf_value_grad_f32_scratch_floats(long M) {
+  const long tiles = (M + 127) / 128 * 8;
+  return tiles * (8L * 16 * 64 * 4) + ((M + 127) / 128 * 128) * 128L;
+}
+extern "C" int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                            float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                                            rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Wt && w8row && out0 && grad && scratch, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long tiles = (M + 127) / 128 * 8;
+  float* sig = scratch;
+  float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
+  int rc = launch_sdf_f32_store(x, M, in_scale, Wp, out_scale, out0, sig, s);
+  if (rc) return rc;
+  rc = launch_sdf_back_f32(sig, M, Wt, w8row, gfeat, s);
+  if (rc) return rc;
+  const long n = 3 * M;
+  hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);
+  return check_launch("k_pe_grad_points");
+}
+
 extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
                                  rb_stream_t stream) {

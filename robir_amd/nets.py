@@ -473,6 +473,10 @@ class SDFNetwork(nn.Module):
         assert self.kind == "neus"
         return self._packed.get("back_h3", self, lambda sd: packing.pack_sdf_back_h3(self._sd(sd), _dev(self)))
 
+    def packed_back(self):
+        assert self.kind == "neus"
+        return self._packed.get("back", self, lambda sd: packing.pack_sdf_back(self._sd(sd), _dev(self)))
+
     def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False, precise=False):
         """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
         precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
@@ -487,6 +491,11 @@ class SDFNetwork(nn.Module):
             # values once + one row vector back through the transposed layers, instead of three tangent rows per point
             return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
                                       out_scale)
+        if (grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
+                and M >= ops.SDF_GRAD_F32_MIN_POINTS):
+            # the same at the reference's precision: f32-input MFMA value pass + one pass over the transposed layers
+            out, g = ops.sdf_value_grad_f32(x, M, self.packed(True), self.packed_back(), in_scale, out_scale)
+            return (out if full else out[:, 0].contiguous()), g
         if (not grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE
                 and ops.sdf_ring_waves() == 8):
             # value rows straight from the points: positional encoding fused into the network kernel (csrc/sdf_ring8.hip)

@@ -201,6 +201,21 @@ def pack_sdf_back_h3(sd, device):
     return blob, W[8][0].contiguous().to(device)
 
 
+def pack_sdf_back(sd, device):
+    """pack_sdf_back_h3 for the f32-input MFMA (rb_sdf_value_grad_f32_points, k_sdf_back_f32 in csrc/mlp_kernels.hip): W7^T, W6^T, W5^T,
+    W4^T as [193 continuing rows -> 208 | 63 skip-feature rows -> 64] (N = 272), W3^T (K 193 -> 208), W2^T, W1^T, W0^T (N 63 -> 64),
+    no biases; and row 0 of layer 8.  -> (blob, w8row [256])."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
+    W = [_fold_wn(sdt, SDF + "lin%d." % l) for l in range(9)]
+    m4 = torch.zeros(272, 256)
+    m4[:193] = W[4][:, :193].t()
+    m4[208:271] = W[4][:, 193:256].t()
+    mats = [W[7].t(), W[6].t(), W[5].t(), m4, W[3].t(), W[2].t(), W[1].t(), W[0].t()]
+    ls = [dict(W=m.contiguous(), b=None, n_pad=_pad16(m.shape[0]), k_pad=_pad16(m.shape[1]), perm=None) for m in mats]
+    assert [l["n_pad"] for l in ls] == [256, 256, 256, 272, 256, 256, 256, 64] and ls[4]["k_pad"] == 208
+    return pack_layers(ls, device), W[8][0].contiguous().to(device)
+
+
 def pack_color(sd, device):
     """[304->256 (cols permuted to [feat|x|PE4(view)|normal]), 256->256 x3, 256->16]  (neus_model.py:511-531)."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}

@@ -623,3 +623,36 @@ def test_wide_ring_kernels_are_bit_identical_to_the_first_generation(dev, synth_
     for _ in range(3):
         assert torch.equal(a, ops.cesr_net_points(p, 3000 * 128, 2, sh16, 128, s, ring=True))
     ops.range_check(sync=True)
+
+
+@pytest.mark.parametrize("weights", ["init", "trained_like"])
+def test_sdf_value_grad_reverse_mode_f32(dev, synth_weights, weights):
+    """The exact policy's reverse-mode gradient (k_sdf_mlp<5> + k_sdf_back_f32 + k_pe_grad_points): the 257 outputs are the value
+    kernel's bit for bit, the gradient agrees with the forward-mode rows of the same engine to fp32 rounding and with the oracle's
+    autograd to the value tests' tolerance -- at ragged sizes and across slabs."""
+    from robir_amd import ops, packing
+    from robir_oracle import nets as on
+    sd = synth_weights if weights == "init" else _trained_like(synth_weights, 5)
+    g = torch.Generator().manual_seed(71)
+    blob, back = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf_back(sd, dev)
+    for n in (1, 33, 128, 129, 5000, 70000):
+        x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
+        out, grad = ops.sdf_value_grad_f32(x, n, blob, back, in_scale=2.0, out_scale=0.5)
+        ref_out, ref_grad = ops.sdf_mlp_points(x, n, blob, 3, 2.0, 0.5, 1.0)
+        assert torch.equal(out, ops.sdf_mlp_points(x, n, blob, 1, 2.0, 0.5, 1.0)[0]), n
+        assert torch.equal(out, ref_out), n
+        assert rel_err(grad.cpu(), ref_grad.cpu()) <= 2e-5, (n, rel_err(grad.cpu(), ref_grad.cpu()))
+    x = ((torch.rand(300, 3, generator=g) - 0.5) * 1.2)
+    _, grad = ops.sdf_value_grad_f32(x.to(dev), 300, blob, back, in_scale=2.0, out_scale=0.5)
+    ref_g = on.implicit_gradient(on.as_torch(sd), x)
+    assert float(ref_g.abs().max()) > 0.5
+    assert rel_err(grad.cpu(), ref_g) <= TOL
+    old = ops.SDF_GRAD_SLAB
+    ops.SDF_GRAD_SLAB = 4096
+    try:
+        x = ((torch.rand(10000, 3, generator=g) - 0.5) * 1.2).to(dev)
+        a = ops.sdf_value_grad_f32(x, 10000, blob, back, 2.0, 0.5)
+    finally:
+        ops.SDF_GRAD_SLAB = old
+    b = ops.sdf_value_grad_f32(x, 10000, blob, back, 2.0, 0.5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
