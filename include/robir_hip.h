@@ -136,6 +136,14 @@ int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* 
  * pre-activation kept (k_sdf_mlp<5>), one pass over the transposed layers (k_sdf_back_f32; Wt / w8row from the host mirror's
  * packing.pack_sdf_back), the encoding's Jacobian (k_pe_grad_points) -- 2 x the value pass's MACs instead of the 4 x of the three
  * tangent rows per point of rb_sdf_mlp_points mode 3.  scratch: rb_sdf_value_grad_f32_scratch_floats(M) floats. */
+/* The SDF value pass on EXACT fp32 operands (three f16 pieces per operand, six MFMA products per multiply-add in three fp32 accumulators:
+ * not narrower than an fp32 fma chain; csrc/sdf_x6.hip) -- the default policy's value kernel.  x [M,3] points (encoded in the kernel,
+ * x in_scale), Wp = the host mirror's packing.pack_sdf_x6(full = mode); mode 0: out0 [M] signed distances, 1: out0 [M,257].
+ * rb_sdf_value_grad_x6_points: rb_sdf_value_grad_f32_points with that value pass (same scratch, same Wt / w8row). */
+int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
+                     rb_stream_t stream);
+int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);
 int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);

@@ -613,6 +613,25 @@ extern "C" int rb_sdf_value_grad_f32_points(const float* x, long M, float in_sca
   return check_launch("k_pe_grad_points");
 }
 
+// ... with the value pass on exact three-piece operands (k_sdf_x6<5>, csrc/sdf_x6.hip; Wp = packing.pack_sdf_x6): same scratch.
+extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                           float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                                           rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Wt && w8row && out0 && grad && scratch, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long tiles = (M + 127) / 128 * 8;
+  float* sig = scratch;
+  float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
+  int rc = launch_sdf_x6_store(x, M, in_scale, Wp, out_scale, out0, sig, s);
+  if (rc) return rc;
+  rc = launch_sdf_back_f32(sig, M, Wt, w8row, gfeat, s);
+  if (rc) return rc;
+  const long n = 3 * M;
+  hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);
+  return check_launch("k_pe_grad_points");
+}
+
 extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
                                  rb_stream_t stream) {

@@ -473,6 +473,10 @@ class SDFNetwork(nn.Module):
         assert self.kind == "neus"
         return self._packed.get("back_h3", self, lambda sd: packing.pack_sdf_back_h3(self._sd(sd), _dev(self)))
 
+    def packed_x6(self, full=True):
+        assert self.kind == "neus"
+        return self._packed.get("x6_full" if full else "x6_dist", self, lambda sd: packing.pack_sdf_x6(self._sd(sd), _dev(self), full=full))
+
     def packed_back(self):
         assert self.kind == "neus"
         return self._packed.get("back", self, lambda sd: packing.pack_sdf_back(self._sd(sd), _dev(self)))
@@ -493,9 +497,15 @@ class SDFNetwork(nn.Module):
                                       out_scale)
         if (grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
                 and M >= ops.SDF_GRAD_F32_MIN_POINTS):
-            # the same at the reference's precision: f32-input MFMA value pass + one pass over the transposed layers
-            out, g = ops.sdf_value_grad_f32(x, M, self.packed(True), self.packed_back(), in_scale, out_scale)
+            # the same at the reference's precision: value pass on exact three-piece operands (or the f32-input MFMA) + one pass over
+            # the transposed layers on the f32-input MFMA
+            if ops.SDF_X6:
+                out, g = ops.sdf_value_grad_x6(x, M, self.packed_x6(True), self.packed_back(), in_scale, out_scale)
+            else:
+                out, g = ops.sdf_value_grad_f32(x, M, self.packed(True), self.packed_back(), in_scale, out_scale)
             return (out if full else out[:, 0].contiguous()), g
+        if not grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_X6:
+            return ops.sdf_points_x6(x, M, self.packed_x6(full), full, in_scale, out_scale), None
         if (not grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE
                 and ops.sdf_ring_waves() == 8):
             # value rows straight from the points: positional encoding fused into the network kernel (csrc/sdf_ring8.hip)

@@ -246,6 +246,7 @@ def sdf_points_jvp_h3(x, M, blob, full, scale_log2, in_scale=1.0, out_scale=1.0,
 
 SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)
 SDF_GRAD_MIN_POINTS = 16384       # below this the three-launch reverse form does not pay (0.25 ms floor; measured crossover)
+SDF_X6 = _os.environ.get("ROBIR_SDF_X6", "1") == "1"    # exact policy: SDF value passes on exact three-piece operands (csrc/sdf_x6.hip)
 SDF_GRAD_F32_MIN_POINTS = 16384   # ... of the f32-input-MFMA form (three launches against one of the four-row forward-mode kernel)
 SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB of scratch per point)
 _sdf_grad_scratch = {}
@@ -307,6 +308,37 @@ def sdf_value_grad_f32(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     for a in range(0, M, slab):
         n = min(slab, M - a)
         call("rb_sdf_value_grad_f32_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob), ptr(wt), ptr(w8),
+             c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), stream_ptr())
+    return out0, grad
+
+
+def sdf_points_x6(x, M, blob, full, in_scale=1.0, out_scale=1.0):
+    """SDF value rows on exact three-piece operands (csrc/sdf_x6.hip): x [M,3] -> out [M,257] | [M]; blob = packing.pack_sdf_x6(full)."""
+    x = _f32(x)
+    out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
+    if M > 0:
+        call("rb_sdf_x6_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_float(out_scale), ptr(out0),
+             c_int(0), stream_ptr())
+    return out0
+
+
+def sdf_value_grad_x6(x, M, blob, back, in_scale=1.0, out_scale=1.0):
+    """sdf_value_grad_f32 with the value pass on exact three-piece operands (blob = packing.pack_sdf_x6(full=True))."""
+    wt, w8 = back
+    out0 = torch.empty(M, 257, dtype=torch.float32, device=x.device)
+    grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    if M == 0:
+        return out0, grad
+    slab = min(M, SDF_GRAD_SLAB)
+    need = int(_lib.lib().rb_sdf_value_grad_f32_scratch_floats(c_long(slab)))
+    key = (x.device, torch.cuda.current_stream().cuda_stream, "f32")
+    scratch = _sdf_grad_scratch.get(key)
+    if scratch is None or scratch.numel() < need:
+        scratch = _sdf_grad_scratch[key] = torch.empty(need, dtype=torch.float32, device=x.device)
+    x = _f32(x)
+    for a in range(0, M, slab):
+        n = min(slab, M - a)
+        call("rb_sdf_value_grad_x6_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob), ptr(wt), ptr(w8),
              c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), stream_ptr())
     return out0, grad
 

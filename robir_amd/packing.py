@@ -93,8 +93,13 @@ def pack_layers_x6(layers, device, scale_log2=H3_SCALE_LOG2):
             raise ValueError("exact-operand packing: |w| * 2^%d = %.3g exceeds the f16 range; run this network with "
                              "ROBIR_VIS_PRECISION=fp32" % (scale_log2, wmax))
         keep += [W, b]
+        perm = None
+        if l.get("perm") is not None:
+            perm = torch.tensor(l["perm"], dtype=torch.int32, device=device)
+            assert perm.numel() == l["k_pad"]
+        keep.append(perm)
         _lib.call("rb_pack_layer_x6", _lib.ptr(W), _lib.ptr(b), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
-                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), ctypes.c_void_p(0), ctypes.c_int(scale_log2),
+                  ctypes.c_int(l["n_pad"]), ctypes.c_int(l["k_pad"]), _lib.ptr(perm), ctypes.c_int(scale_log2),
                   ctypes.c_void_p(blob[off:off + sz].data_ptr()), _lib.stream_ptr())
         off += sz
     torch.cuda.current_stream().synchronize()
@@ -182,6 +187,24 @@ def pack_sdf_h3(sd, device, full=True):
             W, b, n_pad = W[:1].contiguous(), b[:1].contiguous(), 16
         ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
     return pack_layers_h3(ls, device)
+
+
+def pack_sdf_x6(sd, device, full=True):
+    """pack_sdf_h3's layout with every weight as three halves, scale 2^0 (rb_sdf_x6_points, csrc/sdf_x6.hip)."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
+    ls = []
+    for l in range(9):
+        W = _fold_wn(sdt, SDF + "lin%d." % l)
+        b = sdt[SDF + "lin%d.bias" % l].float()
+        n_pad, k_pad, perm = _pad16(W.shape[0]), _pad32(W.shape[1]), None
+        if l == 4:
+            k_pad = 288
+            perm = [k if k < 193 else -1 for k in range(208)] + [193 + j if j < 63 else -1 for j in range(64)] + [-1] * 16
+        if l == 8 and not full:
+            W, b, n_pad = W[:1].contiguous(), b[:1].contiguous(), 16
+        ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)])       # a wave's shifted-back copy span never leaves the blob; slack for the last chunk
 
 
 def pack_sdf_back_h3(sd, device):

@@ -656,3 +656,36 @@ def test_sdf_value_grad_reverse_mode_f32(dev, synth_weights, weights):
         ops.SDF_GRAD_SLAB = old
     b = ops.sdf_value_grad_f32(x, 10000, blob, back, 2.0, 0.5)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("weights", ["init", "trained_like"])
+def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
+    """k_sdf_x6 (csrc/sdf_x6.hip: exact three-piece operands, six products per multiply-add): values against the f32-input-MFMA kernel
+    and the oracle, the sdf-only form against the full one, the reverse-mode gradient through its sigmoid tiles against the fp32 one --
+    ragged sizes, many rounds per workgroup, run to run."""
+    from robir_amd import ops, packing
+    from robir_oracle import nets as on
+    sd = synth_weights if weights == "init" else _trained_like(synth_weights, 5)
+    g = torch.Generator().manual_seed(91)
+    b32, back = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf_back(sd, dev)
+    x6f, x6d = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False)
+    for n in (1, 15, 64, 65, 1000, 40000, 300001):
+        x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
+        ref = ops.sdf_mlp_points(x, n, b32, 1, 2.0, 0.5, 1.0)[0]
+        out = ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)
+        assert rel_err(out.cpu(), ref.cpu()) <= 2e-6, (n, rel_err(out.cpu(), ref.cpu()))
+        d = ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5)
+        assert torch.equal(d, out[:, 0]), n
+        assert torch.equal(out, ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)), n
+        if n in (65, 40000):
+            o2, grad = ops.sdf_value_grad_x6(x, n, x6f, back, 2.0, 0.5)
+            assert torch.equal(o2, out), n
+            _, g32 = ops.sdf_value_grad_f32(x, n, b32, back, 2.0, 0.5)
+            assert rel_err(grad.cpu(), g32.cpu()) <= 2e-5, (n, rel_err(grad.cpu(), g32.cpu()))
+    x = ((torch.rand(300, 3, generator=g) - 0.5) * 1.2)
+    osd = on.as_torch(sd)
+    out = ops.sdf_points_x6(x.to(dev), 300, x6f, True, 2.0, 0.5)
+    assert rel_err(out.cpu(), on.implicit_forward(osd, x)) <= TOL
+    _, grad = ops.sdf_value_grad_x6(x.to(dev), 300, x6f, back, 2.0, 0.5)
+    assert rel_err(grad.cpu(), on.implicit_gradient(osd, x)) <= TOL
+    ops.range_check(sync=True)

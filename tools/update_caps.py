@@ -17,6 +17,8 @@ for line in open(src):
         caps[n] = max(2.0 * meas[n], d["tol"])
 dst = os.path.join(ROOT, "tests", "golden", "measured_caps.json")
 old = json.load(open(dst)) if os.path.exists(dst) and "--fresh" not in sys.argv else {}
+if "--raise-only" in sys.argv:         # a re-measurement after an arithmetic change: never tighten what another policy / run needed
+    caps = {k: max(v, old.get(k, 0.0)) for k, v in caps.items()}
 old.update(caps)                      # comparisons not re-measured in this run keep their recorded cap
 out = {k: float("%.3g" % v) for k, v in sorted(old.items())}
 json.dump(out, open(dst, "w"), indent=0, sort_keys=True)
