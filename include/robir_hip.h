@@ -139,9 +139,13 @@ int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* 
 /* The SDF value pass on EXACT fp32 operands (three f16 pieces per operand, six MFMA products per multiply-add in three fp32 accumulators:
  * not narrower than an fp32 fma chain; csrc/sdf_x6.hip) -- the default policy's value kernel.  x [M,3] points (encoded in the kernel,
  * x in_scale), Wp = the host mirror's packing.pack_sdf_x6(full = mode); mode 0: out0 [M] signed distances, 1: out0 [M,257].
- * rb_sdf_value_grad_x6_points: rb_sdf_value_grad_f32_points with that value pass (same scratch, same Wt / w8row). */
+ * rb_sdf_value_grad_x6_points: rb_sdf_value_grad_f32_points with that value pass and the pass over the transposed layers on exact
+ * operands too (csrc/sdf_back_x6.hip; Wt / w8row = packing.pack_sdf_back_x6; same scratch). */
 int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
                      rb_stream_t stream);
+/* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
+int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                       const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);

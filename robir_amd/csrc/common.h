@@ -33,6 +33,7 @@ unsigned* range_flags();
 int launch_sdf_f32_store(const float* xyz, long M, float in_scale, const float* Wp, float out_scale, float* out0, float* sig,
                          hipStream_t s);
 int launch_sdf_back_f32(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s);
+int launch_sdf_back_x6(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s);                       // sdf_back_x6.hip
 int launch_sdf_x6_store(const float* x, long M, float in_scale, const float* Wp, float out_scale, float* out0, float* sig, hipStream_t s);   // sdf_x6.hip
 
 }  // namespace rb

@@ -613,7 +613,8 @@ extern "C" int rb_sdf_value_grad_f32_points(const float* x, long M, float in_sca
   return check_launch("k_pe_grad_points");
 }
 
-// ... with the value pass on exact three-piece operands (k_sdf_x6<5>, csrc/sdf_x6.hip; Wp = packing.pack_sdf_x6): same scratch.
+// ... with both passes on exact three-piece operands (k_sdf_x6<5>, csrc/sdf_x6.hip, Wp = packing.pack_sdf_x6; k_sdf_back_x6,
+// csrc/sdf_back_x6.hip, Wt = packing.pack_sdf_back_x6): same scratch.
 extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                            float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
                                            rb_stream_t stream) {
@@ -625,7 +626,7 @@ extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scal
   float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
   int rc = launch_sdf_x6_store(x, M, in_scale, Wp, out_scale, out0, sig, s);
   if (rc) return rc;
-  rc = launch_sdf_back_f32(sig, M, Wt, w8row, gfeat, s);
+  rc = launch_sdf_back_x6(sig, M, Wt, w8row, gfeat, s);
   if (rc) return rc;
   const long n = 3 * M;
   hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);

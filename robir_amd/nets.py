@@ -477,6 +477,10 @@ class SDFNetwork(nn.Module):
         assert self.kind == "neus"
         return self._packed.get("x6_full" if full else "x6_dist", self, lambda sd: packing.pack_sdf_x6(self._sd(sd), _dev(self), full=full))
 
+    def packed_back_x6(self):
+        assert self.kind == "neus"
+        return self._packed.get("back_x6", self, lambda sd: packing.pack_sdf_back_x6(self._sd(sd), _dev(self)))
+
     def packed_back(self):
         assert self.kind == "neus"
         return self._packed.get("back", self, lambda sd: packing.pack_sdf_back(self._sd(sd), _dev(self)))
@@ -500,7 +504,7 @@ class SDFNetwork(nn.Module):
             # the same at the reference's precision: value pass on exact three-piece operands (or the f32-input MFMA) + one pass over
             # the transposed layers on the f32-input MFMA
             if ops.SDF_X6:
-                out, g = ops.sdf_value_grad_x6(x, M, self.packed_x6(True), self.packed_back(), in_scale, out_scale)
+                out, g = ops.sdf_value_grad_x6(x, M, self.packed_x6(True), self.packed_back_x6(), in_scale, out_scale)
             else:
                 out, g = ops.sdf_value_grad_f32(x, M, self.packed(True), self.packed_back(), in_scale, out_scale)
             return (out if full else out[:, 0].contiguous()), g
@@ -587,6 +591,10 @@ class RenderingNetwork(nn.Module):
         return self._packed.get("c", self, lambda sd: packing.pack_color(
             {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
 
+    def packed_x6(self):
+        return self._packed.get("c_x6", self, lambda sd: packing.pack_color_x6(
+            {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
+
     def packed_h3(self):
         return self._packed.get("c_h3", self, lambda sd: packing.pack_color_h3(
             {"implicit_network.neus_model.color_network." + k: v for k, v in sd.items()}, _dev(self)))
@@ -597,6 +605,9 @@ class RenderingNetwork(nn.Module):
             fn = ops.color_mlp_h3_points if ops.SDF_FUSED_PE else ops.color_mlp_h3_two      # encoding inside the kernel | tail rows
             return fn(points, view_dirs, normals, feature_vectors, self.packed_h3(), packing.H3_SCALE_LOG2,
                       x_scale=x_scale, feat_scale=feat_scale)
+        if ops.SDF_FUSED_PE and ops.SDF_X6:
+            return ops.color_x6_points(points, view_dirs, normals, feature_vectors, self.packed_x6(), x_scale=x_scale,
+                                       feat_scale=feat_scale)
         if ops.SDF_FUSED_PE:
             return ops.color_mlp_points(points, view_dirs, normals, feature_vectors, self.packed(), x_scale=x_scale,
                                         feat_scale=feat_scale)

@@ -204,6 +204,17 @@ def color_mlp_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0):
     return rgb
 
 
+def color_x6_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0):
+    """color_mlp_points on exact three-piece operands (csrc/color_x6.hip; blob = packing.pack_color_x6)."""
+    x, view, normal = _f32(x), _f32(view), _f32(normal)
+    assert feat.dtype == torch.float32 and feat.stride(-1) == 1
+    M = x.shape[0]
+    rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+    call("rb_color_x6_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
+         ptr(view), ptr(normal), c_long(M), ptr(blob), ptr(rgb), c_int(0), stream_ptr())
+    return rgb
+
+
 import os as _os
 SDF_KERNEL = _os.environ.get("ROBIR_SDF_KERNEL", "ring")     # "ring" | "v1" (first-generation k_sdf_mlp_h3)
 
@@ -323,7 +334,8 @@ def sdf_points_x6(x, M, blob, full, in_scale=1.0, out_scale=1.0):
 
 
 def sdf_value_grad_x6(x, M, blob, back, in_scale=1.0, out_scale=1.0):
-    """sdf_value_grad_f32 with the value pass on exact three-piece operands (blob = packing.pack_sdf_x6(full=True))."""
+    """sdf_value_grad_f32 with both passes on exact three-piece operands (blob = packing.pack_sdf_x6(full=True), back =
+    packing.pack_sdf_back_x6)."""
     wt, w8 = back
     out0 = torch.empty(M, 257, dtype=torch.float32, device=x.device)
     grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)

@@ -239,6 +239,20 @@ def pack_sdf_back(sd, device):
     return pack_layers(ls, device), W[8][0].contiguous().to(device)
 
 
+def pack_sdf_back_x6(sd, device):
+    """pack_sdf_back with every weight as three halves, scale 2^0 (k_sdf_back_x6, csrc/sdf_back_x6.hip): W3^T's K 193 -> 224."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
+    W = [_fold_wn(sdt, SDF + "lin%d." % l) for l in range(9)]
+    m4 = torch.zeros(272, 256)
+    m4[:193] = W[4][:, :193].t()
+    m4[208:271] = W[4][:, 193:256].t()
+    mats = [W[7].t(), W[6].t(), W[5].t(), m4, W[3].t(), W[2].t(), W[1].t(), W[0].t()]
+    ls = [dict(W=m.contiguous(), b=None, n_pad=_pad16(m.shape[0]), k_pad=_pad32(m.shape[1]), perm=None) for m in mats]
+    assert [l["n_pad"] for l in ls] == [256, 256, 256, 272, 256, 256, 256, 64] and ls[4]["k_pad"] == 224
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)]), W[8][0].contiguous().to(device)
+
+
 def pack_color(sd, device):
     """[304->256 (cols permuted to [feat|x|PE4(view)|normal]), 256->256 x3, 256->16]  (neus_model.py:511-531)."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}
@@ -265,6 +279,21 @@ def pack_color_h3(sd, device):
             perm = [33 + k for k in range(256)] + list(range(33)) + [-1] * 31
         ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=320 if l == 0 else _pad32(W.shape[1]), perm=perm))
     return pack_layers_h3(ls, device)
+
+
+def pack_color_x6(sd, device):
+    """pack_color_h3's layout with every weight as three halves, scale 2^0 (rb_color_x6_points, csrc/color_x6.hip)."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(COL)}
+    ls = []
+    for l in range(5):
+        W = _fold_wn(sdt, COL + "lin%d." % l)
+        b = sdt[COL + "lin%d.bias" % l].float()
+        perm = None
+        if l == 0:
+            perm = [33 + k for k in range(256)] + list(range(33)) + [-1] * 31
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=320 if l == 0 else _pad32(W.shape[1]), perm=perm))
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)])
 
 
 def pack_illum(sd, device):

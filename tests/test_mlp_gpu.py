@@ -668,7 +668,7 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
     sd = synth_weights if weights == "init" else _trained_like(synth_weights, 5)
     g = torch.Generator().manual_seed(91)
     b32, back = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf_back(sd, dev)
-    x6f, x6d = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False)
+    x6f, x6d, back6 = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False), packing.pack_sdf_back_x6(sd, dev)
     for n in (1, 15, 64, 65, 1000, 40000, 300001):
         x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
         ref = ops.sdf_mlp_points(x, n, b32, 1, 2.0, 0.5, 1.0)[0]
@@ -677,15 +677,33 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
         d = ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5)
         assert torch.equal(d, out[:, 0]), n
         assert torch.equal(out, ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)), n
-        if n in (65, 40000):
-            o2, grad = ops.sdf_value_grad_x6(x, n, x6f, back, 2.0, 0.5)
+        if n in (1, 65, 1000, 40000, 300001):
+            o2, grad = ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)
             assert torch.equal(o2, out), n
             _, g32 = ops.sdf_value_grad_f32(x, n, b32, back, 2.0, 0.5)
             assert rel_err(grad.cpu(), g32.cpu()) <= 2e-5, (n, rel_err(grad.cpu(), g32.cpu()))
+            assert torch.equal(grad, ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)[1]), n
     x = ((torch.rand(300, 3, generator=g) - 0.5) * 1.2)
     osd = on.as_torch(sd)
     out = ops.sdf_points_x6(x.to(dev), 300, x6f, True, 2.0, 0.5)
     assert rel_err(out.cpu(), on.implicit_forward(osd, x)) <= TOL
-    _, grad = ops.sdf_value_grad_x6(x.to(dev), 300, x6f, back, 2.0, 0.5)
+    _, grad = ops.sdf_value_grad_x6(x.to(dev), 300, x6f, back6, 2.0, 0.5)
     assert rel_err(grad.cpu(), on.implicit_gradient(osd, x)) <= TOL
+    ops.range_check(sync=True)
+
+
+def test_color_exact_operand_kernel(dev, synth_weights):
+    """k_color_x6 (csrc/color_x6.hip) against the f32-input-MFMA colour kernel on the same inputs: ragged sizes, many rounds, run to run."""
+    from robir_amd import ops, packing
+    g = torch.Generator().manual_seed(97)
+    b32, x6 = packing.pack_color(synth_weights, dev), packing.pack_color_x6(synth_weights, dev)
+    for n in (1, 15, 64, 65, 5000, 300001):
+        x = ((torch.rand(n, 3, generator=g) - 0.5)).to(dev)
+        v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        out = torch.randn(n, 257, generator=g).to(dev)
+        ref = ops.color_mlp_points(x, v, nr, out[:, 1:], b32, x_scale=2.0, feat_scale=2.0)
+        a = ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0)
+        assert float((a - ref).abs().max()) <= 2e-6, (n, float((a - ref).abs().max()))
+        assert torch.equal(a, ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0)), n
     ops.range_check(sync=True)
