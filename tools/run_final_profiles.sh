@@ -35,6 +35,8 @@ python tools/prof_perchunk.py 2>/dev/null | grep per-chunk > $O/${TAG}_perchunk_
 python tools/prof_deferred.py 1024 128 2>/dev/null | grep -v "BOX\|boxes" > $O/${TAG}_deferred_rates.txt
 unset ROBIR_PRECISION
 python tools/prof_perchunk.py 2>/dev/null | grep per-chunk | sed 's/^/exact policy: /' >> $O/${TAG}_perchunk_rate.txt
+for C in 2 3 5; do RB_CONFIG_REPS=1 prof config${C}_exact python tools/bench_configs.py $C; done
+RB_CONFIG_REPS=1 pmc config2_exact "sdf_x6\|sdf_back_x6\|color_x6" python tools/bench_configs.py 2
 pmc dvis_x6 "dvis_x6" python tools/prof_dvis.py f16x6 32
 pmc dvis_v2 "dvis_v2" python tools/prof_dvis.py f16x3-v2 32
 export ROBIR_PRECISION=split RB_CONFIG_REPS=1
