@@ -2,7 +2,9 @@
 
   ROBIR_PRECISION=exact  (default)  not narrower than the reference's fp32: the fused light-visibility kernel carries every
                                     fp32 operand exactly as three f16 pieces (six f16 MFMA products per multiply-add, three fp32
-                                    accumulators: csrc/vis_diffuse_x6.hip), every other MLP runs on the f32-input MFMA;
+                                    accumulators: csrc/vis_diffuse_x6.hip), and so do the SDF network (values and reverse-mode
+                                    gradient) and the colour network (csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip;
+                                    ROBIR_SDF_X6=0 puts them back on the f32-input MFMA); the other MLPs run on the f32-input MFMA;
   ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
                                     2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
                                     guarded by the activation-range sentinel (ops.range_check).
