@@ -139,17 +139,23 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     };
     auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
     // hidden chunk pj: softplus (+ its sigmoid in MODE 5), three-way split into the next layer's operand registers
-    auto hidden_pair = [&](const SxAcc& a, int pj, int q, f4& sg) {
+    // hidden chunk pj in four stages (they go between the MFMA runs of the next chunk, one per run): A = softplus (+ its sigmoid in
+    // MODE 5) of a value pair, B = exact three-way split into the next layer's operand registers
+    float ev0[2], ev1[2];
+    auto stage_a = [&](const SxAcc& a, int q, f4& sg) {
       float s0, s1;
-      float v0 = softplus100<false>(combine(a, 2 * q), &s0), v1 = softplus100<false>(combine(a, 2 * q + 1), &s1);
+      // log(1 + e) without the log1p correction (mlp_engine.h: an absolute error <= 4e-10 on the activation, below an fp32 sum's own rounding)
+      float v0 = softplus100_fast(combine(a, 2 * q), &s0), v1 = softplus100_fast(combine(a, 2 * q + 1), &s1);
       if (SKIPOUT) {
         v0 *= inv_sqrt2;
         v1 *= inv_sqrt2;
       }
       sg[2 * q] = s0;
       sg[2 * q + 1] = s1;
-      put_pair(v0, v1, yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+      ev0[q] = v0;
+      ev1[q] = v1;
     };
+    auto stage_b = [&](int pj, int q) { put_pair(ev0[q], ev1[q], yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q); };
     auto store_sig = [&](int pj, const f4& sg) {
       if constexpr (STORE) sig[((rrow >> 4) * 8 + lrt) * (16L * 64) + pj * 64 + lane] = sg;
     };
@@ -228,19 +234,29 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
           for (int k = k0; k <= kb; ++k) SX_MFMA(acc.c0, wfh[(jb * KB + k) % NB], xh[k]);
 #undef SX_MFMA
         }
-        if (jb > 0) {                          // epilogue of chunk jb-1
+        if (jb > 0 && (st % BS == BS - 1 || kb == KB - 1)) {      // epilogue of chunk jb-1: a stage beside every MFMA run
           constexpr int dummy3 = 0;
           (void)dummy3;
-          const int e0 = 0, e1 = KB >= 8 ? 3 : (KB - 1);
-          if (!OUT) {
-            if (kb == e0) hidden_pair(accs[(jb - 1) & 1], jb - 1, 0, sgp);
-            if (kb == e1) {
-              hidden_pair(accs[(jb - 1) & 1], jb - 1, 1, sgp);
-              store_sig(jb - 1, sgp);
-            }
-          } else if (kb == e0) {
-            output_chunk(accs[(jb - 1) & 1], jb - 1);
+          int nm = 0, mi = 0;                    // MFMA-issuing k-blocks of this chunk; index of this one
+          for (int k = 0; k < KB; ++k) {
+            const bool issues = ((jb * KB + k) % BS == BS - 1) || k == KB - 1;
+            if (issues && k < kb) ++mi;
+            if (issues) ++nm;
           }
+#pragma unroll
+          for (int sgi = 0; sgi < 4; ++sgi)
+            if ((sgi * nm) / 4 == mi) {
+              const SxAcc& pa = accs[(jb - 1) & 1];
+              if (OUT) {
+                if (sgi == 0) output_chunk(pa, jb - 1);
+              } else if (sgi == 0) stage_a(pa, 0, sgp);
+              else if (sgi == 1) stage_b(jb - 1, 0);
+              else if (sgi == 2) stage_a(pa, 1, sgp);
+              else {
+                stage_b(jb - 1, 1);
+                store_sig(jb - 1, sgp);
+              }
+            }
         }
         if (kb >= HB) {
 #pragma unroll
@@ -272,8 +288,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     if constexpr (OUT) {
       output_chunk(last, NCH - 1);
     } else {
-      hidden_pair(last, NCH - 1, 0, sgp);
-      hidden_pair(last, NCH - 1, 1, sgp);
+      stage_a(last, 0, sgp);
+      stage_b(NCH - 1, 0);
+      stage_a(last, 1, sgp);
+      stage_b(NCH - 1, 1);
       store_sig(NCH - 1, sgp);
       if constexpr (SKIPOUT) {
 #pragma unroll
