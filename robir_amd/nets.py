@@ -500,7 +500,7 @@ class SDFNetwork(nn.Module):
             return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
                                       out_scale)
         if (grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
-                and M >= ops.SDF_GRAD_F32_MIN_POINTS):
+                and M >= (1 if ops.SDF_X6 else ops.SDF_GRAD_F32_MIN_POINTS)):      # exact operands: three launches of 0.07 ms beat 0.31
             # the same at the reference's precision: value pass on exact three-piece operands (or the f32-input MFMA) + one pass over
             # the transposed layers on the f32-input MFMA
             if ops.SDF_X6:

@@ -1,2 +1,2 @@
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py --config 2 --precision exact --steps 2 2>/dev/null | tail -1 | cut -c1-260
+python tools/prof_perchunk.py 2>/dev/null | grep per-chunk
