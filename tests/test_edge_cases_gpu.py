@@ -239,3 +239,62 @@ def test_round3_entry_points_on_empty_and_tiny_inputs(dev, synth_weights):
         ops.OVIS_COMPACT = old_c
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
     ops.range_check(sync=True)
+
+
+def test_round3_second_half_entry_points_on_empty_tiny_and_bad_inputs(dev, synth_weights):
+    """The chunk-stream / exact-operand / one-launch entry points of the round's second half: zero rows launch nothing and keep their
+    shapes, one row gives finite results equal to the reference kernels' within their bounds, null pointers and bad arguments come
+    back as RobirHipError (never a device fault), rb_scatter_rows covers no-hit, broadcast and default-only blocks."""
+    import ctypes
+    from robir_amd import _lib, ops, packing, synth
+    s = packing.H3_SCALE_LOG2
+    e3 = torch.zeros(0, 3, device=dev)
+    one = torch.tensor([[0.05, -0.1, 0.2]], device=dev)
+    c = synth.synth_cesr_nets(0)
+    sh16 = packing.pack_softplus512_h3({"net." + k: v for k, v in c["shadow_net"].items()}, "net.", 191, dev)
+    ill16 = packing.pack_illum_h3(synth_weights, dev)
+    col16, col6, col32 = packing.pack_color_h3(synth_weights, dev), packing.pack_color_x6(synth_weights, dev), packing.pack_color(synth_weights, dev)
+    x6f, back6 = packing.pack_sdf_x6(synth_weights, dev, full=True), packing.pack_sdf_back_x6(synth_weights, dev)
+    b32, back = packing.pack_sdf(synth_weights, dev, full=True), packing.pack_sdf_back(synth_weights, dev)
+    feat0, feat1 = torch.zeros(0, 257, device=dev), torch.randn(1, 257, generator=torch.Generator().manual_seed(3)).to(dev)
+    # zero rows
+    assert ops.cesr_net_points(e3, 0, 2, sh16, 128, s, ring=True).shape == (0, 2)
+    assert ops.wide_mlp_points(e3, None, ill16, False, s, ring=True).shape == (0, 144)
+    assert ops.wide_mlp_h3(torch.zeros(0, 64, device=dev), ill16, False, s, ring=True).shape == (0, 144)
+    assert ops.color_mlp_h3_points(e3, e3, e3, feat0[:, 1:], col16, s, ring=True).shape == (0, 3)
+    assert ops.color_x6_points(e3, e3, e3, feat0[:, 1:], col6).shape == (0, 3)
+    assert ops.sdf_points_x6(e3, 0, x6f, True).shape == (0, 257)
+    for fn, args in ((ops.sdf_value_grad_x6, (x6f, back6)), (ops.sdf_value_grad_f32, (b32, back))):
+        o, g = fn(e3, 0, *args)
+        assert o.shape == (0, 257) and g.shape == (0, 3)
+    # one row: the exact-operand kernels against the f32-input MFMA
+    v = torch.nn.functional.normalize(torch.tensor([[0.3, -0.2, 0.9]], device=dev), dim=-1)
+    a, b = ops.color_x6_points(one, v, v, feat1[:, 1:], col6), ops.color_mlp_points(one, v, v, feat1[:, 1:], col32)
+    assert float((a - b).abs().max()) <= 2e-6
+    (o6, g6), (o32, g32) = ops.sdf_value_grad_x6(one, 1, x6f, back6, 2.0, 0.5), ops.sdf_value_grad_f32(one, 1, b32, back, 2.0, 0.5)
+    assert rel_err(o6.cpu(), o32.cpu()) <= 1e-5 and rel_err(g6.cpu(), g32.cpu()) <= 1e-4, (rel_err(o6.cpu(), o32.cpu()), rel_err(g6.cpu(), g32.cpu()))
+    # bad arguments through the C ABI
+    L = _lib.lib()
+    nul = ctypes.c_void_p(0)
+    y = torch.empty(4, 3, device=dev)
+    for name, args in (
+            ("rb_cesr_net_ring_points", (nul, ctypes.c_long(4), ctypes.c_int(2), ctypes.c_int(128), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_cesr_net_ring_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_int(1), ctypes.c_int(128), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_cesr_net_ring_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_int(2), ctypes.c_int(200), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_sdf_x6_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_float(1.0), ops.ptr(x6f), ctypes.c_int(3), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_color_x6_points", (nul, ctypes.c_long(257), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_float(1.0), ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ops.ptr(col6), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_octree_cast_coop", (nul,) * 6 + (ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ctypes.c_int(32), ctypes.c_double(0.005), ctypes.c_int(64), ctypes.c_float(0.1)) + (nul,) * 9)):
+        assert getattr(L, name)(*args) != 0, name
+        assert b"null pointer" in L.rb_last_error() or b"kind" in L.rb_last_error() or b"n_label" in L.rb_last_error() or b"mode" in L.rb_last_error(), (name, L.rb_last_error())
+    # rb_scatter_rows
+    idx = torch.tensor([5, 0, 3], device=dev)
+    src3, src1 = torch.arange(9, dtype=torch.float32, device=dev).reshape(3, 3), torch.tensor([[7.0], [8.0], [9.0]], device=dev)
+    o3, ob, od = ops.scatter_rows([src3, src1, None], [3, 3, 1], idx, 6)
+    exp3 = torch.ones(6, 3, device=dev)
+    exp3[idx] = src3
+    expb = torch.ones(6, 3, device=dev)
+    expb[idx] = src1.expand(-1, 3)
+    assert torch.equal(o3, exp3) and torch.equal(ob, expb) and torch.equal(od, torch.ones(6, 1, device=dev))
+    none = ops.scatter_rows([src3[:0], None], [3, 1], idx[:0], 4, fill=0.5)
+    assert all(bool((t == 0.5).all()) for t in none) and none[0].shape == (4, 3)
+    ops.range_check(sync=True)

@@ -1,2 +1,1 @@
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python tools/prof_perchunk.py 2>/dev/null | grep per-chunk
+timeout 900 python -m pytest tests/test_edge_cases_gpu.py -m gpu -x -q 2>&1 | tail -15
