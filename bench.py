@@ -49,7 +49,7 @@ CHUNK = 1024
 
 PRECISIONS = {
     # name: (light-visibility kernel, stand-alone MLP kernels, dtype string of the JSON line)
-    "exact": ("f16x6", "fp32",
+    "exact": ("f16x6", "f16x6",
               "f32 (light-visibility MLP, SDF net (values and reverse-mode gradient) and colour net: every fp32 operand exact as three "
               "f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the other MLPs on the f32-input MFMA) "
               "-- not narrower than the reference's fp32"),
@@ -254,10 +254,8 @@ def set_precision(name, vis_override=None):
     from robir_amd import sg_render
     vis, mlp, dtype = PRECISIONS[name]
     vis = vis_override or vis
-    from robir_amd import ops
     sg_render.VIS_PRECISION = vis
     os.environ["ROBIR_MLP_PRECISION"] = mlp
-    ops.SDF_X6 = name == "exact" and os.environ.get("ROBIR_SDF_X6", "1") == "1"     # fp32-mfma: every MLP on the f32-input MFMA
     return vis, mlp, dtype
 
 

@@ -146,6 +146,8 @@ int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, in
 /* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
 int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
+/* The visibility MLP on exact three-piece operands (csrc/vis_x6.hip; Wp = packing.pack_vis_x6): the arguments of rb_vis_mlp_points. */
+int rb_vis_x6_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);

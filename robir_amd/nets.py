@@ -103,7 +103,7 @@ def _dev(module):
 
 
 # ----------------------------------------------------------------------------------------- visibility
-from .precision import mlp_precision  # noqa: E402,F401  ('fp32' under the default policy, 'f16x3' under ROBIR_PRECISION=split)
+from .precision import mlp_precision  # noqa: E402,F401  ('f16x6' under the default policy, 'f16x3' under ROBIR_PRECISION=split)
 
 
 class VisNetwork(nn.Module):
@@ -131,13 +131,16 @@ class VisNetwork(nn.Module):
     def packed_full_h3(self):
         return self._packed.get("full_h3", self, lambda sd: packing.pack_vis_h3(self._rename(sd), _dev(self)))
 
+    def packed_full_x6(self):
+        return self._packed.get("full_x6", self, lambda sd: packing.pack_vis_x6(self._rename(sd), _dev(self)))
+
     def packed_split(self):
         return self._packed.get("split", self, lambda sd: packing.pack_vis_split(self._rename(sd), _dev(self)))
 
     def logits_from_features(self, X):
         """X [M,128] = [PE10(p) | PE10(d)] (ops.feat_vis) -> logits [M,2]; arithmetic per robir_amd.MLP_PRECISION."""
         forward_only_guard(self)
-        if mlp_precision() == "fp32":
+        if mlp_precision() != "f16x3":          # feature rows: the f32-input MFMA kernel under 'fp32' and 'f16x6' alike
             return ops.vis_mlp(X, self.packed_full())
         return ops.vis_mlp_h3(X, self.packed_full_h3(), packing.H3_SCALE_LOG2)
 
@@ -147,7 +150,9 @@ class VisNetwork(nn.Module):
         forward_only_guard(self)
         if not ops.SDF_FUSED_PE:
             return self.logits_from_features(ops.feat_vis(points.float().contiguous(), dirs.float().contiguous(), rep=rep))
-        if mlp_precision() == "fp32":
+        if mlp_precision() == "f16x6":      # exact three-piece operands (csrc/vis_x6.hip)
+            return ops.vis_x6_points(points, dirs, self.packed_full_x6(), rep)
+        if mlp_precision() != "f16x3":
             return ops.vis_mlp_points(points, dirs, self.packed_full(), rep)
         return ops.vis_mlp_points(points, dirs, self.packed_full_h3(), rep, packing.H3_SCALE_LOG2)
 
@@ -499,16 +504,17 @@ class SDFNetwork(nn.Module):
             # values once + one row vector back through the transposed layers, instead of three tangent rows per point
             return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
                                       out_scale)
-        if (grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
-                and M >= (1 if ops.SDF_X6 else ops.SDF_GRAD_F32_MIN_POINTS)):      # exact operands: three launches of 0.07 ms beat 0.31
+        x6 = mlp_precision() == "f16x6"
+        if (grad and not precise and mlp_precision() in ("fp32", "f16x6") and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
+                and M >= (1 if x6 else ops.SDF_GRAD_F32_MIN_POINTS)):      # exact operands: three launches of 0.07 ms beat 0.31
             # the same at the reference's precision: value pass on exact three-piece operands (or the f32-input MFMA) + one pass over
             # the transposed layers on the f32-input MFMA
-            if ops.SDF_X6:
+            if x6:
                 out, g = ops.sdf_value_grad_x6(x, M, self.packed_x6(True), self.packed_back_x6(), in_scale, out_scale)
             else:
                 out, g = ops.sdf_value_grad_f32(x, M, self.packed(True), self.packed_back(), in_scale, out_scale)
             return (out if full else out[:, 0].contiguous()), g
-        if not grad and not precise and mlp_precision() == "fp32" and ops.SDF_FUSED_PE and ops.SDF_X6:
+        if not grad and not precise and x6 and ops.SDF_FUSED_PE:
             return ops.sdf_points_x6(x, M, self.packed_x6(full), full, in_scale, out_scale), None
         if (not grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE
                 and ops.sdf_ring_waves() == 8):
@@ -517,7 +523,7 @@ class SDFNetwork(nn.Module):
         if grad and not precise and mlp_precision() == "f16x3" and ops.SDF_KERNEL == "ring" and ops.SDF_FUSED_PE:
             return ops.sdf_points_jvp_h3(x, M, self.packed_h3(full), full, packing.H3_SCALE_LOG2, in_scale, out_scale,
                                          out_scale * in_scale)
-        if ops.SDF_FUSED_PE and (precise or mlp_precision() == "fp32"):
+        if ops.SDF_FUSED_PE and (precise or mlp_precision() in ("fp32", "f16x6")):
             # f32-input MFMA kernel with the encoding (tangent rows included) evaluated inside it
             return ops.sdf_mlp_points(x, M, self.packed(full), mode, in_scale, out_scale, out_scale * in_scale)
         X = ops.feat_pe10(x, scale=in_scale, jvp=grad)
@@ -605,7 +611,7 @@ class RenderingNetwork(nn.Module):
             fn = ops.color_mlp_h3_points if ops.SDF_FUSED_PE else ops.color_mlp_h3_two      # encoding inside the kernel | tail rows
             return fn(points, view_dirs, normals, feature_vectors, self.packed_h3(), packing.H3_SCALE_LOG2,
                       x_scale=x_scale, feat_scale=feat_scale)
-        if ops.SDF_FUSED_PE and ops.SDF_X6:
+        if ops.SDF_FUSED_PE and mlp_precision() == "f16x6":
             return ops.color_x6_points(points, view_dirs, normals, feature_vectors, self.packed_x6(), x_scale=x_scale,
                                        feat_scale=feat_scale)
         if ops.SDF_FUSED_PE:

@@ -133,6 +133,16 @@ def vis_mlp_points(p, d, blob, rep=1, scale_log2=None):
     return Y
 
 
+def vis_x6_points(p, d, blob, rep=1):
+    """vis_mlp_points on exact three-piece operands (csrc/vis_x6.hip; blob = packing.pack_vis_x6)."""
+    p, d = _f32(p), _f32(d)
+    M = d.shape[0]
+    assert p.shape[0] * rep == M
+    Y = torch.empty(M, 2, dtype=torch.float32, device=d.device)
+    call("rb_vis_x6_points", ptr(p), ptr(d), c_long(M), c_int(rep), ptr(blob), ptr(Y), c_int(0), stream_ptr())
+    return Y
+
+
 def linear_pe10_256(x, blob):
     """linear_64_256(feat_pe10(x)) with the encoding fused."""
     x = _f32(x)
@@ -257,7 +267,6 @@ def sdf_points_jvp_h3(x, M, blob, full, scale_log2, in_scale=1.0, out_scale=1.0,
 
 SDF_GRAD = _os.environ.get("ROBIR_SDF_GRAD", "reverse")     # "reverse" (csrc/sdf_back.hip) | "forward" (mode 3 rows)
 SDF_GRAD_MIN_POINTS = 16384       # below this the three-launch reverse form does not pay (0.25 ms floor; measured crossover)
-SDF_X6 = _os.environ.get("ROBIR_SDF_X6", "1") == "1"    # exact policy: SDF value passes on exact three-piece operands (csrc/sdf_x6.hip)
 SDF_GRAD_F32_MIN_POINTS = 16384   # ... of the f32-input-MFMA form (three launches against one of the four-row forward-mode kernel)
 SDF_GRAD_SLAB = 1 << 20           # points per slab of the reverse form (8.5 KB of scratch per point)
 _sdf_grad_scratch = {}

@@ -129,6 +129,16 @@ def pack_vis_h3(sd, device):
     return pack_layers_h3(ls, device)
 
 
+def pack_vis_x6(sd, device):
+    """The five layers with every weight as three halves, scale 2^0 (rb_vis_x6_points, csrc/vis_x6.hip)."""
+    ls = []
+    for i in range(5):
+        W, b = _t(sd, VIS + "%d.weight" % (2 * i)), _t(sd, VIS + "%d.bias" % (2 * i))
+        ls.append(dict(W=W, b=b, n_pad=_pad16(W.shape[0]), k_pad=(W.shape[1] + 31) // 32 * 32))
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)])
+
+
 def pack_vis_split(sd, device):
     """First visibility layer split into its point half (with bias) and direction half (no bias), each 64->256,
     plus the hidden stack [256->256 x3] and the 2x256 output layer kept in plain row-major form."""

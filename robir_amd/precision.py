@@ -3,8 +3,9 @@
   ROBIR_PRECISION=exact  (default)  not narrower than the reference's fp32: the fused light-visibility kernel carries every
                                     fp32 operand exactly as three f16 pieces (six f16 MFMA products per multiply-add, three fp32
                                     accumulators: csrc/vis_diffuse_x6.hip), and so do the SDF network (values and reverse-mode
-                                    gradient) and the colour network (csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip;
-                                    ROBIR_SDF_X6=0 puts them back on the f32-input MFMA); the other MLPs run on the f32-input MFMA;
+                                    gradient), the colour network and the stand-alone visibility MLP (MLP mode "f16x6":
+                                    csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip, vis_x6.hip); the other MLPs run on the f32-input
+                                    MFMA.  ROBIR_MLP_PRECISION=fp32 puts every stand-alone MLP on the f32-input MFMA;
   ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
                                     2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
                                     guarded by the activation-range sentinel (ops.range_check).
@@ -12,7 +13,7 @@ ROBIR_VIS_PRECISION / ROBIR_MLP_PRECISION override the two halves of the policy 
 """
 import os
 
-POLICIES = {"exact": ("f16x6", "fp32"), "split": ("f16x3-auto", "f16x3")}
+POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3")}
 VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3")
 
 
@@ -24,11 +25,12 @@ def policy():
 
 
 def mlp_precision():
-    """Arithmetic of the stand-alone MLP kernels (SDF, colour, visibility, 512-wide nets): 'fp32' (f32-input MFMA) or
+    """Arithmetic of the stand-alone MLP kernels (SDF, colour, visibility, 512-wide nets): 'f16x6' (exact three-piece operands where
+    such a kernel exists -- SDF, colour, visibility MLP -- and the f32-input MFMA elsewhere), 'fp32' (f32-input MFMA everywhere) or
     'f16x3' (split precision)."""
     p = os.environ.get("ROBIR_MLP_PRECISION") or POLICIES[policy()][1]
-    if p not in ("f16x3", "fp32"):
-        raise ValueError("ROBIR_MLP_PRECISION must be f16x3 or fp32")
+    if p not in ("f16x3", "fp32", "f16x6"):
+        raise ValueError("ROBIR_MLP_PRECISION must be f16x6, fp32 or f16x3")
     return p
 
 

@@ -75,7 +75,7 @@ def test_mlp_precision_switch(monkeypatch):
     monkeypatch.delenv("ROBIR_MLP_PRECISION", raising=False)
     monkeypatch.delenv("ROBIR_VIS_PRECISION", raising=False)
     monkeypatch.delenv("ROBIR_PRECISION", raising=False)
-    assert nets.mlp_precision() == "fp32" and precision.vis_precision() == "f16x6"     # default policy: not narrower than fp32
+    assert nets.mlp_precision() == "f16x6" and precision.vis_precision() == "f16x6"     # default policy: not narrower than fp32
     monkeypatch.setenv("ROBIR_PRECISION", "split")
     assert nets.mlp_precision() == "f16x3" and precision.vis_precision() == "f16x3-auto"
     monkeypatch.setenv("ROBIR_MLP_PRECISION", "fp32")

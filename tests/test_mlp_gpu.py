@@ -707,3 +707,19 @@ def test_color_exact_operand_kernel(dev, synth_weights):
         assert float((a - ref).abs().max()) <= 2e-6, (n, float((a - ref).abs().max()))
         assert torch.equal(a, ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0)), n
     ops.range_check(sync=True)
+
+
+def test_vis_exact_operand_kernel(dev, synth_weights):
+    """k_vis_x6 (csrc/vis_x6.hip) against the f32-input-MFMA visibility MLP on the same points and directions: ragged sizes, several
+    directions per point, many rounds, run to run."""
+    from robir_amd import ops, packing
+    g = torch.Generator().manual_seed(101)
+    b32, x6 = packing.pack_vis(synth_weights, dev), packing.pack_vis_x6(synth_weights, dev)
+    for n, rep in ((1, 1), (17, 8), (130, 8), (5000, 1), (40001, 8)):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(n * rep, 3, generator=g), dim=-1).to(dev)
+        ref = ops.vis_mlp_points(p, d, b32, rep)
+        a = ops.vis_x6_points(p, d, x6, rep)
+        assert float((a - ref).abs().max()) <= 5e-6, (n, rep, float((a - ref).abs().max()))     # logits of O(1): fp32 rounding of either sum
+        assert torch.equal(a, ops.vis_x6_points(p, d, x6, rep)), (n, rep)
+    ops.range_check(sync=True)

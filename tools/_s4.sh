@@ -1,6 +1,4 @@
-export AB_PRECISION=f16x6
-for r in 1 2; do
-python tools/ab_dvis.py blk robir_amd/librobir_hip.so 64 2>&1 | tail -2
-python tools/ab_dvis.py single robir_amd/librobir_hip_x6single.so 64 2>&1 | tail -2
-done
-python tools/ab_dvis.py compare blk single
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep "^FAILED\|passed\|failed" | cut -c1-200
+ROBIR_PRECISION=split timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep "^FAILED\|passed\|failed" | cut -c1-200
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac']); print({k:(v['value'],v['ms_per_step']) for k,v in d['legs'].items()}); print([(e['config'], round(e['ms'],1)) for e in d['configs']['exact']], [(e['config'], round(e['ms'],1)) for e in d['configs']['split']])"

@@ -121,7 +121,7 @@ def config1(model, reps=3):
     t = timed(lambda: neus.sdf_network(pts), reps, (SDF_TIMER,))
     return {"config": 1, "workload": "SDF network forward (PE + 9 layers, 257 outputs), 64x64 rays x 64 samples",
             "value": 4096 / t, "unit": "rays/s", "ms": t * 1e3, "points_per_s": pts.shape[0] / t,
-            "roofline": SDF_TIMER.roofline("SDF net (encoding + value rows)", nets.mlp_precision(), ops.SDF_X6)}
+            "roofline": SDF_TIMER.roofline("SDF net (encoding + value rows)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
 
 
 def config2(model, reps=2):
@@ -138,7 +138,7 @@ def config2(model, reps=2):
     # 112 SDF evaluations for the sampling + 128 x (SDF+features, gradient, colour) = 0.59 GFLOP per ray
     return {"config": 2, "workload": "render_neus 400x400, 64+64 samples/ray, 4 up-sampling steps, colour net (Norm stage)",
             "value": R / t, "unit": "rays/s", "ms": t * 1e3, "algorithmic_tflops": 0.59e9 * R / t / 1e12,
-            "roofline": SDF_TIMER.roofline("SDF net (encoding + value rows + reverse-mode gradient)", nets.mlp_precision(), ops.SDF_X6)}
+            "roofline": SDF_TIMER.roofline("SDF net (encoding + value rows + reverse-mode gradient)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
 
 
 def config3(model, reps=2):
@@ -156,7 +156,7 @@ def config3(model, reps=2):
     t = timed(illum, reps, (SDF_TIMER,))
     return {"config": 3, "workload": "800x800 forward('Illum') + trace_radiance(nsamp=8), every 1024-px chunk its own lock-step batch",
             "value": N / t, "unit": "primary rays/s", "ms": t * 1e3,
-            "roofline": SDF_TIMER.roofline("SDF net (borrow_color: value rows + reverse-mode gradient)", nets.mlp_precision(), ops.SDF_X6)}
+            "roofline": SDF_TIMER.roofline("SDF net (borrow_color: value rows + reverse-mode gradient)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
 
 
 def config5(model, reps=1, first=875, nch=125, trace=True):
