@@ -148,6 +148,10 @@ int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, co
                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
 /* The visibility MLP on exact three-piece operands (csrc/vis_x6.hip; Wp = packing.pack_vis_x6): the arguments of rb_vis_mlp_points. */
 int rb_vis_x6_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, int n_workgroups, rb_stream_t stream);
+/* The 512-wide ReLU nets (SparseAE encoder: raw latent [M,32]; indirect-illumination decoder: raw SG outputs [M,144]) on exact
+ * three-piece operands (csrc/wide_x6.hip; Wp = packing.pack_wide_x6): the arguments of rb_wide_mlp_points. */
+int rb_wide_x6_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, int n_workgroups, rb_stream_t stream);
+int rb_wide_x6(const float* X /* feature rows [M,64] */, long M, const float* Wp, int encoder, float* Y, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);

@@ -200,6 +200,10 @@ class SparseAE(nn.Module):
             blob = self._packed.get("enc_h3", self, lambda sd: packing.pack_sparse_ae_encoder_h3(
                 {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
             return ops.wide_mlp_h3(X, blob, True, packing.H3_SCALE_LOG2)
+        if mlp_precision() == "f16x6":      # exact three-piece operands (csrc/wide_x6.hip)
+            blob = self._packed.get("enc_x6", self, lambda sd: packing.pack_sparse_ae_encoder_x6(
+                {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
+            return ops.wide_x6(X, blob, True)
         return ops.ae_encode(X, self._blobs()[0])
 
     def _encode_points(self, pts):
@@ -210,6 +214,10 @@ class SparseAE(nn.Module):
             blob = self._packed.get("enc_h3", self, lambda sd: packing.pack_sparse_ae_encoder_h3(
                 {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
             return ops.wide_mlp_points(pts, None, blob, True, packing.H3_SCALE_LOG2)
+        if mlp_precision() == "f16x6":      # exact three-piece operands (csrc/wide_x6.hip)
+            blob = self._packed.get("enc_x6", self, lambda sd: packing.pack_sparse_ae_encoder_x6(
+                {"ae." + k: v for k, v in sd.items()}, "ae", _dev(self)))
+            return ops.wide_x6_points(pts, None, blob, True)
         return ops.wide_mlp_points(pts, None, self._blobs()[0], True)
 
     def run_points(self, pts, noise):
@@ -321,6 +329,10 @@ class IndirctIllumNetwork(nn.Module):
                 if ops.SDF_FUSED_PE:        # [PE10(x) | hdr_shift] encoded inside the lobe net's kernel
                     return ops.illum_decode(ops.wide_mlp_points(points, hdr, blob3, False, packing.H3_SCALE_LOG2))
                 return ops.illum_decode(ops.wide_mlp_h3(X, blob3, False, packing.H3_SCALE_LOG2))
+            if ops.SDF_FUSED_PE and mlp_precision() == "f16x6":      # exact three-piece operands (csrc/wide_x6.hip)
+                blob6 = self._packed.get("lobe_x6", self.lobe_layer, lambda sd: packing.pack_illum_x6(
+                    {"indirect_illum_network.lobe_layer." + k: v for k, v in sd.items()}, dev))
+                return ops.illum_decode(ops.wide_x6_points(points, hdr, blob6, False))
             if ops.SDF_FUSED_PE:
                 return ops.illum_decode(ops.wide_mlp_points(points, hdr, blob, False))
             return ops.illum_decode(ops.illum_mlp(X, blob))

@@ -143,6 +143,26 @@ def vis_x6_points(p, d, blob, rep=1):
     return Y
 
 
+def wide_x6_points(x, extra, blob, encoder):
+    """wide_mlp_points on exact three-piece operands (csrc/wide_x6.hip; blob = packing.pack_wide_x6 / pack_illum_x6 / ..._encoder_x6)."""
+    x = _f32(x)
+    M = x.shape[0]
+    e = _f32(extra).reshape(-1) if extra is not None else None
+    Y = torch.empty(M, 32 if encoder else 144, dtype=torch.float32, device=x.device)
+    if M > 0:
+        call("rb_wide_x6_points", ptr(x), ptr(e), c_long(M), ptr(blob), c_int(1 if encoder else 0), ptr(Y), c_int(0), stream_ptr())
+    return Y
+
+
+def wide_x6(X, blob, encoder):
+    """wide_x6_points on feature rows X [M,64]."""
+    M = X.shape[0]
+    Y = torch.empty(M, 32 if encoder else 144, dtype=torch.float32, device=X.device)
+    if M > 0:
+        call("rb_wide_x6", ptr(X), c_long(M), ptr(blob), c_int(1 if encoder else 0), ptr(Y), c_int(0), stream_ptr())
+    return Y
+
+
 def linear_pe10_256(x, blob):
     """linear_64_256(feat_pe10(x)) with the encoding fused."""
     x = _f32(x)

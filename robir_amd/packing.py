@@ -332,6 +332,24 @@ def pack_sparse_ae_encoder_h3(sd, prefix, device):
     return pack_layers_h3(enc, device)
 
 
+def pack_wide_x6(layers, device):
+    """Five layers [64->512, 512->512 x3, 512->32 | 144] (dicts W, b) with every weight as three halves, scale 2^0 (rb_wide_x6_points,
+    csrc/wide_x6.hip)."""
+    ls = [dict(W=l["W"], b=l["b"], n_pad=_pad16(l["W"].shape[0]), k_pad=_pad32(l["W"].shape[1])) for l in layers]
+    assert [l["k_pad"] for l in ls] == [64, 512, 512, 512, 512] and ls[0]["n_pad"] == 512
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)])
+
+
+def pack_sparse_ae_encoder_x6(sd, prefix, device):
+    return pack_wide_x6([dict(W=_t(sd, prefix + ".brdf_encoder_layer.%d.weight" % (2 * i)), b=_t(sd, prefix + ".brdf_encoder_layer.%d.bias" % (2 * i)))
+                         for i in range(5)], device)
+
+
+def pack_illum_x6(sd, device):
+    return pack_wide_x6([dict(W=_t(sd, ILL + "lobe_layer.%d.weight" % (2 * i)), b=_t(sd, ILL + "lobe_layer.%d.bias" % (2 * i))) for i in range(5)], device)
+
+
 def pack_sparse_ae(sd, prefix, device):
     """-> (encoder blob [64->512, 512->512 x3, 512->32], decoder blob [32->128, 128->128, 128->16])."""
     enc, dec = [], []

@@ -723,3 +723,26 @@ def test_vis_exact_operand_kernel(dev, synth_weights):
         assert float((a - ref).abs().max()) <= 5e-6, (n, rep, float((a - ref).abs().max()))     # logits of O(1): fp32 rounding of either sum
         assert torch.equal(a, ops.vis_x6_points(p, d, x6, rep)), (n, rep)
     ops.range_check(sync=True)
+
+
+def test_wide_exact_operand_kernels(dev, synth_weights):
+    """k_wide_x6 (csrc/wide_x6.hip: half-chunk stream of the 512-wide nets) against the f32-input-MFMA kernels on the same points: the
+    SparseAE encoder and the indirect-illumination decoder, ragged sizes, many rounds, run to run."""
+    from robir_amd import ops, packing
+    g = torch.Generator().manual_seed(103)
+    ill32, ill6 = packing.pack_illum(synth_weights, dev), packing.pack_illum_x6(synth_weights, dev)
+    pre = "envmap_material_network.spec_brdf_encoder_layer"
+    enc32, _ = packing.pack_sparse_ae(synth_weights, pre, dev)
+    enc6 = packing.pack_sparse_ae_encoder_x6(synth_weights, pre, dev)
+    for n in (1, 15, 64, 65, 940, 40001):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        hdr = torch.rand(n, 1, generator=g).to(dev)
+        for ref, got in ((ops.wide_mlp_points(p, hdr, ill32, False), lambda: ops.wide_x6_points(p, hdr, ill6, False)),
+                         (ops.wide_mlp_points(p, None, enc32, True), lambda: ops.wide_x6_points(p, None, enc6, True))):
+            a = got()
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((a - ref).abs().max()) <= 5e-6 * scale, (n, float((a - ref).abs().max()), scale)
+            assert torch.equal(a, got()), n
+        Xp = ops.feat_pe10(p)
+        assert torch.equal(ops.wide_x6(Xp, enc6, True), ops.wide_x6_points(p, None, enc6, True)), n      # the row form: same bits
+    ops.range_check(sync=True)
