@@ -483,12 +483,18 @@ def main():
             ok = torch.isfinite(ref_img).all(-1) & torch.isfinite(img).all(-1)
             a, b = img[ok], ref_img[ok]
             rel = (a - b).abs() / (b.abs() + b.abs().mean(0, keepdim=True))
-            d = {"max_rel_diff": float(rel.max()), "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
+            flat = rel.flatten().float()
+            flat = flat[torch.isfinite(flat)]
+            q = torch.quantile(flat[:: max(1, flat.numel() // 4_000_000)], torch.tensor([0.5, 0.999], device=flat.device)) if flat.numel() else torch.zeros(2)
+            d = {"max_rel_diff": float(rel.max()), "median_rel_diff": float(q[0]), "p99.9_rel_diff": float(q[1]),
+                 "frac_entries_beyond_1e-4": float((rel > 1e-4).float().mean()),
                  "frac_entries_beyond_1e-5": float((rel > 1e-5).float().mean()), "rays_beyond_1e-3": int((rel > 1e-3).any(-1).sum())}
             (legs[name] if name in legs else line.setdefault("headline_image", {}))["distance_from_fp32_mfma_image"] = d
         line["legs"] = legs
-        line["legs_note"] = ("same view, same draws; outliers beyond 1e-3 are rays on which a sampled direction sits on the "
-                             "n.d > 1e-6 cull (tests/test_precision_gpu.py anchors the modes on a float64 evaluation)")
+        line["legs_note"] = ("same view, same draws; two fp32-accurate evaluations round differently (the exact-operand kernels are not "
+                             "bitwise the f32-input MFMA's sums), so the entries beyond 1e-4 are rays on which a threshold decision -- "
+                             "a sampled direction on the n.d > 1e-6 cull, a hit mask -- flips within that rounding; the median and the "
+                             "99.9th percentile show the arithmetic (tests/test_precision_gpu.py anchors the modes on a float64 evaluation)")
     if world == 1 and not args.no_legs and args.vis == "mlp":
         # The other synthetic scene at the headline precision (2 steps): hit fraction, visibility pairs per hit ray and rate
         other = "nonconvex" if args.scene == "sphere" else "sphere"
