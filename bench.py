@@ -50,9 +50,9 @@ CHUNK = 1024
 PRECISIONS = {
     # name: (light-visibility kernel, stand-alone MLP kernels, dtype string of the JSON line)
     "exact": ("f16x6", "f16x6",
-              "f32 (light-visibility MLP, SDF net (values and reverse-mode gradient) and colour net: every fp32 operand exact as three "
-              "f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the other MLPs on the f32-input MFMA) "
-              "-- not narrower than the reference's fp32"),
+              "f32 (every MLP -- light visibility, SDF values and reverse-mode gradient, colour, visibility, 512-wide and CESR nets: every "
+              "fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the 32 -> 128 "
+              "-> 16 auto-encoder decoders on the f32-input MFMA) -- not narrower than the reference's fp32"),
     "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
     "split": ("f16x3-auto", "f16x3", "f32 operands as 22-bit f16 hi/lo pairs, 3 f16 MFMA products per multiply-add, fp32 accumulate "
                                      "(parity-tested throughput mode; NARROWER than fp32)"),

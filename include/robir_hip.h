@@ -152,6 +152,9 @@ int rb_vis_x6_points(const float* p, const float* d, long M, int rep, const floa
  * three-piece operands (csrc/wide_x6.hip; Wp = packing.pack_wide_x6): the arguments of rb_wide_mlp_points. */
 int rb_wide_x6_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, int n_workgroups, rb_stream_t stream);
 int rb_wide_x6(const float* X /* feature rows [M,64] */, long M, const float* Wp, int encoder, float* Y, int n_workgroups, rb_stream_t stream);
+/* The CESR nets on exact three-piece operands (csrc/cesr_x6.hip; Wp = packing.pack_softplus512_x6): the arguments of rb_cesr_net_points
+ * (kind 0: normal_net on PE10(x), 2: shadow_net on (point, one-hot label) rows). */
+int rb_cesr_net_x6_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);

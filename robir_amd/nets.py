@@ -558,6 +558,10 @@ class SDFNetwork(nn.Module):
         forward_only_guard(self)
         if mlp_precision() == "f16x3":
             return ops.cesr_net_points(pts, M, kind, self.packed_w512_h3(), n_label, packing.H3_SCALE_LOG2)
+        if mlp_precision() == "f16x6":      # exact three-piece operands (csrc/cesr_x6.hip)
+            blob = self._packed.get("w512_x6", self, lambda sd: packing.pack_softplus512_x6(
+                {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
+            return ops.cesr_net_x6_points(pts, M, kind, blob, n_label)
         return ops.cesr_net_points(pts, M, kind, self.packed(), n_label)
 
     def eval_point_labels(self, Xp, n_label=128):

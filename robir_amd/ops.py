@@ -923,6 +923,15 @@ def scatter_rows(srcs, dst_widths, idx, N, fill=1.0):
     return outs
 
 
+def cesr_net_x6_points(x, M, kind, blob, n_label=1):
+    """cesr_net_points on exact three-piece operands (csrc/cesr_x6.hip; blob = packing.pack_softplus512_x6)."""
+    x = _f32(x)
+    Y = torch.empty(M, 3 if kind == 0 else 2, dtype=torch.float32, device=x.device)
+    if M > 0:
+        call("rb_cesr_net_x6_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), c_int(0), stream_ptr())
+    return Y
+
+
 def material_decode(brdf, brdf_r):
     brdf, brdf_r = _f32(brdf), _f32(brdf_r)
     n, dev = brdf.shape[0], brdf.device

@@ -384,6 +384,27 @@ def pack_softplus512(sd, prefix, k_in, device):
     return pack_layers(ls, device)
 
 
+def pack_softplus512_x6(sd, prefix, k_in, device):
+    """pack_softplus512 with every weight as three halves, scale 2^0 (rb_cesr_net_x6_points, csrc/cesr_x6.hip): the skip layer padded to
+    576 slots = [lin3 part | input part | 48 zero slots] (two half-chunks of K = 288)."""
+    sdt = {k: _t(sd, k) for k in sd if k.startswith(prefix)}
+    k0p = _pad16(k_in)
+    n3 = 512 - k_in
+    n3p = _pad16(n3)
+    assert n3p + k0p == 528 and k0p % 32 == 0
+    ls = []
+    for l in range(9):
+        W = _fold_wn(sdt, prefix + "lin%d." % l)
+        b = sdt[prefix + "lin%d.bias" % l].float()
+        n_pad, k_pad, perm = _pad16(W.shape[0]), _pad32(W.shape[1]), None
+        if l == 4:
+            k_pad = 576
+            perm = ([k if k < n3 else -1 for k in range(n3p)] + [n3 + j if j < k_in else -1 for j in range(k0p)] + [-1] * 48)
+        ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
+    blob = pack_layers_x6(ls, device, scale_log2=0)
+    return torch.cat([blob, torch.zeros(2048, device=device)])
+
+
 def pack_softplus512_h3(sd, prefix, k_in, device):
     """pack_softplus512 in split-precision form (rb_cesr_net_h3): the skip layer padded to 544 slots."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(prefix)}

@@ -746,3 +746,31 @@ def test_wide_exact_operand_kernels(dev, synth_weights):
         Xp = ops.feat_pe10(p)
         assert torch.equal(ops.wide_x6(Xp, enc6, True), ops.wide_x6_points(p, None, enc6, True)), n      # the row form: same bits
     ops.range_check(sync=True)
+
+
+def test_cesr_exact_operand_kernels(dev):
+    """k_cesr_x6 (csrc/cesr_x6.hip) against the f32-input-MFMA CESR kernels on the same points: normal_net, and shadow_net over one-hot
+    labels -- ragged sizes, several label counts, many rounds, run to run."""
+    from robir_amd import ops, packing, synth
+    c = synth.synth_cesr_nets(0)
+    g = torch.Generator().manual_seed(107)
+    sh = {"net." + k: v for k, v in c["shadow_net"].items()}
+    no = {"net." + k: v for k, v in c["normal_net"].items()}
+    sh32, sh6 = packing.pack_softplus512(sh, "net.", 191, dev), packing.pack_softplus512_x6(sh, "net.", 191, dev)
+    no32, no6 = packing.pack_softplus512(no, "net.", 63, dev), packing.pack_softplus512_x6(no, "net.", 63, dev)
+    for n in (1, 15, 64, 65, 1000, 40001):
+        p = ((torch.rand(n, 3, generator=g) - 0.5) * 0.6).to(dev)
+        ref = ops.cesr_net_points(p, n, 0, no32)
+        a = ops.cesr_net_x6_points(p, n, 0, no6)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((a - ref).abs().max()) <= 5e-6 * scale, ("normal_net", n, float((a - ref).abs().max()), scale)
+        assert torch.equal(a, ops.cesr_net_x6_points(p, n, 0, no6)), n
+        for nl in ((128,) if n > 1000 else (1, 3, 128)):
+            if n * nl > 600000:
+                continue
+            ref = ops.cesr_net_points(p, n * nl, 2, sh32, nl)
+            a = ops.cesr_net_x6_points(p, n * nl, 2, sh6, nl)
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((a - ref).abs().max()) <= 5e-6 * scale, ("shadow_net", n, nl, float((a - ref).abs().max()), scale)
+            assert torch.equal(a, ops.cesr_net_x6_points(p, n * nl, 2, sh6, nl)), (n, nl)
+    ops.range_check(sync=True)

@@ -1,3 +1,2 @@
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs 2>gpurun_out/e.txt | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['headline_image']); print({k:v.get('distance_from_fp32_mfma_image') for k,v in d['legs'].items()})"
-tail -3 gpurun_out/e.txt
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep "^FAILED\|passed\|failed" | cut -c1-200
+python bench.py --config 5 --precision exact --steps 1 --config5-chunks 125 2>/dev/null | tail -1 | cut -c1-300

@@ -197,7 +197,7 @@ def config5(model, reps=1, first=875, nch=125, trace=True):
                                      + ("" if trace else " (no trace_radiance)"),
             "value": nch * 1024 / t, "unit": "rays/s", "ms": t * 1e3, "chunks": nch, "hit_rays": state["hits"],
             "hit_rays_per_s": state["hits"] / t,
-            "roofline": SHADOW_TIMER.roofline("shadow_net (512 x 8 softplus net over 128 one-hot labels)", nets.mlp_precision())}
+            "roofline": SHADOW_TIMER.roofline("shadow_net (512 x 8 softplus net over 128 one-hot labels)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
 
 
 CONFIGS = {1: config1, 2: config2, 3: config3, 5: config5}
