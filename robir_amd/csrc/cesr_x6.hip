@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     constexpr int LI = decltype(LI_tag)::value;
     constexpr int KU = Net::kunit(LI), KB = KU / 32, HV = Net::hv(LI), NU = Net::nunits(LI), UB = Net::ubase(LI);
     constexpr bool OUT = LI == 8, SKIPOUT = LI == 3;
-    constexpr int BS = 1, DB = KB >= 6 ? 2 : 1, D = BS * DB, NB = BS * (DB + 1);      // three fragment sets: the register file is full
+#ifndef QX_DB
+#define QX_DB 1              // fragment sets read ahead per k-block: 2 measured 1 % slower (and 66 instead of 42 spilled registers in the shadow_net instance)
+#endif
+    constexpr int BS = 1, DB = KB >= 6 ? QX_DB : 1, D = BS * DB, NB = BS * (DB + 1);      // three fragment sets: the register file is full
     constexpr int HB = KB / 2, NSTEP = NU * KB;
     static_assert(D + BS - 1 <= KB - HB, "reads of the next unit start after the barrier");
     SxAcc accs[2];
