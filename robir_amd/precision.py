@@ -3,9 +3,9 @@
   ROBIR_PRECISION=exact  (default)  not narrower than the reference's fp32: the fused light-visibility kernel carries every
                                     fp32 operand exactly as three f16 pieces (six f16 MFMA products per multiply-add, three fp32
                                     accumulators: csrc/vis_diffuse_x6.hip), and so do the SDF network (values and reverse-mode
-                                    gradient), the colour network and the stand-alone visibility MLP (MLP mode "f16x6":
-                                    csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip, vis_x6.hip); the other MLPs run on the f32-input
-                                    MFMA.  ROBIR_MLP_PRECISION=fp32 puts every stand-alone MLP on the f32-input MFMA;
+                                    gradient), the colour network, the stand-alone visibility MLP, the 512-wide nets and the CESR
+                                    nets (MLP mode "f16x6": csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip, vis_x6.hip, wide_x6.hip,
+                                    cesr_x6.hip); the small auto-encoder decoders run on the f32-input MFMA.  ROBIR_MLP_PRECISION=fp32 puts every stand-alone MLP on the f32-input MFMA;
   ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
                                     2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
                                     guarded by the activation-range sentinel (ops.range_check).
