@@ -22,6 +22,11 @@ namespace rb {
 
 constexpr int BX_SLOT_B = 24 * 1024 + 512;
 constexpr int BX_NCHUNK = 117;
+#ifndef BX_NSLOT
+#define BX_NSLOT 4                       // ring slots: copies run BX_NSLOT - 1 chunks ahead of the MFMAs (5: measured the same, 13.0-13.3 vs
+                                         // 13.0-13.5 ms per 2^20 points for value + gradient: the copies' latency is not what the waves wait for)
+#endif
+constexpr int BX_AH = BX_NSLOT - 1;
 __host__ __device__ constexpr int bx_K(int l) { return l == 4 ? 224 : 256; }
 __host__ __device__ constexpr int bx_nch(int l) { return l == 3 ? 17 : (l == 7 ? 4 : 16); }
 __host__ __device__ constexpr int bx_cbase(int l) {
@@ -57,8 +62,8 @@ static_assert(sx_np(224) == 7 && sx_np(256) == 7 && sx_units(224) == 3 && sx_uni
 __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ sig, long M, const f4* __restrict__ Wt,
                                                          const float* __restrict__ w8row, float* __restrict__ gfeat,
                                                          unsigned* __restrict__ range_word) {
-  __shared__ f4 ring[4 * BX_SLOT_B / 16];              // 98 KB
-  __shared__ f4 bias_ring[4 * 16];
+  __shared__ f4 ring[BX_NSLOT * BX_SLOT_B / 16];       // 98 / 123 KB
+  __shared__ f4 bias_ring[BX_NSLOT * 16];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long nrounds = (M + 63) >> 6;
@@ -69,8 +74,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
   const unsigned ring_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ring);
   const unsigned bias_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)bias_ring);
   const unsigned lane16 = (unsigned)lane * 16u, lane4 = (unsigned)lane * 4u;
-  unsigned slot_b[4] = {0u, (unsigned)BX_SLOT_B, 2u * BX_SLOT_B, 3u * BX_SLOT_B};
-  unsigned bslot_b[4] = {0u, 256u, 512u, 768u};
+  unsigned slot_b[BX_NSLOT], bslot_b[BX_NSLOT];
+#pragma unroll
+  for (int i = 0; i < BX_NSLOT; ++i) {
+    slot_b[i] = (unsigned)i * BX_SLOT_B;
+    bslot_b[i] = (unsigned)i * 256u;
+  }
   unsigned sat = 0u;
   u4 xh[8], xm[8], xl[8];              // operands of the current layer: three pieces, one tile
   u4 yh[8], ym[8], yl[8];              // ... of the next layer
@@ -117,12 +126,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
     f4 bnext = f4{0.f, 0.f, 0.f, 0.f};
     u4 wfh[NB], wfm[NB], wfl[NB];
     const f4* wl = Wt + bx_coff(cb);
-    const f4* wnext[3];
+    const f4* wnext[BX_AH];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) wnext[i] = Wt + bx_coff(cb + NCH + i);
+    for (int i = 0; i < BX_AH; ++i) wnext[i] = Wt + bx_coff(cb + NCH + i);
     asm volatile("" : "+s"(wl));
-    auto frag_of = [&](int c) { return reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + slot_b[c & 3]) + lane; };
-    auto bias_of = [&](int c) { return *(reinterpret_cast<const f4*>(reinterpret_cast<const char*>(bias_ring) + bslot_b[c & 3]) + g); };
+    auto frag_of = [&](int c) { return reinterpret_cast<const u4*>(reinterpret_cast<const char*>(ring) + slot_b[c % BX_NSLOT]) + lane; };
+    auto bias_of = [&](int c) { return *(reinterpret_cast<const f4*>(reinterpret_cast<const char*>(bias_ring) + bslot_b[c % BX_NSLOT]) + g); };
     auto zero_acc = [&](SxAcc& a, const f4& b) {
       a.c0 = b;
       a.c1 = f4{0.f, 0.f, 0.f, 0.f};
@@ -171,18 +180,19 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
       if (jb > 0) zero_acc(acc, bnext);
       constexpr int dummy2 = 0;
       (void)dummy2;
-      const int K3 = jb + 3 < NCH ? K : bx_K(bx_layer_of(CB + jb + 3));
-      const f4* src3 = jb + 3 < NCH ? wl + (long)(jb + 3) * sx_cf4(K) : wnext[jb + 3 - NCH < 3 ? jb + 3 - NCH : 0];
-      const int sl3 = (jb + 3) & 3;
+      const int K3 = jb + BX_AH < NCH ? K : bx_K(bx_layer_of(CB + jb + BX_AH));
+      const f4* src3 = jb + BX_AH < NCH ? wl + (long)(jb + BX_AH) * sx_cf4(K) : wnext[jb + BX_AH - NCH < BX_AH ? jb + BX_AH - NCH : 0];
+      const int sl3 = (jb + BX_AH) % BX_NSLOT;
       const unsigned dst3 = ring_b + slot_b[sl3], bdst3 = bias_b + bslot_b[sl3];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         const int st = jb * KB + kb;
         if (kb == HB) {   // chunk jb+1 must have landed: the copies of chunk jb+2 (7) -- and, in the layer's first two chunks, the
                           // younger gate loads -- may still be in flight
-          if (jb < 2 && NSIG == 16) sx_wait<23>();
-          else if (jb < 2 && NSIG == 13) sx_wait<20>();
-          else sx_wait<7>();
+          // in flight behind chunk jb+1: the copies of chunks jb+2 .. jb+BX_AH-1 (7 each)
+          if (jb < BX_AH - 1 && NSIG == 16) sx_wait<7 * (BX_AH - 2) + 16>();
+          else if (jb < BX_AH - 1 && NSIG == 13) sx_wait<7 * (BX_AH - 2) + 13>();
+          else sx_wait<7 * (BX_AH - 2)>();
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
           bnext = bias_of(jb + 1);
@@ -232,15 +242,15 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
       }
     }
     {   // slot 0 = the slot of the next layer's first chunk
-      constexpr int R = NCH & 3;
-      unsigned a[4], b[4];
+      constexpr int R = NCH % BX_NSLOT;
+      unsigned a[BX_NSLOT], b[BX_NSLOT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = slot_b[(i + R) & 3];
-        b[i] = bslot_b[(i + R) & 3];
+      for (int i = 0; i < BX_NSLOT; ++i) {
+        a[i] = slot_b[(i + R) % BX_NSLOT];
+        b[i] = bslot_b[(i + R) % BX_NSLOT];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < BX_NSLOT; ++i) {
         slot_b[i] = a[i];
         bslot_b[i] = b[i];
       }
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
 
   // ---- prologue: chunks 0, 1, 2 of the stream
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < BX_AH; ++c)
 #pragma unroll
     for (int u = 0; u < 3; ++u)
       sx_copy_unit<256>(u, Wt + bx_coff(c), lane4, lane16, bias_b + bslot_b[c], ring_b + slot_b[c], wave);
