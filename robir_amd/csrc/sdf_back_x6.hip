@@ -193,7 +193,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
           if (jb < BX_AH - 1 && NSIG == 16) sx_wait<7 * (BX_AH - 2) + 16>();
           else if (jb < BX_AH - 1 && NSIG == 13) sx_wait<7 * (BX_AH - 2) + 13>();
           else sx_wait<7 * (BX_AH - 2)>();
+#ifndef BX_ABL_NOBAR                  // timing ablation (wrong results)
           __builtin_amdgcn_s_barrier();
+#endif
           asm volatile("" ::: "memory");
           bnext = bias_of(jb + 1);
         }
@@ -233,7 +235,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
         if (kb >= HB) {
 #pragma unroll
           for (int u = 0; u < 3; ++u)
+#ifdef BX_ABL_NODMA
+            if (false) {
+#else
             if ((u * (KB - HB)) / 3 == kb - HB) {
+#endif
               if (K3 == 224) sx_copy_unit<224>(u, src3, lane4, lane16, bdst3, dst3, wave);
               else sx_copy_unit<256>(u, src3, lane4, lane16, bdst3, dst3, wave);
             }
