@@ -15,12 +15,13 @@ def _f32(t):
     return t.contiguous()
 
 
-RANGE_FAMILIES = ("light-visibility kernel (rb_dvis_fused*)", "visibility MLP (rb_vis_mlp_h3)", "SDF MLP (rb_sdf_mlp_h3)",
-                  "colour MLP (rb_color_mlp_h3)", "512-wide nets (rb_wide_mlp_h3)", "CESR nets (rb_cesr_net_h3)")
+RANGE_FAMILIES = ("light-visibility kernel (rb_dvis_fused*)", "visibility MLP (rb_vis_mlp_h3 / rb_vis_x6_points)",
+                  "SDF MLP (rb_sdf_mlp_h3 / rb_sdf_x6_points / rb_sdf_value_grad*)", "colour MLP (rb_color_mlp_h3 / rb_color_x6_points)",
+                  "512-wide nets (rb_wide_mlp_h3 / rb_wide_x6*)", "CESR nets (rb_cesr_net_h3 / rb_cesr_net_x6_points)")
 
 
 def range_check(sync=False):
-    """Raise RobirHipError if a split-precision kernel saw an activation beyond the f16 range of its hi/lo operand pairs
+    """Raise RobirHipError if a split-precision or exact-operand kernel saw an activation beyond the f16 range of its leading operand piece
     (include/robir_hip.h: rb_range_check).  sync=False costs nothing and reports kernels that have completed; sync=True waits
     for the current stream first."""
     mask = ctypes.c_uint(0)
@@ -28,7 +29,7 @@ def range_check(sync=False):
     if mask.value:
         fams = [RANGE_FAMILIES[i] for i in range(len(RANGE_FAMILIES)) if mask.value >> i & 1]
         raise _lib.RobirHipError(
-            "split-precision (f16x3) arithmetic overflowed its activation range in: " + "; ".join(fams) + " -- the outputs of "
+            "f16-piece arithmetic (split precision f16x3 / exact operands f16x6) overflowed its activation range in: " + "; ".join(fams) + " -- the outputs of "
             "the call(s) since the last check are not fp32-accurate.  Select the exact f32-input MFMA kernels for this "
             "checkpoint: ROBIR_MLP_PRECISION=fp32 and ROBIR_VIS_PRECISION=fp32 (INTEGRATION.md, 'range limits')")
 

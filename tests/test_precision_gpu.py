@@ -186,6 +186,11 @@ def test_activation_range_sentinel(monkeypatch):
         ops.range_check(sync=True)
     assert "light-visibility" in str(ei.value) and "rb_vis_mlp_h3" in str(ei.value)
     ops.range_check(sync=True)                                       # reading clears the words
+    run(s_bad, "f16x6", "f16x6")                                     # the exact-operand kernels carry the same f16 range on their leading piece
+    with pytest.raises(_lib.RobirHipError, match="overflowed its activation range") as ei6:
+        ops.range_check(sync=True)
+    assert "light-visibility" in str(ei6.value) and "rb_vis_x6_points" in str(ei6.value)
+    ops.range_check(sync=True)
     logits, vis, ref_logits, ref_vis = run(s_bad, "fp32", "fp32")    # the remedy the message names
     ops.range_check(sync=True)
     e1, e2 = rel_err(logits, ref_logits), rel_err(vis, ref_vis)
