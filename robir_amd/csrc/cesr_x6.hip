@@ -343,18 +343,9 @@ extern "C" int rb_cesr_net_x6_points(const float* x, long M, int kind, int n_lab
                                      rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && Wp && Y, "null pointer");
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 63) / 64, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr;
   hipStream_t s = (hipStream_t)stream;
   switch (kind) {

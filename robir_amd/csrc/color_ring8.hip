@@ -294,18 +294,9 @@ extern "C" int rb_color_ring_points(const float* feat, long feat_stride, float f
                                     int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
-  const long rounds = (M + 127) / 128;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 127) / 128, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   hipLaunchKernelGGL(k_color_ring8, dim3(grid), dim3(512), 0, (hipStream_t)stream, feat, feat_stride, feat_scale, x, x_scale, view, normal,
                      M, (const f4*)Wp, ldexpf(1.0f, -scale_log2), rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
   return check_launch("k_color_ring8");

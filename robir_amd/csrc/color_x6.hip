@@ -283,18 +283,9 @@ extern "C" int rb_color_x6_points(const float* feat, long feat_stride, float fea
                                   const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 63) / 64, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   hipLaunchKernelGGL(k_color_x6, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, feat_stride, feat_scale, x, x_scale, view, normal, M,
                      (const f4*)Wp, rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
   return check_launch("k_color_x6");

@@ -10,6 +10,10 @@ namespace rb {
 char* err_buf();
 int fail(const char* what, const char* detail);
 int check_launch(const char* kernel);
+// compute units of the current device (cached per process; <= 0: the query failed) and the grid of a persistent kernel:
+// min(rounds, n_workgroups), n_workgroups <= 0 meaning one workgroup per compute unit
+int device_cus();
+int persistent_grid(long rounds, int n_workgroups);
 
 // ceil(n / per_block) workgroups.  A dispatch carries its grid size in work-items as a 32-bit number: workgroups x
 // workgroup size must stay below 2^32, beyond that the tail of the grid silently never runs (found by the full-size

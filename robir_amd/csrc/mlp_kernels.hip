@@ -9,6 +9,21 @@ namespace rb {
 
 static thread_local char g_err[512] = "";
 char* err_buf() { return g_err; }
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+int persistent_grid(long rounds, int n_workgroups) {
+  if (n_workgroups <= 0) n_workgroups = device_cus();
+  if (n_workgroups <= 0) return -1;
+  return (int)(rounds < n_workgroups ? rounds : n_workgroups);
+}
 
 // Range sentinel words (common.h): pinned host memory mapped into every device's address space, allocated once.
 static unsigned* g_range_host = nullptr;

@@ -314,15 +314,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
 
 // host-side launcher for sdf_back.hip (rb_sdf_value_grad_x6_points)
 int launch_sdf_back_x6(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s) {
-  const long rounds = (M + 63) / 64;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-    cus = prop.multiProcessorCount;
-  }
-  const unsigned grid = (unsigned)(rounds < cus ? rounds : cus);
+  const int pg = persistent_grid((M + 63) / 64, 0);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   hipLaunchKernelGGL(k_sdf_back_x6, dim3(grid), dim3(256), 0, s, (const f4*)sig, M, (const f4*)Wt, w8row, gfeat,
                      range_flags() ? range_flags() + RB_RANGE_SDF : nullptr);
   return check_launch("k_sdf_back_x6");

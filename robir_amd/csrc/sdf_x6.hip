@@ -356,20 +356,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
 using namespace rb;
 
 namespace {
-int sx_grid(long M, int n_workgroups) {
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  return (int)(rounds < n_workgroups ? rounds : n_workgroups);
-}
+int sx_grid(long M, int n_workgroups) { return persistent_grid((M + 63) / 64, n_workgroups); }
 int sx_launch(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, float* sig, int n_workgroups,
               hipStream_t s) {
   const int grid = sx_grid(M, n_workgroups);

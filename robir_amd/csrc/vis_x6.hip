@@ -237,18 +237,9 @@ extern "C" int rb_vis_x6_points(const float* p, const float* d, long M, int rep,
   if (M <= 0) return 0;
   RB_REQUIRE(p && d && Wp && logits, "null pointer");
   RB_REQUIRE(rep >= 1, "rep must be >= 1");
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 63) / 64, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   hipLaunchKernelGGL(k_vis_x6, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, d, rep, M, (const f4*)Wp, logits,
                      range_flags() ? range_flags() + RB_RANGE_VIS : nullptr);
   return check_launch("k_vis_x6");

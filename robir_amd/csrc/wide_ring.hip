@@ -4,20 +4,7 @@
 using namespace rb;
 
 namespace {
-int wr_grid(long M, int n_workgroups) {
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  return (int)(rounds < n_workgroups ? rounds : n_workgroups);
-}
+int wr_grid(long M, int n_workgroups) { return persistent_grid((M + 63) / 64, n_workgroups); }
 }  // namespace
 
 extern "C" {

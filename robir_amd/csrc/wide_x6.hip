@@ -272,14 +272,9 @@ using namespace rb;
 extern "C" int rb_wide_x6(const float* X, long M, const float* Wp, int encoder, float* Y, int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && Y, "null pointer");
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-    n_workgroups = prop.multiProcessorCount;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 63) / 64, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr;
   if (encoder) hipLaunchKernelGGL((k_wide_x6<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, M, (const f4*)Wp, Y, rw);
   else hipLaunchKernelGGL((k_wide_x6<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, X, (const float*)nullptr, M, (const f4*)Wp, Y, rw);
@@ -290,18 +285,9 @@ extern "C" int rb_wide_x6_points(const float* x, const float* extra, long M, con
                                  rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && Wp && Y, "null pointer");
-  const long rounds = (M + 63) / 64;
-  if (n_workgroups <= 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-      cus = prop.multiProcessorCount;
-    }
-    n_workgroups = cus;
-  }
-  const unsigned grid = (unsigned)(rounds < n_workgroups ? rounds : n_workgroups);
+  const int pg = persistent_grid((M + 63) / 64, n_workgroups);
+  if (pg <= 0) return rb::fail(__func__, "device query failed");
+  const unsigned grid = (unsigned)pg;
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_WIDE : nullptr;
   if (encoder) hipLaunchKernelGGL(k_wide_x6<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, extra, M, (const f4*)Wp, Y, rw);
   else hipLaunchKernelGGL(k_wide_x6<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, extra, M, (const f4*)Wp, Y, rw);
