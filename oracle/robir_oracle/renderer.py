@@ -191,10 +191,11 @@ def sphere_dirs(u1, u2):
     return torch.stack([s * torch.cos(t), s * torch.sin(t), u], -1)
 
 
-def trace_radiance(sd, tables_sec, fwd, nsamp, u1, u2):
+def trace_radiance(sd, tables_sec, fwd, nsamp, u1, u2, test_dir=None):
     """IDRNetwork.trace_radiance (implicit_differentiable_renderer.py:566-650).
     fwd: output of forward(..., 'Illum') (points, hdr_shift, network_object_mask, normals);
-    tables_sec: octree of the secondary tracer (max_iter = 32); u1,u2 [n*nsamp] uniform draws."""
+    tables_sec: octree of the secondary tracer (max_iter = 32); u1,u2 [n*nsamp] uniform draws; test_dir [3]: the debug option of
+    :594-595 (one given direction for every sample instead of the draws)."""
     points, shift, mask = fwd["points"], fwd["hdr_shift"], fwd["network_object_mask"]
     N = points.shape[0]
     out_rad = torch.zeros(N, nsamp, 3)
@@ -208,7 +209,7 @@ def trace_radiance(sd, tables_sec, fwd, nsamp, u1, u2):
     if n > 0:
         nr = fwd["normals"][mask][:, None, :]
         nr = nr / torch.clamp(nr.norm(dim=-1, keepdim=True), 1e-4)
-        sdirs = sphere_dirs(u1, u2).view(n, nsamp, 3)
+        sdirs = test_dir[None, None].expand(n, nsamp, 3) if test_dir is not None else sphere_dirs(u1, u2).view(n, nsamp, 3)
         back = (nr * sdirs).sum(-1) < 0
         sec_x, sec_hit, _ = octree_mod.trace(tables_sec, o + nr[:, 0] * 0.005, sdirs, 32)
         if sec_hit.any():

@@ -305,8 +305,6 @@ class IDRNetwork(nn.Module):
         calling trace_radiance once per 1024-pixel chunk (training/train_visibility.py); without it the call is ONE batch, like
         one reference call."""
         forward_only_guard(self)
-        if test_dir is not None:
-            raise NotImplementedError("test_dir (debug option) is not built")
         points, shift, mask = input["points"], input["hdr_shift"], input["network_object_mask"]
         dev = points.device
         N = points.shape[0]
@@ -321,11 +319,21 @@ class IDRNetwork(nn.Module):
         if n > 0:
             o = points[idx].contiguous()
             nr = input["normals"].detach()[idx].contiguous()
-            if draws is None:
-                u1, u2 = torch.rand(n * nsamp).to(dev), torch.rand(n * nsamp).to(dev)   # CPU generator, like the reference
+            if test_dir is not None:
+                # one given direction for every sample (implicit_differentiable_renderer.py:594-595): the quantities rb_sphere_dirs
+                # derives from its directions, from this one
+                nrm = nr / torch.clamp(nr.norm(dim=-1, keepdim=True), min=1e-4)
+                d = test_dir.to(dev).float().reshape(1, 3).expand(n * nsamp, 3).contiguous()
+                dots = (nrm[:, None, :] * d.view(n, nsamp, 3)).sum(-1)
+                back = (dots < 0).reshape(-1).to(torch.uint8).contiguous()
+                cosw = torch.relu(dots).reshape(-1).contiguous()
+                origins = (o + nrm * 0.005).contiguous()
             else:
-                u1, u2 = draws
-            d, back, cosw, origins = ops.sphere_dirs(u1.to(dev), u2.to(dev), nr, o, nsamp)
+                if draws is None:
+                    u1, u2 = torch.rand(n * nsamp).to(dev), torch.rand(n * nsamp).to(dev)   # CPU generator, like the reference
+                else:
+                    u1, u2 = draws
+                d, back, cosw, origins = ops.sphere_dirs(u1.to(dev), u2.to(dev), nr, o, nsamp)
             sdirs = d.reshape(n, nsamp, 3)
             with torch.no_grad():
                 if chunk is not None and N > chunk:

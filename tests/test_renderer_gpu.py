@@ -231,6 +231,17 @@ def test_trace_radiance_second_weight_set(dev):
     bounded("trace_radiance_second_ckpt/trace_radiance", out["trace_radiance"].cpu(), ref["trace_radiance"], 1e-3, 0.004)
     bounded("trace_radiance_second_ckpt/gt_integral", out["gt_integral"].cpu(), ref["gt_integral"], 1e-3, 0.01)
     assert float((out["indir_mask"].cpu() == ref["indir_mask"]).float().mean()) > 0.999
+    # test_dir (implicit_differentiable_renderer.py:594-595): one given direction for every sample
+    td = torch.nn.functional.normalize(torch.tensor([0.3, -0.5, 0.8]), dim=0)
+    out = m.trace_radiance(fwd, nsamp=4, test_dir=td)
+    ref = orend.trace_radiance(sd, T, {k: v.cpu() for k, v in fwd.items()}, 4, None, None, test_dir=td)
+    assert torch.equal(out["sample_dirs"].cpu(), ref["sample_dirs"].contiguous())
+    assert int((out["gt_vis"].cpu() != ref["gt_vis"]).sum()) <= 4
+    assert rel_err(out["pred_vis"].cpu(), ref["pred_vis"]) <= 1e-4
+    assert float((out["indir_mask"].cpu() == ref["indir_mask"]).float().mean()) > 0.999
+    both = (out["gt_vis"].cpu() == ref["gt_vis"])[..., 0].all(-1)
+    assert rel_err(out["trace_radiance"].cpu()[both], ref["trace_radiance"][both]) <= 2e-3
+    assert rel_err(out["gt_integral"].cpu()[both], ref["gt_integral"][both]) <= 2e-3
 
 
 def test_points_dirs_form_equals_uv_form(dev, model):
