@@ -18,8 +18,13 @@
 #include "x6_ring.h"
 #include <type_traits>
 
+#ifndef SX_PK
+#define SX_PK 0      // 1: the softplus stage on value pairs (v_pk_* f32): bit-identical, measured 1 % slower (profiles/r03_sdf_x6_ablation.md)
+#endif
+
 namespace rb {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int SX_SLOT_B = 27 * 1024 + 512;      // K = 288: 27 KB of fragments (+ slack: the slot's last copy may start 1 KB early)
 __host__ __device__ constexpr int sx_K(int l) { return l == 0 ? 64 : (l == 4 ? 288 : 256); }
 __host__ __device__ constexpr int sx_nch(int l, int last) { return l == 3 ? 13 : (l == 8 ? last : 16); }
@@ -142,6 +147,31 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     // hidden chunk pj in four stages (they go between the MFMA runs of the next chunk, one per run): A = softplus (+ its sigmoid in
     // MODE 5) of a value pair, B = exact three-way split into the next layer's operand registers
     float ev0[2], ev1[2];
+#if SX_PK
+    // the same arithmetic on value PAIRS: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 round like their scalar forms (bit-identical),
+    // the transcendentals and the selects stay per value
+    auto stage_a = [&](const SxAcc& a, int q, f4& sg) {
+      const f2 c0 = q ? f2{a.c0[2], a.c0[3]} : f2{a.c0[0], a.c0[1]};
+      const f2 c1 = q ? f2{a.c1[2], a.c1[3]} : f2{a.c1[0], a.c1[1]};
+      const f2 c2 = q ? f2{a.c2[2], a.c2[3]} : f2{a.c2[0], a.c2[1]};
+      const f2 k11 = f2{C11, C11};
+      const f2 z = __builtin_elementwise_fma(__builtin_elementwise_fma(c2, k11, c1), k11, c0);
+      const f2 t = z * SP_T_PER_Z;
+      const f2 e = f2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      const f2 u = e + 1.0f;
+      f2 sp = f2{__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])} * SP_LN2_OVER_100;
+      const bool lin0 = t[0] > SP_T_LINEAR, lin1 = t[1] > SP_T_LINEAR;
+      if constexpr (STORE) {
+        const f2 sgv = e * f2{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+        sg[2 * q] = lin0 ? 1.0f : sgv[0];
+        sg[2 * q + 1] = lin1 ? 1.0f : sgv[1];
+      }
+      f2 v = f2{lin0 ? z[0] : sp[0], lin1 ? z[1] : sp[1]};
+      if (SKIPOUT) v = v * inv_sqrt2;
+      ev0[q] = v[0];
+      ev1[q] = v[1];
+    };
+#else
     auto stage_a = [&](const SxAcc& a, int q, f4& sg) {
       float s0, s1;
       // log(1 + e) without the log1p correction (mlp_engine.h: an absolute error <= 4e-10 on the activation, below an fp32 sum's own rounding)
@@ -155,6 +185,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
       ev0[q] = v0;
       ev1[q] = v1;
     };
+#endif
     auto stage_b = [&](int pj, int q) { put_pair(ev0[q], ev1[q], yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q); };
     auto store_sig = [&](int pj, const f4& sg) {
       if constexpr (STORE) sig[((rrow >> 4) * 8 + lrt) * (16L * 64) + pj * 64 + lane] = sg;
@@ -173,7 +204,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     };
     zero_acc(accs[0], bias_of(0));
 #pragma unroll
+#ifdef SXA_NOREAD
+    for (int i = 0; i < NB; ++i)
+#else
     for (int i = 0; i < D; ++i)
+#endif
       if (i < NSTEP) {
         const u4* f = frag_of(i / KB) + (3 * (i % KB)) * 64;
         wfh[i % NB] = f[0];
@@ -200,10 +235,21 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
           if (allowed >= 8) sx_wait<8>();
           else if (allowed >= 7) sx_wait<7>();
           else sx_wait<3>();
+#ifndef SXA_NOBAR
           __builtin_amdgcn_s_barrier();
+#endif
           asm volatile("" ::: "memory");
           bnext = bias_of(jb + 1);
         }
+#ifdef SXA_NOREAD                     // no fragment reads: the registers are redefined behind the compiler's back (no instruction)
+        if (st % BS == 0) {
+#pragma unroll
+          for (int i = BS - 1; i >= 0; --i) {
+            const int s2 = st + D + i;
+            if (s2 < NSTEP) asm volatile("" : "+v"(wfl[s2 % NB]), "+v"(wfm[s2 % NB]), "+v"(wfh[s2 % NB]));
+          }
+        }
+#else
         if (st % BS == 0) {
 #pragma unroll
           for (int i = BS - 1; i >= 0; --i) {
@@ -216,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
             }
           }
         }
+#endif
         // the six products of BS k-blocks, a run per accumulator: class 2 (wl.xh, wm.xm, wh.xl), class 1 (wm.xh, wh.xm), class 0 (wh.xh)
         if (st % BS == BS - 1 || kb == KB - 1) {
           const int k0 = (st % BS == BS - 1) ? (kb - (BS - 1) > 0 ? kb - (BS - 1) : 0) : kb - (st % BS);
@@ -234,6 +281,20 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
           for (int k = k0; k <= kb; ++k) SX_MFMA(acc.c0, wfh[(jb * KB + k) % NB], xh[k]);
 #undef SX_MFMA
         }
+#ifdef SXA_NOEPI                      // timing ablations (wrong results): -DSXA_NOEPI / _NOREAD / _NODMA / _NOBAR
+        if (jb > 0 && kb == KB - 1) {         // the data dependence of the epilogue without its arithmetic
+          const SxAcc& pa = accs[(jb - 1) & 1];
+          const int pj = jb - 1;
+          if (OUT) output_chunk(pa, pj);
+          else
+            for (int q = 0; q < 2; ++q) {
+              const unsigned hv = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(pa.c0[2 * q] + pa.c1[2 * q], pa.c0[2 * q + 1] + pa.c2[2 * q + 1]));
+              yh[pj >> 1][(pj & 1) * 2 + q] = hv;
+              ym[pj >> 1][(pj & 1) * 2 + q] = hv;
+              yl[pj >> 1][(pj & 1) * 2 + q] = hv;
+            }
+        }
+#else
         if (jb > 0 && (st % BS == BS - 1 || kb == KB - 1)) {      // epilogue of chunk jb-1: a stage beside every MFMA run
           constexpr int dummy3 = 0;
           (void)dummy3;
@@ -258,6 +319,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
               }
             }
         }
+#endif
+#ifndef SXA_NODMA
         if (kb >= HB) {
 #pragma unroll
           for (int u = 0; u < 3; ++u)
@@ -267,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
               else sx_copy_unit<288>(u, src3, lane4, lane16, bdst3, dst3, wave);
             }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -288,11 +352,20 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     if constexpr (OUT) {
       output_chunk(last, NCH - 1);
     } else {
+#ifndef SXA_NOEPI
       stage_a(last, 0, sgp);
       stage_b(NCH - 1, 0);
       stage_a(last, 1, sgp);
       stage_b(NCH - 1, 1);
       store_sig(NCH - 1, sgp);
+#else
+      for (int q = 0; q < 2; ++q) {
+        const unsigned hv = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(last.c0[2 * q] + last.c1[2 * q], last.c0[2 * q + 1] + last.c2[2 * q + 1]));
+        yh[(NCH - 1) >> 1][((NCH - 1) & 1) * 2 + q] = hv;
+        ym[(NCH - 1) >> 1][((NCH - 1) & 1) * 2 + q] = hv;
+        yl[(NCH - 1) >> 1][((NCH - 1) & 1) * 2 + q] = hv;
+      }
+#endif
       if constexpr (SKIPOUT) {
 #pragma unroll
         for (int kb = 0; kb < 9; ++kb) {

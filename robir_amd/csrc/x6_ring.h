@@ -47,15 +47,29 @@ template <int N>
 __device__ __forceinline__ void sx_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+#ifndef SX_PK_SPLIT
+#define SX_PK_SPLIT 0      // 1: the two scalings as v_pk_mul_f32: bit-identical, no gain (profiles/r03_sdf_x6_ablation.md)
+#endif
 // exact three-way split of two fp32 values (vis_diffuse_x6.hip): v = h + m 2^-11 + l 2^-22
 __device__ __forceinline__ void sx_split_pair(float v0, float v1, float negk, unsigned& h, unsigned& m, unsigned& l) {
   const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+#if SX_PK_SPLIT
+  typedef float sx_f2 __attribute__((ext_vector_type(2)));
+  const sx_f2 sv = sx_f2{v0, v1} * 2048.0f;             // v_pk_mul_f32: the same rounding as two v_mul_f32
+  const float s0 = sv[0], s1 = sv[1];
+#else
   const float s0 = v0 * 2048.0f, s1 = v1 * 2048.0f;
+#endif
   float d0, d1;
   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hu), "s"(negk), "v"(s0));
   asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hu), "s"(negk), "v"(s1));
   const unsigned mu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0, d1));
+#if SX_PK_SPLIT
+  const sx_f2 ev = sx_f2{d0, d1} * 2048.0f;
+  const float e0 = ev[0], e1 = ev[1];
+#else
   const float e0 = d0 * 2048.0f, e1 = d1 * 2048.0f;
+#endif
   unsigned lu;
   asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(mu), "s"(negk), "v"(e0));
   asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(mu), "s"(negk), "v"(e1));
