@@ -62,9 +62,9 @@ def _run_vis(vis_fn, p, d, batch):
 
 
 def diffuse_visibility(points, normals, vis_fn, lobes, lambdas, u_theta, u_phi, thr=1.0, argmax_vis=False,
-                       return_dirs=False, batch=2000000):
+                       return_dirs=False, batch=2000000, bounding=False):
     """get_diffuse_visibility (sg_render.py:111-195).  points/normals [n,3]; lobes [L,3]; lambdas [L,1];
-    u_theta/u_phi [L,nsamp] uniform draws.  -> vis [L,n]."""
+    u_theta/u_phi [L,nsamp] uniform draws.  -> vis [L,n]; bounding=True (sg_render.py:185-186) -> per-sample vis [L,nsamp,n]."""
     L, nsamp = u_theta.shape
     n = points.shape[0]
     axis = unit_eps(lobes.unsqueeze(-2))                                  # [L,1,3]
@@ -81,6 +81,8 @@ def diffuse_visibility(points, normals, vis_fn, lobes, lambdas, u_theta, u_phi, 
     vis = torch.zeros(n, L * nsamp)
     vis[front] = pv
     vis = vis.reshape(n, L, nsamp).permute(1, 2, 0)                       # [L,nsamp,n]
+    if bounding:
+        return vis
     w = torch.exp(lam * ((dirs * axis).sum(-1, keepdim=True) - 1.0))      # [L,nsamp,1]
     out = (vis * w).sum(1) / (w.sum(1) + TINY)                            # [L,n]
     if return_dirs:

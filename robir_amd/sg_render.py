@@ -109,9 +109,9 @@ def _chunks(chunk_id, n_chunks, n=None):
 
 def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=8, testing=False, thr=1.0,
                            bounding=False, argmax_vis=False, *, draws=None, chunk_id=None, n_chunks=1, stats=None):
-    """-> vis [L, n] (sg_render.py:111-195).  lgtSGLobes [L,3], lgtSGLambdas [L,1]."""
-    if bounding:
-        raise NotImplementedError("bounding=True (per-sample visibilities) has no caller in the reference")
+    """-> vis [L, n] (sg_render.py:111-195).  lgtSGLobes [L,3], lgtSGLambdas [L,1].  bounding=True (sg_render.py:185-186; no
+    caller in the reference) returns the per-sample visibilities [L, nsamp, n] before the lobe-weighted mean: the fused kernels never
+    hold them, so that branch evaluates VisModel on the culled pairs (the MLP kernel on points / directions) and scatters."""
     dev = points.device
     L = lgtSGLobes.shape[0]
     n = points.shape[0]
@@ -123,6 +123,9 @@ def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, 
         u_t, u_p = draws["dvis_theta"], draws["dvis_phi"]
     else:
         u_t, u_p = _rand((C, L, nsamp), dev), _rand((C, L, nsamp), dev)
+    if bounding:
+        dirs, wdir, wsum = ops.dvis_dirs(lgt, u_t.to(dev), u_p.to(dev), thr, direct=True)
+        return _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis, per_sample=True)
     return _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis, cid, C, stats, direct=True).t()
 
 
@@ -160,7 +163,7 @@ def _diffuse_vis_core(points, normals, VisModel, lgt, u_t, u_p, thr, argmax_vis,
     return _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis)
 
 
-def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis):
+def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L, nsamp, argmax_vis, per_sample=False):
     """Any other VisModel callable (e.g. OctreeVisModel): directions/weights from the HIP kernel, the callable is
     evaluated on the culled pairs in 2M batches like the reference."""
     n = points.shape[0]
@@ -177,6 +180,8 @@ def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L,
     pv = logits.argmax(-1).float() if argmax_vis else torch.softmax(logits, -1)[..., 1]
     vis = torch.zeros(n, LS, device=points.device)
     vis[front] = pv
+    if per_sample:                                              # bounding=True: [L, nsamp, n] (sg_render.py:177,185-186)
+        return vis.reshape(n, L, nsamp).permute(1, 2, 0)
     w = wdir.reshape(C, L, nsamp)[c]
     return (vis.reshape(n, L, nsamp) * w).sum(-1) / wsum.reshape(C, L)[c]
 

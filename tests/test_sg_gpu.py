@@ -72,6 +72,35 @@ def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd, precision):
         print(f"[{precision}] chunk {c}: max rel err vs oracle {rel_err(out[sl], ref):.3e}")
 
 
+@pytest.mark.parametrize("argmax_vis", [False, True])
+def test_diffuse_visibility_bounding_vs_oracle(dev, vis_net, oracle_sd, argmax_vis):
+    """bounding=True (sg_render.py:185-186): the per-sample visibilities [L, nsamp, n] before the lobe-weighted mean, culled pairs 0;
+    and their weighted mean is what the fused kernel returns."""
+    from robir_amd import sg_render, synth
+    from robir_oracle import nets as on, sg as osg
+    g = np.random.Generator(np.random.PCG64(25))
+    n, L, nsamp = 29, 128, 8
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, L, sharp=True))
+    lobe, lam = lgt[:, :3], lgt[:, 3:4].abs()
+    u = torch.from_numpy(g.random((2, L, nsamp), dtype=np.float32))
+    draws = {"dvis_theta": u[0][None].to(dev), "dvis_phi": u[1][None].to(dev)}
+    out = sg_render.get_diffuse_visibility(pts.to(dev), nrm.to(dev), vis_net, lobe.to(dev), lam.to(dev), nsamp=nsamp, bounding=True,
+                                           argmax_vis=argmax_vis, draws=draws).cpu()
+    vis_fn = lambda p, d: on.vis_logits(oracle_sd, p, d)
+    ref = osg.diffuse_visibility(pts, nrm, vis_fn, lobe, lam, u[0], u[1], bounding=True, argmax_vis=argmax_vis)
+    assert out.shape == ref.shape == (L, nsamp, n)
+    if argmax_vis:      # 0 / 1 decisions: a logit pair closer than the arithmetic's error may flip
+        assert float((out != ref).float().mean()) <= 2e-3
+    else:
+        assert float((out - ref).abs().max()) <= 2e-5, float((out - ref).abs().max())
+        mean = sg_render.get_diffuse_visibility(pts.to(dev), nrm.to(dev), vis_net, lobe.to(dev), lam.to(dev), nsamp=nsamp,
+                                                draws=draws).cpu()
+        refm = osg.diffuse_visibility(pts, nrm, vis_fn, lobe, lam, u[0], u[1])
+        assert rel_err(mean, refm) <= TOL
+
+
 @pytest.mark.parametrize("testing,inv,argmax_vis", [(False, False, False), (True, True, False), (False, False, True)])
 def test_specular_visibility_vs_oracle(dev, vis_net, oracle_sd, testing, inv, argmax_vis):
     """get_specular_visibility on its own (sg_render.py:198-301; inside render_with_sg it only shows through sg_specular_rgb):
