@@ -130,8 +130,9 @@ def kl_divergence(x, mu=0.05):
 
 def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws,
                    comp_vis=True, vis_fn=None, lin_diff=False, testing=False, indir_integral=None, metallic=None,
-                   argmax_vis=False, stats=None, diffuse_vis=None, prefit=False):
-    """render_with_sg, single-view, diffuse_vis=None, fun_spec=False (sg_render.py:343-565).
+                   argmax_vis=False, stats=None, diffuse_vis=None, prefit=False, fun_spec=False):
+    """render_with_sg, single-view (sg_render.py:343-565); fun_spec=True returns the specular term as a function of
+    (roughness, draws) and sg_rgb = the diffuse term (sg_render.py:413,544-551).
     lgt_sgs [n,M,7].  draws: dict with 'dvis_theta','dvis_phi' [M,32] (comp_vis only) and
     'svis_theta','svis_phi' [n,8]."""
     n, M = lgt_sgs.shape[0], lgt_sgs.shape[1]
@@ -161,6 +162,33 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
         vis_shadow = (light_vis * l_mu0).sum(1) / torch.clamp(l_mu0.sum(1), 1e-4)
 
     # ---------------- specular (sg_render.py:414-500)
+    def specular_rgb_fn(roughness, draws=draws):
+        return _specular(points, nrm, view, f0, roughness, diffuse_albedo, metallic, l_lobe, l_lam, l_mu0, vis_fn, draws, testing,
+                         comp_vis, argmax_vis)
+
+    spec = None if fun_spec else specular_rgb_fn(roughness)
+
+    # ---------------- diffuse (sg_render.py:505-536)
+    l_mu_d = l_mu0 * light_vis if comp_vis else l_mu0
+    dmu = l_mu_d if lin_diff else l_mu_d * (diffuse_albedo / math.pi).unsqueeze(-2)
+    p_lobe, p_lam, p_mu = sg_product(nrm, LAMBDA_COS, MU_COS, l_lobe, l_lam, dmu)
+    diff = p_mu * hemisphere_int(p_lam, (p_lobe * nrm).sum(-1, keepdim=True)) \
+        - dmu * ALPHA_COS * hemisphere_int(l_lam, (l_lobe * nrm).sum(-1, keepdim=True))
+    diff = diff.sum(-2).clamp(min=0.0)
+    if indir_integral is not None:
+        diff = indir_integral if lin_diff else indir_integral * (diffuse_albedo / math.pi)
+    if fun_spec:
+        return {"sg_rgb": diff, "sg_specular_rgb": specular_rgb_fn, "sg_diffuse_rgb": diff, "vis_shadow": vis_shadow,
+                "supervise": supervise}
+    return {"sg_rgb": spec + diff, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": vis_shadow,
+            "supervise": supervise}
+
+
+def _specular(points, nrm, view, f0, roughness, diffuse_albedo, metallic, l_lobe, l_lam, l_mu0, vis_fn, draws, testing, comp_vis,
+              argmax_vis):
+    """specular_rgb_fn (sg_render.py:413-500): warped BRDF lobe of `roughness`, its sampled visibility, product with the light SGs and
+    the clamped cosine, hemisphere integral."""
+    n, M = nrm.shape[0], nrm.shape[1]
     r4 = 2.0 / (roughness * roughness * roughness * roughness)             # [n,1]
     b_lam = r4.unsqueeze(1).expand(n, M, 1)
     b_mu = (r4 / math.pi).expand(n, 3).unsqueeze(1).expand(n, M, 3)
@@ -190,19 +218,7 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
     p_lobe, p_lam, p_mu = sg_product(nrm, LAMBDA_COS, MU_COS, f_lobe, f_lam, f_mu)
     spec = p_mu * hemisphere_int(p_lam, (p_lobe * nrm).sum(-1, keepdim=True)) \
         - f_mu * ALPHA_COS * hemisphere_int(f_lam, (f_lobe * nrm).sum(-1, keepdim=True))
-    spec = spec.sum(-2).clamp(min=0.0)
-
-    # ---------------- diffuse (sg_render.py:505-536)
-    l_mu_d = l_mu0 * light_vis if comp_vis else l_mu0
-    dmu = l_mu_d if lin_diff else l_mu_d * (diffuse_albedo / math.pi).unsqueeze(-2)
-    p_lobe, p_lam, p_mu = sg_product(nrm, LAMBDA_COS, MU_COS, l_lobe, l_lam, dmu)
-    diff = p_mu * hemisphere_int(p_lam, (p_lobe * nrm).sum(-1, keepdim=True)) \
-        - dmu * ALPHA_COS * hemisphere_int(l_lam, (l_lobe * nrm).sum(-1, keepdim=True))
-    diff = diff.sum(-2).clamp(min=0.0)
-    if indir_integral is not None:
-        diff = indir_integral if lin_diff else indir_integral * (diffuse_albedo / math.pi)
-    return {"sg_rgb": spec + diff, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": vis_shadow,
-            "supervise": supervise}
+    return spec.sum(-2).clamp(min=0.0)
 
 
 def render_with_all_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws,

@@ -230,9 +230,9 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
                    VisModel=None, fun_spec=False, lin_diff=False, testing=False, indir_integral=None, metallic=None,
                    diffuse_vis=None, prefit=False, argmax_vis=False, *, draws=None, chunk_id=None, n_chunks=1,
                    stats=None):
-    """sg_render.py:343-565 (single view).  lgtSGs [n,M,7] (or [M,7])."""
-    if fun_spec:
-        raise NotImplementedError("fun_spec=True (specular as a closure) is a training-only path")
+    """sg_render.py:343-565 (single view).  lgtSGs [n,M,7] (or [M,7]).  fun_spec=True (sg_render.py:413,544-551): the specular term
+    comes back as a function of a roughness tensor (its specular visibility is sampled at every call, like the reference's closure;
+    `draws=` pins the samples), `sg_rgb` is then the diffuse term alone."""
     if viewdirs.dim() == 3:
         raise NotImplementedError("multi-view shading is not on the hot path")
     dev = points.device
@@ -265,15 +265,28 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
             supervise = _kl_divergence((light_vis - pred).abs(), 0.01) * factor
             if prefit != "warmup":
                 light_vis = pred
-    u_t, u_p = draws.get("svis_theta"), draws.get("svis_phi")
-    if u_t is None:
-        u_t, u_p = _rand((n, 8), dev), _rand((n, 8), dev)
-    bvis = _specular_vis_core(pts, nrm, vd, VisModel, rough, u_t.to(dev), u_p.to(dev), testing, not comp_vis, argmax_vis,
-                              cid, C)
     lgt = lgt_first if shared else lgtSGs.float().contiguous()
-    rgb, spec, diff, shadow = ops.sg_shade(nrm, vd, lgt, f0, rough, diffuse_albedo, bvis, light_vis=light_vis,
-                                           metallic=metallic, indir_integral=indir_integral, lin_diff=lin_diff,
-                                           want_shadow=True)
+
+    def shade(rough_, spec_draws):
+        u_t, u_p = spec_draws.get("svis_theta"), spec_draws.get("svis_phi")
+        if u_t is None:
+            u_t, u_p = _rand((n, 8), dev), _rand((n, 8), dev)
+        bvis = _specular_vis_core(pts, nrm, vd, VisModel, rough_, u_t.to(dev), u_p.to(dev), testing, not comp_vis, argmax_vis,
+                                  cid, C)
+        return ops.sg_shade(nrm, vd, lgt, f0, rough_, diffuse_albedo, bvis, light_vis=light_vis, metallic=metallic,
+                            indir_integral=indir_integral, lin_diff=lin_diff, want_shadow=True)
+
+    if fun_spec:
+        # the diffuse term and the shadow do not depend on the specular visibility: one shading pass with bvis = 1 gives them
+        _, _, diff, shadow = ops.sg_shade(nrm, vd, lgt, f0, rough, diffuse_albedo, torch.ones(n, device=dev), light_vis=light_vis,
+                                          metallic=metallic, indir_integral=indir_integral, lin_diff=lin_diff, want_shadow=True)
+
+        def specular_rgb_fn(roughness, draws=None):
+            return shade(roughness.float().contiguous().reshape(-1), draws or {})[1]
+
+        return {"sg_rgb": diff, "sg_specular_rgb": specular_rgb_fn, "sg_diffuse_rgb": diff, "vis_shadow": shadow,
+                "supervise": supervise}
+    rgb, spec, diff, shadow = shade(rough, draws)
     return {"sg_rgb": rgb, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": shadow, "supervise": supervise}
 
 

@@ -101,6 +101,68 @@ def test_diffuse_visibility_bounding_vs_oracle(dev, vis_net, oracle_sd, argmax_v
         assert rel_err(mean, refm) <= TOL
 
 
+@pytest.mark.parametrize("comp_vis", [True, False])
+def test_render_with_sg_fun_spec_vs_oracle(dev, vis_net, oracle_sd, comp_vis):
+    """fun_spec=True (sg_render.py:413,544-551): the specular term as a function of a roughness tensor, sg_rgb = the diffuse term.
+    The closure at another roughness against the oracle's on the same draws; at the call's own roughness and draws it is the
+    specular term of the plain call."""
+    from robir_amd import sg_render, synth
+    from robir_oracle import nets as on, sg as osg
+    g = np.random.Generator(np.random.PCG64(35))
+    n, M = 41, 128 if comp_vis else 24
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    view = torch.nn.functional.normalize(nrm + 0.7 * torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    # roughness >= 0.4: below it the reference's fp32 formulas are ill-conditioned against these sharp lights (lambda up to 500 x a
+    # BRDF lobe of 2 / r^4) -- at r = 0.2 the HIP kernel and the fp32 oracle are each 5e-3 from a float64 evaluation and 1.4e-3 apart
+    rough = torch.from_numpy(np.exp(g.uniform(np.log(0.4), np.log(0.9), (n, 1))).astype(np.float32))
+    rough2 = torch.from_numpy(np.exp(g.uniform(np.log(0.4), np.log(0.9), (n, 1))).astype(np.float32))
+    albedo = torch.from_numpy(g.uniform(0.1, 0.9, (n, 3)).astype(np.float32))
+    f0 = torch.full((1, 1), 0.02)
+    if comp_vis:
+        lgt = torch.from_numpy(synth.synth_light_sgs(3, M, sharp=True))
+        lgt_o = lgt[None].expand(n, M, 7)
+        indir = None
+    else:       # the indirect pass: per-point lobes, the integral replaces the diffuse term
+        lgt = torch.from_numpy(np.stack([synth.synth_light_sgs(100 + i, M, sharp=False) for i in range(n)]))
+        lgt_o = lgt
+        indir = torch.from_numpy(g.uniform(0.0, 1.0, (n, 3)).astype(np.float32))
+    u = torch.from_numpy(g.random((2, M, 32), dtype=np.float32))
+    sv = torch.from_numpy(g.random((4, n, 8), dtype=np.float32))
+    d0 = {"svis_theta": sv[0], "svis_phi": sv[1]}
+    d1 = {"svis_theta": sv[2], "svis_phi": sv[3]}
+    if comp_vis:
+        d0.update(dvis_theta=u[0], dvis_phi=u[1])
+    todev = lambda d: {k: v.to(dev) for k, v in d.items()}
+    kw = dict(comp_vis=comp_vis, VisModel=vis_net, indir_integral=None if indir is None else indir.to(dev), testing=True)
+    args = (pts.to(dev), nrm.to(dev), view.to(dev), lgt.to(dev), f0.to(dev), rough.to(dev), albedo.to(dev))
+    out = sg_render.render_with_sg(*args, fun_spec=True, draws=todev(d0), **kw)
+    plain = sg_render.render_with_sg(*args, draws=todev(d0), **kw)
+    assert callable(out["sg_specular_rgb"])
+    assert torch.equal(out["sg_rgb"], out["sg_diffuse_rgb"]) and torch.equal(out["sg_diffuse_rgb"], plain["sg_diffuse_rgb"])
+    assert torch.equal(out["sg_specular_rgb"](rough.to(dev), draws=todev(d0)), plain["sg_specular_rgb"])
+    vis_fn = lambda p, d: on.vis_logits(oracle_sd, p, d)
+    ref = osg.render_with_sg(pts, nrm, view, lgt_o, f0, rough, albedo, d0, comp_vis=comp_vis, vis_fn=vis_fn,
+                             indir_integral=indir, testing=True, fun_spec=True)
+    assert rel_err(out["sg_rgb"].cpu(), ref["sg_rgb"]) <= TOL
+    got = out["sg_specular_rgb"](rough2.to(dev), draws=todev(d1)).cpu()
+    want = ref["sg_specular_rgb"](rough2, d1)
+    # the yardstick for the closure: the oracle's formulas in float64 (the MLP stays fp32).  The specular term is a sum over lobes of
+    # differences of two hemisphere integrals: where it is small (0.011 at the worst point of the indirect case) two fp32 evaluations of
+    # the reference's formulas differ by a few 1e-4 of it, whatever their order of summation (kernel: wave-shuffle tree, 2.2e-4 from
+    # float64 there; torch: 4e-5 on that point, 2.5e-4 on others of the direct case) -- hence 3e-4 against float64 next to TOL
+    vis64 = lambda p, d: on.vis_logits(oracle_sd, p.float(), d.float()).double()
+    r64 = osg.render_with_sg(pts.double(), nrm.double(), view.double(), lgt_o.double(), f0.double(), rough.double(), albedo.double(),
+                             {k: v.double() for k, v in d0.items()}, comp_vis=comp_vis, vis_fn=vis64,
+                             indir_integral=None if indir is None else indir.double(), testing=True, fun_spec=True)
+    t64 = r64["sg_specular_rgb"](rough2.double(), {k: v.double() for k, v in d1.items()})
+    e_hip, e_f32, e_pair = rel_err(got.double(), t64), rel_err(want.double(), t64), rel_err(got, want)
+    print(f"fun_spec closure (comp_vis={comp_vis}): vs fp32 oracle {e_pair:.3e}; vs float64 {e_hip:.3e} (fp32 oracle: {e_f32:.3e})")
+    assert e_pair <= TOL or e_hip <= max(1.25 * e_f32, 3e-4), (e_pair, e_hip, e_f32)
+    if comp_vis:
+        assert rel_err(out["vis_shadow"].cpu(), ref["vis_shadow"]) <= TOL
+
+
 @pytest.mark.parametrize("testing,inv,argmax_vis", [(False, False, False), (True, True, False), (False, False, True)])
 def test_specular_visibility_vs_oracle(dev, vis_net, oracle_sd, testing, inv, argmax_vis):
     """get_specular_visibility on its own (sg_render.py:198-301; inside render_with_sg it only shows through sg_specular_rgb):
