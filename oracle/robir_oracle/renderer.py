@@ -135,13 +135,14 @@ def cesr_sg_render(sd, shadow_sd, normal_sd, points, view_dirs, indir_sgs, indir
 def forward(sd, tables, uv, pose, K, object_mask, hdr_shift, draws, trainstage="Material", testing=True,
             trace_log=None, stats=None, cesr=None):
     """IDRNetwork.forward, uv/pose/intrinsics input form (implicit_differentiable_renderer.py:290-479)
-    for one chunk of N pixels (B = 1).  tables: primary octree.  draws: see robir_amd.synth.pbr_draws
-    (row counts = number of hit rays of this chunk)."""
+    for one lock-step batch of B x N pixels (the runners use B = 1; B views are ONE cast over B N rays, :299-305, outputs
+    flattened to [B N, ...]).  tables: primary octree.  draws: see robir_amd.synth.pbr_draws (row counts = number of hit rays)."""
     dirs, cam = camera_rays(uv, pose, K)
-    N = dirs.shape[1]
+    B, N = dirs.shape[0], dirs.shape[1]
     _, hit, dist = octree_mod.trace(tables, cam, dirs, -1, trace_log)
     dirs = dirs.reshape(-1, 3)
-    points = cam[:, None, :].expand(1, N, 3).reshape(-1, 3) + dist[:, None] * dirs     # all rays (:324)
+    points = cam[:, None, :].expand(B, N, 3).reshape(-1, 3) + dist[:, None] * dirs     # all rays (:324)
+    N = B * N
     sdf_out = nets.implicit_forward(sd, points)[:, 0:1]
     ret = {"points": points, "sdf_output": sdf_out, "network_object_mask": hit,
            "object_mask": object_mask.reshape(-1), "ray_dirs": dirs, "hdr_shift": hdr_shift}

@@ -101,7 +101,7 @@ class IDRNetwork(nn.Module):
             return self._forward_points_dirs(input, trainstage, fun_spec, lin_diff, draws, stats)
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
         if uv.shape[0] != 1:
-            raise NotImplementedError("batch size 1 (every runner uses 1)")
+            return self._forward_views(input, trainstage, fun_spec, lin_diff, draws, stats)
         N = uv.shape[1]
         # A call normally is one lock-step chunk, whatever its size (the reference's semantics).  With
         # `model.lockstep_chunk = 1024` a larger call is rendered as consecutive 1024-pixel chunks in one batched pass --
@@ -168,6 +168,22 @@ class IDRNetwork(nn.Module):
         mask = torch.ones(N, dtype=torch.bool, device=uv.device)
         return self._render(uv, pose, K, mask, hdr_shift, chunk, trainstage, False, False, draws, stats, None)
 
+    def _forward_views(self, input, trainstage, fun_spec, lin_diff, draws, stats):
+        """Batch size B > 1 (no runner uses it): the reference casts the B x N rays of the B views as ONE lock-step batch from their
+        own camera centres and flattens every output to [B N, ...] (implicit_differentiable_renderer.py:299-305,324); every ray is
+        traced, `object_mask` only travels along."""
+        uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
+        B, N = uv.shape[0], uv.shape[1]
+        self.flush()
+        with torch.no_grad():
+            d = torch.cat([ops.camera_rays(pose[b, :4, :4].float().contiguous(), K[b, :3, :3].float().contiguous(),
+                                           uv[b].float().contiguous()) for b in range(B)])
+            o = pose[:, None, :3, 3].float().expand(B, N, 3).reshape(-1, 3).contiguous()
+        hdr = input.get("hdr_shift")
+        return self._render(None, None, None, input["object_mask"].reshape(-1), None if hdr is None else hdr.reshape(B * N, -1),
+                            B * N, trainstage, fun_spec, lin_diff, draws, stats, input.get("albedo_ratio"), origins=o, dirs_in=d,
+                            trace_all=True)
+
     def _forward_points_dirs(self, input, trainstage, fun_spec, lin_diff, draws, stats):
         """Second input form (implicit_differentiable_renderer.py:306-322): per-ray origins `points` and directions
         `dirs`; rays outside `object_mask` are not traced (dist 0, no hit).  One lock-step batch."""
@@ -179,18 +195,18 @@ class IDRNetwork(nn.Module):
                             input.get("albedo_ratio"), origins=o.contiguous(), dirs_in=d)
 
     def _render(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
-                albedo_ratio, origins=None, dirs_in=None):
+                albedo_ratio, origins=None, dirs_in=None, trace_all=False):
         # split-precision range sentinel (ops.range_check): free of charge without a sync -- an overflow in an earlier call is
         # reported here at the latest; ROBIR_RANGE_CHECK=sync waits for this call's own kernels before returning
         ops.range_check(sync=False)
         out = self._render_impl(uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
-                                albedo_ratio, origins, dirs_in)
+                                albedo_ratio, origins, dirs_in, trace_all)
         if _RANGE_SYNC:
             ops.range_check(sync=True)
         return out
 
     def _render_impl(self, uv, pose, K, object_mask, hdr_shift, chunk, trainstage, fun_spec, lin_diff, draws, stats,
-                     albedo_ratio, origins=None, dirs_in=None):
+                     albedo_ratio, origins=None, dirs_in=None, trace_all=False):
         draws = draws or {}
         if origins is not None:
             dev, N = origins.device, origins.shape[0]
@@ -198,7 +214,7 @@ class IDRNetwork(nn.Module):
                 dirs = dirs_in
                 hit = torch.zeros(N, dtype=torch.bool, device=dev)
                 dist = torch.zeros(N, device=dev)
-                sel = object_mask.nonzero()[:, 0]
+                sel = torch.arange(N, device=dev) if trace_all else object_mask.nonzero()[:, 0]
                 if sel.numel() > 0 and self.use_octree:
                     _, h, t = self.ray_tracer.sdf_octree.cast_full(origins[sel].contiguous(), dirs[sel].contiguous())
                     hit[sel], dist[sel] = h, t
