@@ -290,6 +290,13 @@ int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const fl
 int rb_dvis_fused_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* rb_dvis_fused_x6 with TWO 16-sample tiles per wave (csrc/vis_diffuse_x6t.hip, round 4): a weight fragment read from the LDS feeds
+ * both tiles and a pass of the weights serves 128 samples.  Same arguments, same arithmetic (three-piece operands, six products, one
+ * fp32 accumulator per weight class); the products of a class are summed half-chunk by half-chunk, so vis_out agrees with
+ * rb_dvis_fused_x6 to fp32 summation order, not bit for bit. */
+int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                      float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
  *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
  *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point

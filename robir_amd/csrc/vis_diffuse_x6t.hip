@@ -1,0 +1,387 @@
+// Light-SG visibility with EXACT fp32 operands on the f16 matrix pipe, TWO 16-sample tiles per wave (round 4;
+// get_diffuse_visibility, model/sg_render.py:111-195; VisNetwork, model/implicit_differentiable_renderer.py:241-258).
+//
+// k_dvis_x6 (vis_diffuse_x6.hip) gives a wave one tile: every weight fragment it reads from the LDS feeds one MFMA per product, and a
+// workgroup re-copies the net's 1.15 MB of three-piece weights for every 64 samples -- per chunk and CU 96 KB of fragment reads and
+// 24 KB of LDS-DMA writes next to 192 MFMAs, a quarter of the kernel's time (profiles/r03_*).  Here a wave holds the operands of TWO
+// tiles (2 x 2 x 96 registers: current and next layer), so a fragment feeds two MFMAs and a pass of the weights serves 128 samples:
+// half the LDS traffic per MFMA.  What pays for the registers: the fragments of a chunk are no longer resident (96 registers) but a
+// rolling window of HALF a chunk (4 k-blocks x 3 pieces = 48 registers: a piece's registers are refilled with the next half's right
+// behind the last MFMA that reads them), and next round's table rows are not held across a round (64 registers per tile) but fetched
+// during the head into the registers the next-layer operands have just left.
+//
+// Arithmetic: that of k_dvis_x6 (three-piece operands, six products, one fp32 accumulator per weight class; see its header).  The
+// products of a class are summed half-chunk by half-chunk (h.h | h.m, m.h | h.l, m.m, l.h per four k-blocks), not product by product
+// over the whole chunk: another -- equally valid -- fp32 summation order, so the results differ from k_dvis_x6's in the last bits.
+#include "../../include/robir_hip.h"
+#include "common.h"
+#include "mlp_engine.h"
+#include "x6_ring.h"
+
+namespace rb {
+
+#define RB_TINY 1e-6f
+constexpr int XT_MAX_DIRS = 4096;
+constexpr int XT_WF4 = 1536;             // weight part of a packed chunk: [kb 8][piece 3][lane 64] x 16 B = 24 KB
+constexpr int XT_CF4 = 4 + XT_WF4;       // packed chunk in global memory: 16 bias floats + weights
+constexpr int XT_SLOTS = 4, XT_DIST = 3;
+constexpr int XT_PIECES = 6;             // 4 KB rows (1 KB per wave) of one chunk copy
+
+__device__ __forceinline__ void xt_dma16(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_uniform), "v"(lane_byte_off),
+               "s"(gbase_uniform)
+               : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void k_dvis_x6t(
+    const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
+    const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
+    const float* __restrict__ wsum, const f4* __restrict__ W49, int L, int nsamp, int argmax_vis,
+    float* __restrict__ vis_out, unsigned long long* __restrict__ eval_count, unsigned* __restrict__ range_word) {
+  __shared__ f4 ring[XT_SLOTS * XT_WF4];   // 96 KB
+  __shared__ f4 headw[XT_WF4];             // 24 KB: chunk 48 (256 -> 2 head, rows 2..15 zero)
+  __shared__ f4 bias_tab[49 * 4];
+  __shared__ float vis_tab[XT_MAX_DIRS];
+  __shared__ unsigned short idx_list[XT_MAX_DIRS];
+  __shared__ f4 a_row[64];
+  __shared__ int s_count;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long p = blockIdx.x;
+  const int LS = L * nsamp;
+  const long dbase = (cid ? (long)cid[p] : 0L) * LS;
+  const float negk = -2048.0f;
+  constexpr float C11 = 1.0f / 2048.0f;
+  if (tid == 0) s_count = 0;
+  if (tid < 64) a_row[tid] = reinterpret_cast<const f4*>(A + p * 256)[tid];
+  for (int i = tid; i < 49 * 4; i += 256) bias_tab[i] = W49[(long)(i >> 2) * XT_CF4 + (i & 3)];
+  for (int i = tid; i < XT_WF4; i += 256) headw[i] = W49[48L * XT_CF4 + 4 + i];
+  for (int j = tid; j < LS; j += 256) vis_tab[j] = 0.f;
+  __syncthreads();
+  // ---- cull + compaction (order inside the list is irrelevant: results are scattered by direction index)
+  const float nx = normals[3 * p], ny = normals[3 * p + 1], nz = normals[3 * p + 2];
+  for (int j0 = 0; j0 < LS; j0 += 256) {
+    const int j = j0 + tid;
+    bool front = false;
+    if (j < LS) {
+      const float* d = dirs + 3 * (dbase + j);
+      const float c = nx * d[0] + ny * d[1] + nz * d[2];  // sum(n*d): separate mul/add (-ffp-contract=off)
+      front = c > RB_TINY;
+    }
+    const unsigned long long mk = __ballot(front);
+    int base = 0;
+    if (lane == 0 && mk) base = atomicAdd(&s_count, __popcll(mk));
+    base = __shfl(base, 0);
+    if (front) idx_list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)j;
+  }
+  __syncthreads();
+  const int S = s_count;
+  if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
+  const int rounds = (S + 127) / 128;
+
+  // ---- weight ring state
+  const unsigned ring_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ring);
+  const unsigned lane_off = (unsigned)tid * 16u;                  // byte offset of this lane inside a 4 KB DMA row
+  const unsigned wave_lds = ring_b + (unsigned)wave * 1024u;      // + slot * 24576 + i * 4096
+  unsigned row_off[XT_PIECES];
+#pragma unroll
+  for (int i = 0; i < XT_PIECES; ++i) {
+    row_off[i] = lane_off + (unsigned)i * 4096u;
+    asm volatile("" : "+v"(row_off[i]));       // keep six registers: re-deriving them per copy costs scalar adds
+  }
+  const u4* ring_u = reinterpret_cast<const u4*>(ring) + lane;
+  // fragment (kb, piece) of a slot: ring_u[slot * XT_WF4 + (kb * 3 + piece) * 64]
+  u4 wh[4], wm[4], wl[4];              // rolling window: the fragments of four k-blocks (half a chunk)
+  f4 bias;
+  if (rounds > 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < XT_PIECES; ++i)
+        xt_dma16(W49 + (long)c * XT_CF4 + 4 + i * 256, lane_off, wave_lds + (unsigned)c * 24576u + (unsigned)i * 4096u);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // chunk 0 landed; chunks 1, 2 stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      wh[k] = ring_u[(k * 3 + 0) * 64];
+      wm[k] = ring_u[(k * 3 + 1) * 64];
+      wl[k] = ring_u[(k * 3 + 2) * 64];
+    }
+    bias = bias_tab[g];
+  }
+
+  unsigned sat = 0u;                   // range sentinel: running max of the h pieces (all >= 0 here: ReLU outputs)
+  u4 xh[2][8], xm[2][8], xl[2][8];     // B operands of the current layer, two tiles (one 128-bit tuple per k-block and piece)
+  u4 yh[2][8], ym[2][8], yl[2][8];     // ... of the next layer, filled chunk by chunk
+
+#define XT_MFMA(ACC, WREG, XREG) \
+  ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, WREG), __builtin_bit_cast(h8, XREG), ACC, 0, 0, 0)
+
+  // relu(z) of output block jb -> operands of the next layer: k-block jb/2, registers 2*(jb&1)+{0,1}; q = register pair.
+  // Three stages per (tile, pair), spread over the MFMA groups of the next chunk.
+  float ev0[2][2], ev1[2][2], ed0, ed1;
+  unsigned eh;
+  SxAcc prev[2];
+  auto ep_stage1 = [&](int t, int q) {
+    const SxAcc& a = prev[t];
+    const float r0 = __builtin_fmaf(__builtin_fmaf(a.c2[2 * q], C11, a.c1[2 * q]), C11, a.c0[2 * q]);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(a.c2[2 * q + 1], C11, a.c1[2 * q + 1]), C11, a.c0[2 * q + 1]);
+    ev0[t][q] = fmaxf(r0, 0.f);
+    ev1[t][q] = fmaxf(r1, 0.f);
+  };
+  auto ep_stage2 = [&](int t, int q) {
+    const unsigned hu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ev0[t][q], ev1[t][q]));
+    const float s0 = ev0[t][q] * 2048.0f, s1 = ev1[t][q] * 2048.0f;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(ed0) : "v"(hu), "s"(negk), "v"(s0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ed1) : "v"(hu), "s"(negk), "v"(s1));
+    eh = hu;
+    sat = sat_acc_nonneg(sat, hu);
+  };
+  auto ep_stage3 = [&](int t, int jb, int q) {
+    const unsigned mu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ed0, ed1));
+    const float e0 = ed0 * 2048.0f, e1 = ed1 * 2048.0f;
+    unsigned lu;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(mu), "s"(negk), "v"(e0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(mu), "s"(negk), "v"(e1));
+    yh[t][jb >> 1][(jb & 1) * 2 + q] = eh;
+    ym[t][jb >> 1][(jb & 1) * 2 + q] = mu;
+    yl[t][jb >> 1][(jb & 1) * 2 + q] = lu;
+  };
+  // the twelve stage instances of a chunk's epilogue in issue order
+  auto ep_slot = [&](int s, int pj) {
+    switch (s) {
+      case 0: ep_stage1(0, 0); break;
+      case 1: ep_stage1(0, 1); break;
+      case 2: ep_stage1(1, 0); break;
+      case 3: ep_stage1(1, 1); break;
+      case 4: ep_stage2(0, 0); break;
+      case 5: ep_stage3(0, pj, 0); break;
+      case 6: ep_stage2(0, 1); break;
+      case 7: ep_stage3(0, pj, 1); break;
+      case 8: ep_stage2(1, 0); break;
+      case 9: ep_stage3(1, pj, 0); break;
+      case 10: ep_stage2(1, 1); break;
+      default: ep_stage3(1, pj, 1); break;
+    }
+  };
+
+  // Layer-0 inputs (rows of the per-direction table): fetched during the head of the previous round into `raw`, which takes the
+  // registers the next-layer operands have just left
+  f4 raw[2][16];
+  int jj[2], jjn[2];
+  auto fetch_rows = [&](int rd_next) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int si = rd_next * 128 + t * 64 + wave * 16 + (lane & 15);
+      jjn[t] = si < S ? (int)idx_list[si] : -1;
+      const int j = jjn[t] < 0 ? 0 : jjn[t];
+      const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) raw[t][kb] = brow[kb * 4];
+    }
+  };
+  if (rounds > 0) fetch_rows(0);
+  for (int rd = 0; rd < rounds; ++rd) {
+    // ---- layer 0: relu(A[p] + Bd[dir]) straight into the operand registers
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      jj[t] = jjn[t];
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const f4 bv = raw[t][kb];
+        const f4 av = a_row[kb * 4 + g];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          unsigned h, m, l;
+          sx_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f), negk, h, m, l);
+          xh[t][kb / 2][(kb & 1) * 2 + q] = h;
+          xm[t][kb / 2][(kb & 1) * 2 + q] = m;
+          xl[t][kb / 2][(kb & 1) * 2 + q] = l;
+          sat = sat_acc_nonneg(sat, h);
+        }
+      }
+    }
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+      const f4* Wl = W49 + (long)l * 16 * XT_CF4 + 4;                          // this layer's chunk 0 weights
+      const f4* Wn = W49 + (long)(l == 2 ? 0 : l + 1) * 16 * XT_CF4 + 4;        // next layer's (next round wraps to 0)
+#pragma unroll
+      for (int jb = 0; jb < 16; ++jb) {
+        SxAcc acc[2];
+        // chunk jb+1 has landed in its slot once at most the copy of chunk jb+2 (6 instructions) is still in flight; past the barrier
+        // every wave has also finished with chunk jb-1 (its second half was read during chunk jb-1's first half), whose slot the copy
+        // of chunk jb+3 reuses
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#ifndef XT_ABL_NOBAR                  // timing ablation (wrong results): no per-chunk barrier
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+        const int nx3 = jb + XT_DIST;
+        const f4* dsrc = nx3 < 16 ? Wl + (long)nx3 * XT_CF4 : Wn + (long)(nx3 - 16) * XT_CF4;
+        const unsigned ddst = wave_lds + (unsigned)(nx3 & 3) * 24576u;
+        const f4 nbias = bias_tab[(l * 16 + jb + 1) * 4 + g];     // index 48 = head chunk after the last layer
+#if defined(XT_ABL_NODMA)            // timing ablation (wrong results): no weight copies
+#define XT_COPY(I) do { } while (0)
+#else
+#define XT_COPY(I) do { xt_dma16(dsrc, row_off[I], ddst + (unsigned)(I) * 4096u); } while (0)
+#endif
+#define XT_FENCE __builtin_amdgcn_sched_barrier(0)
+#ifdef XT_ABL_NOLDS                   // timing ablation (wrong results): no fragment reads
+#define XT_FRAG(DST, KB, PIECE) asm volatile("" : "+v"(DST))
+#else
+#define XT_FRAG(DST, KB, PIECE) DST = nfrag[((KB) * 3 + (PIECE)) * 64]
+#endif
+#define XT_EP(S)                        \
+  do {                                  \
+    if (jb > 0) ep_slot((S), jb - 1);   \
+  } while (0)
+        // four MFMAs on one accumulator, the window's k-blocks k = 0..3 <-> k-blocks 4 H + k of the chunk
+#define XT_RUN(ACC, WP, XP) \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) XT_MFMA(ACC, WP[k], XP[4 * H + k])
+        // ... each fragment refilled with the next half's right behind the last MFMA that reads it
+#define XT_RUN_REFILL(ACC, WP, XP, PIECE)       \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) { \
+    XT_MFMA(ACC, WP[k], XP[4 * H + k]);           \
+    XT_FRAG(WP[k], 4 * (1 - H) + k, PIECE);       \
+  }
+#pragma unroll
+        for (int H = 0; H < 2; ++H) {
+          // the next half's fragments: second half of this chunk's slot | first half of the next chunk's
+          const u4* nfrag = ring_u + ((jb + H) & 3) * XT_WF4;
+          if (H == 0) {
+            acc[0].c0 = bias;
+            acc[1].c0 = bias;
+            acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
+          }
+          XT_RUN(acc[0].c0, wh, xh[0]);                       // 1
+          if (H == 0) XT_EP(0); else XT_EP(9);
+          XT_FENCE;
+          XT_RUN(acc[0].c1, wh, xm[0]);                       // 2
+          if (H == 0) XT_EP(1); else XT_EP(10);
+          XT_FENCE;
+          XT_RUN(acc[0].c2, wh, xl[0]);                       // 3
+          if (H == 0) XT_EP(2); else XT_EP(11);
+          XT_FENCE;
+          XT_RUN(acc[1].c0, wh, xh[1]);                       // 4
+          if (H == 0) XT_EP(3); else XT_COPY(0);
+          XT_FENCE;
+          XT_RUN(acc[1].c1, wh, xm[1]);                       // 5
+          if (H == 0) XT_EP(4); else XT_COPY(1);
+          XT_FENCE;
+          XT_RUN_REFILL(acc[1].c2, wh, xl[1], 0);             // 6: the h fragments' last use
+          XT_FENCE;
+          XT_RUN(acc[0].c1, wm, xh[0]);                       // 7
+          if (H == 0) XT_EP(5); else XT_COPY(2);
+          XT_FENCE;
+          XT_RUN(acc[0].c2, wm, xm[0]);                       // 8
+          if (H == 0) XT_EP(6); else XT_COPY(3);
+          XT_FENCE;
+          XT_RUN(acc[1].c1, wm, xh[1]);                       // 9
+          if (H == 0) XT_EP(7); else XT_COPY(4);
+          XT_FENCE;
+          XT_RUN_REFILL(acc[1].c2, wm, xm[1], 1);             // 10: the m fragments' last use
+          XT_FENCE;
+          XT_RUN(acc[0].c2, wl, xh[0]);                       // 11
+          if (H == 0) XT_EP(8); else XT_COPY(5);
+          XT_FENCE;
+          XT_RUN_REFILL(acc[1].c2, wl, xh[1], 2);             // 12: the l fragments' last use
+          XT_FENCE;
+        }
+#undef XT_RUN
+#undef XT_RUN_REFILL
+#undef XT_COPY
+#undef XT_FENCE
+#undef XT_FRAG
+#undef XT_EP
+        prev[0] = acc[0];
+        prev[1] = acc[1];
+        bias = nbias;
+      }
+#pragma unroll
+      for (int s = 0; s < 12; ++s) ep_slot(s, 15);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          xh[t][kb] = yh[t][kb];
+          xm[t][kb] = ym[t][kb];
+          xl[t][kb] = yl[t][kb];
+        }
+    }
+    // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias (fetched by the last chunk of layer 2) and the fragment
+    // window already holds the first half of the next round's chunk 0.  Next round's rows are requested first: they arrive under
+    // the head's MFMAs (clamped to this round's samples after the final round: harmless)
+    fetch_rows(rd + 1 < rounds ? rd + 1 : rd);
+    {
+      const u4* hw = reinterpret_cast<const u4*>(headw) + lane;
+      SxAcc acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t].c0 = bias;
+        acc[t].c1 = f4{0.f, 0.f, 0.f, 0.f};
+        acc[t].c2 = f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const u4 fh = hw[(kb * 3 + 0) * 64], fm = hw[(kb * 3 + 1) * 64], fl = hw[(kb * 3 + 2) * 64];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          XT_MFMA(acc[t].c0, fh, xh[t][kb]);
+          XT_MFMA(acc[t].c1, fh, xm[t][kb]);
+          XT_MFMA(acc[t].c2, fh, xl[t][kb]);
+          XT_MFMA(acc[t].c1, fm, xh[t][kb]);
+          XT_MFMA(acc[t].c2, fm, xm[t][kb]);
+          XT_MFMA(acc[t].c2, fl, xh[t][kb]);
+        }
+      }
+      bias = bias_tab[g];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float l0 = __builtin_fmaf(__builtin_fmaf(acc[t].c2[0], C11, acc[t].c1[0]), C11, acc[t].c0[0]);
+        const float l1 = __builtin_fmaf(__builtin_fmaf(acc[t].c2[1], C11, acc[t].c1[1]), C11, acc[t].c0[1]);
+        if (g == 0 && jj[t] >= 0) {
+          float v;
+          if (argmax_vis) {
+            v = l1 > l0 ? 1.f : 0.f;
+          } else {
+            const float mx = fmaxf(l0, l1);
+            const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+            v = e1 / (e0 + e1);
+          }
+          vis_tab[jj[t]] = v;
+        }
+      }
+    }
+  }
+#undef XT_MFMA
+  range_report<true>(sat, range_word);
+  // drain the ring (copies still target this workgroup's LDS)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid < L) {
+    const float* w = wdir + dbase + (long)tid * nsamp;
+    float acc = 0.f;
+    for (int k = 0; k < nsamp; ++k) acc += vis_tab[tid * nsamp + k] * w[k];
+    vis_out[p * L + tid] = acc / wsum[(cid ? cid[p] : 0) * L + tid];
+  }
+}
+
+}  // namespace rb
+
+using namespace rb;
+
+extern "C" int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd,
+                                 const float* dirs, const float* wdir, const float* wsum, const float* W49, int L, int nsamp,
+                                 int argmax_vis, int scale_log2, float* vis_out, unsigned long long* eval_count,
+                                 rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
+  RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
+  RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= XT_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
+  RB_REQUIRE(scale_log2 == 0, "k_dvis_x6t takes weights packed with scale_log2 = 0");
+  hipLaunchKernelGGL(k_dvis_x6t, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, wdir,
+                     wsum, (const f4*)W49, L, nsamp, argmax_vis, vis_out, eval_count,
+                     range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr);
+  return check_launch("k_dvis_x6t");
+}

@@ -498,11 +498,11 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         # the CUs; at whole-view sizes the one-point-per-workgroup kernel is as fast and needs no scratch
         precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
     h3 = precision.startswith("f16x3")
-    assert h3 or precision in ("fp32", "f16x6"), precision
+    assert h3 or precision in ("fp32", "f16x6", "f16x6-1t"), precision
     # "f16x3-v2" = second-generation split-precision kernel: two tiles per wave, one workgroup per CU, head on the matrix
     # pipe (csrc/vis_diffuse_v2.hip); "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU,
     # weights staged by LDS-DMA; "f16x6" = the v2 machine with exact three-piece operands (csrc/vis_diffuse_x6.hip)
-    code = {"fp32": 0, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x6": 10}[precision]
+    code = {"fp32": 0, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x6": 10, "f16x6-1t": 10}[precision]
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
@@ -522,8 +522,9 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
              c_int(split["h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
-    if precision == "f16x6":
-        call("rb_dvis_fused_x6", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+    if precision in ("f16x6", "f16x6-1t"):
+        # "f16x6": two 16-sample tiles per wave (csrc/vis_diffuse_x6t.hip); "f16x6-1t": round 3's one-tile kernel (vis_diffuse_x6.hip)
+        call("rb_dvis_fused_x6t" if precision == "f16x6" else "rb_dvis_fused_x6", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["x6_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
