@@ -26,10 +26,20 @@ constexpr int XT_WF4 = 1536;             // weight part of a packed chunk: [kb 8
 constexpr int XT_CF4 = 4 + XT_WF4;       // packed chunk in global memory: 16 bias floats + weights
 constexpr int XT_SLOTS = 4, XT_DIST = 3;
 constexpr int XT_PIECES = 6;             // 4 KB rows (1 KB per wave) of one chunk copy
+#ifndef XT_PINGPONG
+#define XT_PINGPONG 0
+#endif
 
 __device__ __forceinline__ void xt_dma16(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_uniform), "v"(lane_byte_off),
                "s"(gbase_uniform)
+               : "memory");
+}
+// ... with an immediate offset, which advances the global AND the LDS address (x6_ring.h: sx_dma_block)
+template <int OFF>
+__device__ __forceinline__ void xt_dma16_imm(const f4* gbase_uniform, unsigned lane_byte_off, unsigned lds_byte_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_byte_uniform), "v"(lane_byte_off),
+               "s"(gbase_uniform), "n"(OFF)
                : "memory");
 }
 
@@ -81,16 +91,18 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
 
   // ---- weight ring state
   const unsigned ring_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ring);
-  const unsigned lane_off = (unsigned)tid * 16u;                  // byte offset of this lane inside a 4 KB DMA row
-  const unsigned wave_lds = ring_b + (unsigned)wave * 1024u;      // + slot * 24576 + i * 4096
-  unsigned row_off[XT_PIECES];
-#pragma unroll
-  for (int i = 0; i < XT_PIECES; ++i) {
-    row_off[i] = lane_off + (unsigned)i * 4096u;
-    asm volatile("" : "+v"(row_off[i]));       // keep six registers: re-deriving them per copy costs scalar adds
-  }
-  const u4* ring_u = reinterpret_cast<const u4*>(ring) + lane;
-  // fragment (kb, piece) of a slot: ring_u[slot * XT_WF4 + (kb * 3 + piece) * 64]
+  // a wave copies six consecutive 1 KB pieces of a 24 KB chunk: bytes [wave 6 KB, + 6 KB), addressed as (chunk base in SGPRs) + (one
+  // of two per-lane offsets, 4 KB apart) + (an immediate 0 / 1 / 2 / 3 KB): no scalar address arithmetic per copy
+  unsigned voff_a = (unsigned)wave * 6144u + (unsigned)lane * 16u, voff_b = voff_a + 4096u;
+  asm volatile("" : "+v"(voff_a), "+v"(voff_b));
+  const unsigned wave_lds = ring_b + (unsigned)wave * 6144u;      // + slot * 24576 (+ 4096 for pieces 4, 5) + the immediate
+  // fragment (kb, piece) of a slot: ring_u[slot * XT_WF4 + (kb * 3 + piece) * 64].  Two base registers (slots 0, 1 | 2, 3) keep every
+  // read's offset inside the 16-bit immediate of ds_read_b128 (the ring is 96 KB: from one base the compiler keeps an address
+  // register per fragment, parked in the accumulator file and fetched back before every read)
+  typedef const __attribute__((address_space(3))) u4* lds_u4p;
+  unsigned ring_a0 = ring_b + (unsigned)lane * 16u, ring_a2 = ring_a0 + 2u * XT_WF4 * 16u;
+  asm volatile("" : "+v"(ring_a0), "+v"(ring_a2));
+  const lds_u4p ring_u = (lds_u4p)ring_a0, ring_u2 = (lds_u4p)ring_a2;
   u4 wh[4], wm[4], wl[4];              // rolling window: the fragments of four k-blocks (half a chunk)
   f4 bias;
   if (rounds > 0) {
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int i = 0; i < XT_PIECES; ++i)
-        xt_dma16(W49 + (long)c * XT_CF4 + 4 + i * 256, lane_off, wave_lds + (unsigned)c * 24576u + (unsigned)i * 4096u);
+        xt_dma16(W49 + (long)c * XT_CF4 + 4 + i * 64, voff_a, wave_lds + (unsigned)c * 24576u + (unsigned)i * 1024u);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // chunk 0 landed; chunks 1, 2 stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -112,8 +124,10 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
   }
 
   unsigned sat = 0u;                   // range sentinel: running max of the h pieces (all >= 0 here: ReLU outputs)
-  u4 xh[2][8], xm[2][8], xl[2][8];     // B operands of the current layer, two tiles (one 128-bit tuple per k-block and piece)
-  u4 yh[2][8], ym[2][8], yl[2][8];     // ... of the next layer, filled chunk by chunk
+  struct Ops {
+    u4 h[2][8], m[2][8], l[2][8];      // B operands of a layer, two tiles (one 128-bit tuple per k-block and piece)
+  };
+  Ops P, Q;                            // current / next layer's operands, filled chunk by chunk; the layers alternate the roles
 
 #define XT_MFMA(ACC, WREG, XREG) \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, WREG), __builtin_bit_cast(h8, XREG), ACC, 0, 0, 0)
@@ -138,31 +152,31 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
     eh = hu;
     sat = sat_acc_nonneg(sat, hu);
   };
-  auto ep_stage3 = [&](int t, int jb, int q) {
+  auto ep_stage3 = [&](Ops& Y, int t, int jb, int q) {
     const unsigned mu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ed0, ed1));
     const float e0 = ed0 * 2048.0f, e1 = ed1 * 2048.0f;
     unsigned lu;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(mu), "s"(negk), "v"(e0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(mu), "s"(negk), "v"(e1));
-    yh[t][jb >> 1][(jb & 1) * 2 + q] = eh;
-    ym[t][jb >> 1][(jb & 1) * 2 + q] = mu;
-    yl[t][jb >> 1][(jb & 1) * 2 + q] = lu;
+    Y.h[t][jb >> 1][(jb & 1) * 2 + q] = eh;
+    Y.m[t][jb >> 1][(jb & 1) * 2 + q] = mu;
+    Y.l[t][jb >> 1][(jb & 1) * 2 + q] = lu;
   };
   // the twelve stage instances of a chunk's epilogue in issue order
-  auto ep_slot = [&](int s, int pj) {
+  auto ep_slot = [&](Ops& Y, int s, int pj) {
     switch (s) {
       case 0: ep_stage1(0, 0); break;
       case 1: ep_stage1(0, 1); break;
       case 2: ep_stage1(1, 0); break;
       case 3: ep_stage1(1, 1); break;
       case 4: ep_stage2(0, 0); break;
-      case 5: ep_stage3(0, pj, 0); break;
+      case 5: ep_stage3(Y, 0, pj, 0); break;
       case 6: ep_stage2(0, 1); break;
-      case 7: ep_stage3(0, pj, 1); break;
+      case 7: ep_stage3(Y, 0, pj, 1); break;
       case 8: ep_stage2(1, 0); break;
-      case 9: ep_stage3(1, pj, 0); break;
+      case 9: ep_stage3(Y, 1, pj, 0); break;
       case 10: ep_stage2(1, 1); break;
-      default: ep_stage3(1, pj, 1); break;
+      default: ep_stage3(Y, 1, pj, 1); break;
     }
   };
 
@@ -195,15 +209,14 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
         for (int q = 0; q < 2; ++q) {
           unsigned h, m, l;
           sx_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f), negk, h, m, l);
-          xh[t][kb / 2][(kb & 1) * 2 + q] = h;
-          xm[t][kb / 2][(kb & 1) * 2 + q] = m;
-          xl[t][kb / 2][(kb & 1) * 2 + q] = l;
+          P.h[t][kb / 2][(kb & 1) * 2 + q] = h;
+          P.m[t][kb / 2][(kb & 1) * 2 + q] = m;
+          P.l[t][kb / 2][(kb & 1) * 2 + q] = l;
           sat = sat_acc_nonneg(sat, h);
         }
       }
     }
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
+    auto layer = [&](int l, Ops& X, Ops& Y) {
       const f4* Wl = W49 + (long)l * 16 * XT_CF4 + 4;                          // this layer's chunk 0 weights
       const f4* Wn = W49 + (long)(l == 2 ? 0 : l + 1) * 16 * XT_CF4 + 4;        // next layer's (next round wraps to 0)
 #pragma unroll
@@ -224,7 +237,11 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
 #if defined(XT_ABL_NODMA)            // timing ablation (wrong results): no weight copies
 #define XT_COPY(I) do { } while (0)
 #else
-#define XT_COPY(I) do { xt_dma16(dsrc, row_off[I], ddst + (unsigned)(I) * 4096u); } while (0)
+#define XT_COPY(I)                                                                  \
+  do {                                                                              \
+    if ((I) < 4) xt_dma16_imm<((I) & 3) * 1024>(dsrc, voff_a, ddst);                \
+    else xt_dma16_imm<((I) & 3) * 1024>(dsrc, voff_b, ddst + 4096u);                \
+  } while (0)
 #endif
 #define XT_FENCE __builtin_amdgcn_sched_barrier(0)
 #ifdef XT_ABL_NOLDS                   // timing ablation (wrong results): no fragment reads
@@ -234,58 +251,64 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
 #endif
 #define XT_EP(S)                        \
   do {                                  \
-    if (jb > 0) ep_slot((S), jb - 1);   \
+    if (jb > 0) ep_slot(Y, (S), jb - 1); \
   } while (0)
-        // four MFMAs on one accumulator, the window's k-blocks k = 0..3 <-> k-blocks 4 H + k of the chunk
-#define XT_RUN(ACC, WP, XP) \
-  _Pragma("unroll") for (int k = 0; k < 4; ++k) XT_MFMA(ACC, WP[k], XP[4 * H + k])
+        // four MFMAs on one accumulator, the window's k-blocks k = 0..3 <-> k-blocks 4 H + k of the chunk; a chunk's first half walks
+        // them upwards, its second half downwards, so that a half starts with the fragment that was requested LAST: its wait
+        // covers the other three (fragments return in order), one s_waitcnt per piece and half instead of four
+#define XT_RUN(ACC, WP, XP)                     \
+  _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+    const int k = H ? 3 - k_ : k_;               \
+    XT_MFMA(ACC, WP[k], XP[4 * H + k]);          \
+  }
         // ... each fragment refilled with the next half's right behind the last MFMA that reads it
-#define XT_RUN_REFILL(ACC, WP, XP, PIECE)       \
-  _Pragma("unroll") for (int k = 0; k < 4; ++k) { \
-    XT_MFMA(ACC, WP[k], XP[4 * H + k]);           \
-    XT_FRAG(WP[k], 4 * (1 - H) + k, PIECE);       \
+#define XT_RUN_REFILL(ACC, WP, XP, PIECE)          \
+  _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+    const int k = H ? 3 - k_ : k_;                   \
+    XT_MFMA(ACC, WP[k], XP[4 * H + k]);              \
+    XT_FRAG(WP[k], 4 * (1 - H) + k, PIECE);          \
   }
 #pragma unroll
         for (int H = 0; H < 2; ++H) {
           // the next half's fragments: second half of this chunk's slot | first half of the next chunk's
-          const u4* nfrag = ring_u + ((jb + H) & 3) * XT_WF4;
+          const lds_u4p nfrag = (((jb + H) & 2) ? ring_u2 : ring_u) + ((jb + H) & 1) * XT_WF4;
           if (H == 0) {
             acc[0].c0 = bias;
             acc[1].c0 = bias;
             acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
           }
-          XT_RUN(acc[0].c0, wh, xh[0]);                       // 1
+          XT_RUN(acc[0].c0, wh, X.h[0]);                       // 1
           if (H == 0) XT_EP(0); else XT_EP(9);
           XT_FENCE;
-          XT_RUN(acc[0].c1, wh, xm[0]);                       // 2
+          XT_RUN(acc[0].c1, wh, X.m[0]);                       // 2
           if (H == 0) XT_EP(1); else XT_EP(10);
           XT_FENCE;
-          XT_RUN(acc[0].c2, wh, xl[0]);                       // 3
+          XT_RUN(acc[0].c2, wh, X.l[0]);                       // 3
           if (H == 0) XT_EP(2); else XT_EP(11);
           XT_FENCE;
-          XT_RUN(acc[1].c0, wh, xh[1]);                       // 4
+          XT_RUN(acc[1].c0, wh, X.h[1]);                       // 4
           if (H == 0) XT_EP(3); else XT_COPY(0);
           XT_FENCE;
-          XT_RUN(acc[1].c1, wh, xm[1]);                       // 5
+          XT_RUN(acc[1].c1, wh, X.m[1]);                       // 5
           if (H == 0) XT_EP(4); else XT_COPY(1);
           XT_FENCE;
-          XT_RUN_REFILL(acc[1].c2, wh, xl[1], 0);             // 6: the h fragments' last use
+          XT_RUN_REFILL(acc[1].c2, wh, X.l[1], 0);             // 6: the h fragments' last use
           XT_FENCE;
-          XT_RUN(acc[0].c1, wm, xh[0]);                       // 7
+          XT_RUN(acc[0].c1, wm, X.h[0]);                       // 7
           if (H == 0) XT_EP(5); else XT_COPY(2);
           XT_FENCE;
-          XT_RUN(acc[0].c2, wm, xm[0]);                       // 8
+          XT_RUN(acc[0].c2, wm, X.m[0]);                       // 8
           if (H == 0) XT_EP(6); else XT_COPY(3);
           XT_FENCE;
-          XT_RUN(acc[1].c1, wm, xh[1]);                       // 9
+          XT_RUN(acc[1].c1, wm, X.h[1]);                       // 9
           if (H == 0) XT_EP(7); else XT_COPY(4);
           XT_FENCE;
-          XT_RUN_REFILL(acc[1].c2, wm, xm[1], 1);             // 10: the m fragments' last use
+          XT_RUN_REFILL(acc[1].c2, wm, X.m[1], 1);             // 10: the m fragments' last use
           XT_FENCE;
-          XT_RUN(acc[0].c2, wl, xh[0]);                       // 11
+          XT_RUN(acc[0].c2, wl, X.h[0]);                       // 11
           if (H == 0) XT_EP(8); else XT_COPY(5);
           XT_FENCE;
-          XT_RUN_REFILL(acc[1].c2, wl, xh[1], 2);             // 12: the l fragments' last use
+          XT_RUN_REFILL(acc[1].c2, wl, X.h[1], 2);             // 12: the l fragments' last use
           XT_FENCE;
         }
 #undef XT_RUN
@@ -299,16 +322,28 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
         bias = nbias;
       }
 #pragma unroll
-      for (int s = 0; s < 12; ++s) ep_slot(s, 15);
+      for (int s = 0; s < 12; ++s) ep_slot(Y, s, 15);
+    };
+#if XT_PINGPONG     // three copies of the layer body, the operand sets alternate: no register moves at a layer's end
+    layer(0, P, Q);
+    layer(1, Q, P);
+    layer(2, P, Q);
+    Ops& HX = Q;
+#else
+#pragma unroll 1
+    for (int l = 0; l < 3; ++l) {
+      layer(l, P, Q);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) {
-          xh[t][kb] = yh[t][kb];
-          xm[t][kb] = ym[t][kb];
-          xl[t][kb] = yl[t][kb];
+          P.h[t][kb] = Q.h[t][kb];
+          P.m[t][kb] = Q.m[t][kb];
+          P.l[t][kb] = Q.l[t][kb];
         }
     }
+    Ops& HX = P;
+#endif
     // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias (fetched by the last chunk of layer 2) and the fragment
     // window already holds the first half of the next round's chunk 0.  Next round's rows are requested first: they arrive under
     // the head's MFMAs (clamped to this round's samples after the final round: harmless)
@@ -327,12 +362,12 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
         const u4 fh = hw[(kb * 3 + 0) * 64], fm = hw[(kb * 3 + 1) * 64], fl = hw[(kb * 3 + 2) * 64];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          XT_MFMA(acc[t].c0, fh, xh[t][kb]);
-          XT_MFMA(acc[t].c1, fh, xm[t][kb]);
-          XT_MFMA(acc[t].c2, fh, xl[t][kb]);
-          XT_MFMA(acc[t].c1, fm, xh[t][kb]);
-          XT_MFMA(acc[t].c2, fm, xm[t][kb]);
-          XT_MFMA(acc[t].c2, fl, xh[t][kb]);
+          XT_MFMA(acc[t].c0, fh, HX.h[t][kb]);
+          XT_MFMA(acc[t].c1, fh, HX.m[t][kb]);
+          XT_MFMA(acc[t].c2, fh, HX.l[t][kb]);
+          XT_MFMA(acc[t].c1, fm, HX.h[t][kb]);
+          XT_MFMA(acc[t].c2, fm, HX.m[t][kb]);
+          XT_MFMA(acc[t].c2, fl, HX.h[t][kb]);
         }
       }
       bias = bias_tab[g];

@@ -53,7 +53,7 @@ for rep in range(5):
         torch.cuda.synchronize()
         if not argmax:
             times.append(s.elapsed_time(e))
-        out["argmax" if argmax else "softmax"] = o.cpu()
+        out["argmax" if argmax else "softmax"] = o[::16].cpu()       # every 16th point: the files travel back from the GPU box
 os.makedirs(OUT, exist_ok=True)
 torch.save(out, os.path.join(OUT, "ab_%s.pt" % tag))
 print(tag, " ".join(f"{t:.2f}" for t in times), "ms (min %.2f)" % min(times), flush=True)
