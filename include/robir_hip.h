@@ -297,6 +297,13 @@ int rb_dvis_fused_x6(const float* normals, const int* chunk_id, long n, const fl
 int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                       const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                       float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* rb_dvis_stream (below) on the arithmetic and the two-tile machine of rb_dvis_fused_x6t: cull, a persistent grid over the global
+ * tile list (eight 16-sample tiles per round, whatever point they belong to), per-lobe reduce.  Same arguments and scratch as
+ * rb_dvis_stream; every pair goes through rb_dvis_fused_x6t's instruction sequence: vis_out is bit-identical to it. */
+int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                      const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                      unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
+                      int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
  *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
  *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point

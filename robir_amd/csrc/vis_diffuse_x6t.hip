@@ -43,29 +43,77 @@ __device__ __forceinline__ void xt_dma16_imm(const f4* gbase_uniform, unsigned l
                : "memory");
 }
 
-__global__ __launch_bounds__(256, 1) void k_dvis_x6t(
-    const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ A,
-    const float* __restrict__ Bd, const float* __restrict__ dirs, const float* __restrict__ wdir,
-    const float* __restrict__ wsum, const f4* __restrict__ W49, int L, int nsamp, int argmax_vis,
-    float* __restrict__ vis_out, unsigned long long* __restrict__ eval_count, unsigned* __restrict__ range_word) {
+struct XtTile {     // = V3Tile (vis_diffuse_v3.hip): record of a 16-sample tile of the global list
+  int point;        // -1: no such tile
+  int dir_base;     // first row of the point's chunk in dirs / Bd (chunk id * L * nsamp)
+};
+struct XtArgs {
+  // both forms
+  const float *A, *Bd;
+  const f4* W49;
+  int argmax_vis;
+  unsigned* range_word;
+  // one workgroup per point (STREAM = false)
+  const float *normals, *dirs, *wdir, *wsum;
+  const int* cid;
+  int L, nsamp;
+  float* vis_out;
+  unsigned long long* eval_count;
+  // persistent grid over the global tile list (STREAM = true; k_dvis3_cull / k_dvis3_reduce of vis_diffuse_v3.hip around it)
+  const unsigned short* pair_j;
+  const XtTile* tile_info;
+  const unsigned long long* counters;
+  float* pair_vis;
+};
+
+// STREAM = false: one workgroup per surface point, rounds of 128 of its front-facing directions (cull and per-lobe means in the kernel).
+// STREAM = true: a persistent grid walks the global list of 16-sample tiles eight tiles per round, whatever point they belong to:
+//   every tile has its own layer-0 point row (LDS-DMA into a wave-private slot during the previous round's head); the weight ring
+//   runs continuously across rounds; per-pair visibilities go to a global array.  The same instruction sequence per pair: the two
+//   forms are bit-identical.
+template <bool STREAM>
+__global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
   __shared__ f4 ring[XT_SLOTS * XT_WF4];   // 96 KB
   __shared__ f4 headw[XT_WF4];             // 24 KB: chunk 48 (256 -> 2 head, rows 2..15 zero)
   __shared__ f4 bias_tab[49 * 4];
-  __shared__ float vis_tab[XT_MAX_DIRS];
-  __shared__ unsigned short idx_list[XT_MAX_DIRS];
-  __shared__ f4 a_row[64];
+  // per point: vis_tab[4096] float | idx_list[4096] u16 | a_row[64] f4 = 25 KB; stream: a_rows [round parity][tile of the round][64] f4 = 16 KB
+  __shared__ f4 aux[(XT_MAX_DIRS * 4 + XT_MAX_DIRS * 2) / 16 + 64];
   __shared__ int s_count;
+  float* const vis_tab = reinterpret_cast<float*>(aux);
+  unsigned short* const idx_list = reinterpret_cast<unsigned short*>(aux + XT_MAX_DIRS / 4);
+  f4* const a_row = aux + (XT_MAX_DIRS * 6) / 16;
+  f4* const a_rows = aux;
+  const float* __restrict__ A = a.A;
+  const float* __restrict__ Bd = a.Bd;
+  const f4* __restrict__ W49 = a.W49;
+  const int argmax_vis = a.argmax_vis;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long p = blockIdx.x;
-  const int LS = L * nsamp;
-  const long dbase = (cid ? (long)cid[p] : 0L) * LS;
   const float negk = -2048.0f;
   constexpr float C11 = 1.0f / 2048.0f;
-  if (tid == 0) s_count = 0;
-  if (tid < 64) a_row[tid] = reinterpret_cast<const f4*>(A + p * 256)[tid];
+  // per-point form
+  const long p = blockIdx.x;
+  const int L = a.L, nsamp = a.nsamp, LS = L * nsamp;
+  long dbase = 0;
+  int S = 0, rounds = 0;
+  // stream form
+  const int G = gridDim.x;
+  long total_tiles = 0, total_rounds = 0;
   for (int i = tid; i < 49 * 4; i += 256) bias_tab[i] = W49[(long)(i >> 2) * XT_CF4 + (i & 3)];
   for (int i = tid; i < XT_WF4; i += 256) headw[i] = W49[48L * XT_CF4 + 4 + i];
+  if constexpr (STREAM) {
+    total_tiles = (long)a.counters[0];
+    total_rounds = (total_tiles + 7) >> 3;
+    __syncthreads();
+    if ((long)blockIdx.x >= total_rounds) return;           // workgroup-uniform
+    rounds = 1;
+  } else {
+  const float* __restrict__ normals = a.normals;
+  const float* __restrict__ dirs = a.dirs;
+  const int* __restrict__ cid = a.cid;
+  dbase = (cid ? (long)cid[p] : 0L) * LS;
+  if (tid == 0) s_count = 0;
+  if (tid < 64) a_row[tid] = reinterpret_cast<const f4*>(A + p * 256)[tid];
   for (int j = tid; j < LS; j += 256) vis_tab[j] = 0.f;
   __syncthreads();
   // ---- cull + compaction (order inside the list is irrelevant: results are scattered by direction index)
@@ -85,9 +133,10 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
     if (front) idx_list[base + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)j;
   }
   __syncthreads();
-  const int S = s_count;
-  if (tid == 0 && eval_count) atomicAdd(eval_count, (unsigned long long)S);
-  const int rounds = (S + 127) / 128;
+  S = s_count;
+  if (tid == 0 && a.eval_count) atomicAdd(a.eval_count, (unsigned long long)S);
+  rounds = (S + 127) / 128;
+  }
 
   // ---- weight ring state
   const unsigned ring_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ring);
@@ -184,27 +233,68 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
   // registers the next-layer operands have just left
   f4 raw[2][16];
   int jj[2], jjn[2];
-  auto fetch_rows = [&](int rd_next) {
+  // stream form: records of this wave's two tiles in the round after the current one (wave-uniform point / table base, per-lane
+  // direction index, 0xFFFF = padding), looked up at the top of a round and used by the fetches of its head
+  int tpn[2] = {-1, -1}, tbn[2] = {0, 0}, jn2[2] = {0xFFFF, 0xFFFF};
+  const unsigned arow_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)a_rows);
+  auto tile_lookup = [&](long round) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int si = rd_next * 128 + t * 64 + wave * 16 + (lane & 15);
-      jjn[t] = si < S ? (int)idx_list[si] : -1;
-      const int j = jjn[t] < 0 ? 0 : jjn[t];
-      const f4* brow = reinterpret_cast<const f4*>(Bd + (dbase + j) * 256) + g;
+      const long T = round * 8 + wave * 2 + t;
+      XtTile rec{-1, 0};
+      int j = 0xFFFF;
+      if (round < total_rounds && T < total_tiles) {
+        rec = a.tile_info[T];                                  // wave-uniform address: scalar load
+        j = (int)a.pair_j[T * 16 + (lane & 15)];
+      }
+      tpn[t] = __builtin_amdgcn_readfirstlane(rec.point);
+      tbn[t] = __builtin_amdgcn_readfirstlane(rec.dir_base);
+      jn2[t] = j;
+    }
+  };
+  auto fetch_rows = [&](long rd_next, int parity_next) {
+    if constexpr (STREAM) {
+      // the A rows of the next round's two tiles -> this wave's private slots by LDS-DMA (1 KB per tile): OLDER than the row loads
+      // below, whose wait the compiler places in front of the layer-0 split
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const long prow = tpn[t] < 0 ? 0L : (long)tpn[t];
+        xt_dma16(reinterpret_cast<const f4*>(A + prow * 256), (unsigned)lane * 16u,
+                 arow_b + (unsigned)(parity_next * 8 + wave * 2 + t) * 1024u);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      long row;
+      if constexpr (STREAM) {
+        jjn[t] = (tpn[t] < 0 || jn2[t] == 0xFFFF) ? -1 : jn2[t];
+        row = (long)tbn[t] + (jjn[t] < 0 ? 0 : jjn[t]);
+      } else {
+        const int si = (int)rd_next * 128 + t * 64 + wave * 16 + (lane & 15);
+        jjn[t] = si < S ? (int)idx_list[si] : -1;
+        row = dbase + (jjn[t] < 0 ? 0 : jjn[t]);
+      }
+      const f4* brow = reinterpret_cast<const f4*>(Bd + row * 256) + g;
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) raw[t][kb] = brow[kb * 4];
     }
   };
-  if (rounds > 0) fetch_rows(0);
-  for (int rd = 0; rd < rounds; ++rd) {
-    // ---- layer 0: relu(A[p] + Bd[dir]) straight into the operand registers
+  long rd = STREAM ? (long)blockIdx.x : 0L;
+  const long rd_end = STREAM ? total_rounds : (long)rounds, rd_step = STREAM ? (long)G : 1L;
+  int parity = 0;
+  if constexpr (STREAM) tile_lookup(rd);
+  if (rounds > 0) fetch_rows(rd, 0);
+  for (; rd < rd_end; rd += rd_step) {
+    if constexpr (STREAM) tile_lookup(rd + rd_step);
+    // ---- layer 0: relu(A[point] + Bd[dir]) straight into the operand registers
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       jj[t] = jjn[t];
+      const f4* arow = STREAM ? a_rows + (parity * 8 + wave * 2 + t) * 64 : a_row;
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {
         const f4 bv = raw[t][kb];
-        const f4 av = a_row[kb * 4 + g];
+        const f4 av = arow[kb * 4 + g];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           unsigned h, m, l;
@@ -347,7 +437,8 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
     // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias (fetched by the last chunk of layer 2) and the fragment
     // window already holds the first half of the next round's chunk 0.  Next round's rows are requested first: they arrive under
     // the head's MFMAs (clamped to this round's samples after the final round: harmless)
-    fetch_rows(rd + 1 < rounds ? rd + 1 : rd);
+    if constexpr (STREAM) fetch_rows(rd + rd_step, parity ^ 1);
+    else fetch_rows(rd + 1 < rd_end ? rd + 1 : rd, 0);
     {
       const u4* hw = reinterpret_cast<const u4*>(headw) + lane;
       SxAcc acc[2];
@@ -384,23 +475,36 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(
             const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
             v = e1 / (e0 + e1);
           }
-          vis_tab[jj[t]] = v;
+          if constexpr (STREAM) a.pair_vis[(rd * 8 + wave * 2 + t) * 16 + (lane & 15)] = v;
+          else vis_tab[jj[t]] = v;
         }
       }
     }
+    parity ^= 1;
   }
 #undef XT_MFMA
-  range_report<true>(sat, range_word);
+  range_report<true>(sat, a.range_word);
   // drain the ring (copies still target this workgroup's LDS)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid < L) {
-    const float* w = wdir + dbase + (long)tid * nsamp;
-    float acc = 0.f;
-    for (int k = 0; k < nsamp; ++k) acc += vis_tab[tid * nsamp + k] * w[k];
-    vis_out[p * L + tid] = acc / wsum[(cid ? cid[p] : 0) * L + tid];
+  if constexpr (!STREAM) {
+    if (tid < L) {
+      const float* w = a.wdir + dbase + (long)tid * nsamp;
+      float acc = 0.f;
+      for (int k = 0; k < nsamp; ++k) acc += vis_tab[tid * nsamp + k] * w[k];
+      a.vis_out[p * L + tid] = acc / a.wsum[(a.cid ? a.cid[p] : 0) * L + tid];
+    }
   }
 }
+
+// the cull / per-lobe reduce passes around the stream form: precision-agnostic, shared with the split-precision family (vis_diffuse_v3.hip)
+struct V3Tile;
+__global__ void k_dvis3_cull(const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ dirs, int LS,
+                             unsigned short* __restrict__ pair_j, V3Tile* __restrict__ tile_info, int2* __restrict__ point_info,
+                             unsigned long long* __restrict__ counters, unsigned long long* __restrict__ eval_count);
+__global__ void k_dvis3_reduce(const int* __restrict__ cid, long n, const float* __restrict__ wdir, const float* __restrict__ wsum,
+                               const unsigned short* __restrict__ pair_j, const float* __restrict__ pair_vis,
+                               const int2* __restrict__ point_info, int L, int nsamp, float* __restrict__ vis_out);
 
 }  // namespace rb
 
@@ -415,8 +519,42 @@ extern "C" int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long
   RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= XT_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
   RB_REQUIRE(scale_log2 == 0, "k_dvis_x6t takes weights packed with scale_log2 = 0");
-  hipLaunchKernelGGL(k_dvis_x6t, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, n, A, Bd, dirs, wdir,
-                     wsum, (const f4*)W49, L, nsamp, argmax_vis, vis_out, eval_count,
-                     range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr);
+  XtArgs a{};
+  a.A = A, a.Bd = Bd, a.W49 = (const f4*)W49, a.argmax_vis = argmax_vis;
+  a.range_word = range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr;
+  a.normals = normals, a.dirs = dirs, a.wdir = wdir, a.wsum = wsum, a.cid = chunk_id, a.L = L, a.nsamp = nsamp;
+  a.vis_out = vis_out, a.eval_count = eval_count;
+  hipLaunchKernelGGL(k_dvis_x6t<false>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("k_dvis_x6t");
+}
+
+extern "C" int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd,
+                                 const float* dirs, const float* wdir, const float* wsum, const float* W49, int L, int nsamp,
+                                 int argmax_vis, int scale_log2, unsigned short* pair_j, float* pair_vis, int* tile_info,
+                                 int* point_info, unsigned long long* counters, int n_workgroups, float* vis_out,
+                                 unsigned long long* eval_count, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
+  RB_REQUIRE(pair_j && pair_vis && tile_info && point_info && counters, "null scratch pointer");
+  RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each in the cull / reduce passes)");
+  RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= XT_MAX_DIRS && (L * nsamp) % 16 == 0,
+             "need L <= 256, L*nsamp <= 4096 and a multiple of 16");
+  RB_REQUIRE((long)n * (L * nsamp / 16) < (1L << 31), "tile index would overflow 31 bits");
+  RB_REQUIRE(scale_log2 == 0, "k_dvis_x6t takes weights packed with scale_log2 = 0");
+  hipStream_t s = (hipStream_t)stream;
+  if (n_workgroups <= 0) n_workgroups = device_cus();
+  RB_REQUIRE(n_workgroups > 0, "device query failed");
+  if (hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return rb::fail(__func__, "memset failed");
+  hipLaunchKernelGGL(k_dvis3_cull, dim3((unsigned)n), dim3(256), 0, s, normals, chunk_id, n, dirs, L * nsamp, pair_j,
+                     reinterpret_cast<V3Tile*>(tile_info), reinterpret_cast<int2*>(point_info), counters, eval_count);
+  if (int rc = check_launch("k_dvis3_cull")) return rc;
+  XtArgs a{};
+  a.A = A, a.Bd = Bd, a.W49 = (const f4*)W49, a.argmax_vis = argmax_vis;
+  a.range_word = range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr;
+  a.pair_j = pair_j, a.tile_info = reinterpret_cast<const XtTile*>(tile_info), a.counters = counters, a.pair_vis = pair_vis;
+  hipLaunchKernelGGL(k_dvis_x6t<true>, dim3((unsigned)n_workgroups), dim3(256), 0, s, a);
+  if (int rc = check_launch("k_dvis_x6t<stream>")) return rc;
+  hipLaunchKernelGGL(k_dvis3_reduce, dim3((unsigned)n), dim3(256), 0, s, chunk_id, n, wdir, wsum, pair_j, pair_vis,
+                     reinterpret_cast<const int2*>(point_info), L, nsamp, vis_out);
+  return check_launch("k_dvis3_reduce");
 }

@@ -1,6 +1,7 @@
 """Thin Python bindings over the C-ABI (include/robir_hip.h): allocate outputs with torch, pass raw pointers,
 sizes and the current HIP stream.  No arithmetic happens here."""
 import ctypes
+import os
 
 import torch
 
@@ -486,6 +487,7 @@ DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6", "f16x3-
 
 DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
 DVIS_STREAM_MAX_POINTS = 8192     # "f16x3-auto": launches up to this many surface points take the streaming family
+DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "f16x6-pt")      # what "f16x6" runs: f16x6-pt | f16x6-stream | f16x6-1t
 
 
 def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,
@@ -498,18 +500,22 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         # the CUs; at whole-view sizes the one-point-per-workgroup kernel is as fast and needs no scratch
         precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
     h3 = precision.startswith("f16x3")
-    assert h3 or precision in ("fp32", "f16x6", "f16x6-1t"), precision
+    X6 = ("f16x6", "f16x6-1t", "f16x6-pt", "f16x6-stream")
+    assert h3 or precision == "fp32" or precision in X6, precision
+    if precision == "f16x6":
+        precision = DVIS_X6_FORM
     # "f16x3-v2" = second-generation split-precision kernel: two tiles per wave, one workgroup per CU, head on the matrix
     # pipe (csrc/vis_diffuse_v2.hip); "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU,
-    # weights staged by LDS-DMA; "f16x6" = the v2 machine with exact three-piece operands (csrc/vis_diffuse_x6.hip)
-    code = {"fp32": 0, "f16x3": 5, "f16x3-v2": 7, "f16x3-v3": 8, "f16x6": 10, "f16x6-1t": 10}[precision]
+    # weights staged by LDS-DMA; "f16x6*" = exact three-piece operands: "-1t" round 3's one tile per wave, one workgroup per point
+    # (csrc/vis_diffuse_x6.hip); "-pt" two tiles per wave, one workgroup per point; "-stream" two tiles per wave, persistent grid
+    # over the global tile list (both csrc/vis_diffuse_x6t.hip, bit-identical to each other)
     n = normals.shape[0]
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
         assert chunk_id.dtype == torch.int32
-    if precision == "f16x3-v3":
-        # streaming form: global tile list + persistent grid (csrc/vis_diffuse_v3.hip); scratch sized for the worst case
-        # (every direction front-facing) so that nothing has to be read back to the host
+    if precision in ("f16x3-v3", "f16x6-stream"):
+        # streaming form: global tile list + persistent grid (csrc/vis_diffuse_v3.hip, vis_diffuse_x6t.hip); scratch sized for the
+        # worst case (every direction front-facing) so that nothing has to be read back to the host
         LS = L * nsamp
         dev = normals.device
         pair_j = torch.empty(n * LS, dtype=torch.int16, device=dev)
@@ -517,14 +523,14 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         tile_info = torch.empty(n * LS // 16, 2, dtype=torch.int32, device=dev)
         point_info = torch.empty(n, 2, dtype=torch.int32, device=dev)
         counters = torch.empty(2, dtype=torch.int64, device=dev)
-        call("rb_dvis_stream", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
-             ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
-             c_int(split["h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
+        x6 = precision == "f16x6-stream"
+        call("rb_dvis_stream_x6" if x6 else "rb_dvis_stream", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+             ptr(split["hidden_x6_head" if x6 else "hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(split["x6_head_scale_log2" if x6 else "h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
-    if precision in ("f16x6", "f16x6-1t"):
-        # "f16x6": two 16-sample tiles per wave (csrc/vis_diffuse_x6t.hip); "f16x6-1t": round 3's one-tile kernel (vis_diffuse_x6.hip)
-        call("rb_dvis_fused_x6t" if precision == "f16x6" else "rb_dvis_fused_x6", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+    if precision in X6:
+        call("rb_dvis_fused_x6" if precision == "f16x6-1t" else "rb_dvis_fused_x6t", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["x6_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
@@ -535,7 +541,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         return out
     call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
          ptr(split["hidden_h3"] if h3 else split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L),
-         c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(code), c_int(split["h3_scale_log2"] if h3 else 0),
+         c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(5 if h3 else 0), c_int(split["h3_scale_log2"] if h3 else 0),
          ptr(out), ptr(eval_count), stream_ptr())
     return out
 
