@@ -16,6 +16,8 @@
 #include "common.h"
 #include "mlp_engine.h"
 #include "x6_ring.h"
+#include "sdf_x6_layout.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef SX_PK
@@ -24,41 +26,6 @@
 
 namespace rb {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int SX_SLOT_B = 27 * 1024 + 512;      // K = 288: 27 KB of fragments (+ slack: the slot's last copy may start 1 KB early)
-__host__ __device__ constexpr int sx_K(int l) { return l == 0 ? 64 : (l == 4 ? 288 : 256); }
-__host__ __device__ constexpr int sx_nch(int l, int last) { return l == 3 ? 13 : (l == 8 ? last : 16); }
-__host__ __device__ constexpr int sx_nchunk(int last) { return 16 * 7 + 13 + last; }
-__host__ __device__ constexpr int sx_cbase(int l, int last) {
-  int n = 0;
-  for (int i = 0; i < l; ++i) n += sx_nch(i, last);
-  return n;
-}
-__host__ __device__ constexpr int sx_layer_of(int c, int last) {     // stream position (may run past the end once: cyclic) -> layer
-  const int N = sx_nchunk(last);
-  if (c >= N) c -= N;
-  int l = 0, first = 0;
-  for (int i = 0; i < 8; ++i) {
-    first += sx_nch(i, last);
-    if (c >= first) l = i + 1;
-  }
-  return l;
-}
-__host__ __device__ constexpr long sx_coff(int c, int last) {        // float4 offset of chunk c in the packed blob
-  const int N = sx_nchunk(last);
-  if (c >= N) c -= N;
-  long off = 0;
-  int first = 0, base = 0, kl = sx_K(0);
-  for (int i = 0; i < 8; ++i) {
-    first += sx_nch(i, last);
-    if (c >= first) {
-      off += (long)sx_nch(i, last) * sx_cf4(sx_K(i));
-      base = first;
-      kl = sx_K(i + 1);
-    }
-  }
-  return off + (long)(c - base) * sx_cf4(kl);
-}
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz, float in_scale, long M, const f4* __restrict__ Wp,
                                                     float out_scale, float* __restrict__ out0, f4* __restrict__ sig,
@@ -432,6 +399,9 @@ namespace {
 int sx_grid(long M, int n_workgroups) { return persistent_grid((M + 63) / 64, n_workgroups); }
 int sx_launch(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, float* sig, int n_workgroups,
               hipStream_t s) {
+  // round 4: two tiles per wave (sdf_x6t.hip); ROBIR_SDF_X6_TILES=1 keeps this file's one-tile kernel (A/B, bisecting)
+  static const char* const tiles = getenv("ROBIR_SDF_X6_TILES");
+  if (!(tiles && tiles[0] == '1')) return launch_sdf_x6t(x, M, in_scale, Wp, mode, out_scale, out0, sig, n_workgroups, s);
   const int grid = sx_grid(M, n_workgroups);
   if (grid <= 0) return rb::fail("rb_sdf_x6_points", "device query failed");
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;

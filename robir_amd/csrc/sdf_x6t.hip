@@ -1,0 +1,337 @@
+// NeuS SDF network (model/neus_model.py:385-438) with EXACT fp32 operands on the f16 matrix pipe, TWO 16-row tiles per wave -- the value
+// pass of the default precision policy, round 4 (x6t_engine.h has the machine; sdf_x6.hip is round 3's one-tile kernel, the arithmetic
+// and the stream layout are its own: three-piece operands, six products, one fp32 accumulator per weight class, the nine layers as ONE
+// cyclic stream of 142 / 126 chunks through a 4-slot LDS ring filled by LDS-DMA under counted waits).
+//
+// Persistent workgroups of four waves, rounds of 128 rows (wave w, tile t: rows 128 r + 64 t + 16 w ..).  Per chunk: s_waitcnt + s_barrier
+// at its top, K / 32 / WK parts of twelve MFMA runs (WK = 2 / 4 / 3 k-blocks for K = 64 / 256 / 288), the fragment window refilled piece
+// by piece, the copies of the chunk three ahead and the previous chunk's epilogue (softplus + exact three-way split of four value pairs:
+// twelve items) spread over the runs that carry no refill.  The biases of all chunks are resident in the LDS (9 KB), the encoded rows of
+// a round too (32 KB: the skip layer's input part is rebuilt from them, the operand registers are all taken).
+// MODE 0: signed distance only -> out0[M].   MODE 1: all 257 outputs -> out0[M,257].   MODE 5: MODE 1 + sigmoid(100 z) of every hidden
+// pre-activation -> sig [tile = row / 16][layer 8][chunk 16][lane 64] float4, the layout k_sdf_back_* read.
+// The products of a class are summed part by part, not product by product over the whole chunk as in k_sdf_x6: another fp32 summation
+// order, results differ from the one-tile kernel's in the last bits.
+#include "../../include/robir_hip.h"
+#include "common.h"
+#include "mlp_engine.h"
+#include "x6_ring.h"
+#include "sdf_x6_layout.h"
+#include "x6t_engine.h"
+#include <type_traits>
+
+namespace rb {
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xyz, float in_scale, long M, const f4* __restrict__ Wp,
+                                                     float out_scale, float* __restrict__ out0, f4* __restrict__ sig,
+                                                     unsigned* __restrict__ range_word) {
+  constexpr bool FULL = MODE != 0, STORE = MODE == 5;
+  constexpr int LAST = FULL ? 17 : 1, NCHUNK = sx_nchunk(LAST);
+  __shared__ f4 ring[4 * SX_SLOT_B / 16];              // 110 KB
+  __shared__ f4 bias_tab[NCHUNK * 4];                  // 9 KB: the 16 biases of every chunk of the stream
+  __shared__ float pe_scratch[4 * 2 * 16 * 64];        // 32 KB: [wave][tile][row 16][64 encoded inputs]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long nrounds = (M + 127) >> 7;
+  if ((long)blockIdx.x >= nrounds) return;
+
+  const float negk = -2048.0f, inv_sqrt2 = 0.70710678118654752440f;
+  constexpr float C11 = 1.0f / 2048.0f;
+  const unsigned ring_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)ring);
+  unsigned ring_lane = ring_b + (unsigned)lane * 16u;                  // + slot + fragment offset: the fragment reads
+  asm volatile("" : "+v"(ring_lane));
+  // first 1 KB piece of this wave's span of a chunk copy, per K of the stream
+  const int first64 = xt_span_first(64, wave), first256 = xt_span_first(256, wave), first288 = xt_span_first(288, wave);
+  auto span_first = [&](int K_) { return K_ == 64 ? first64 : (K_ == 256 ? first256 : first288); };
+  __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out0, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t sig_rsrc = __builtin_amdgcn_make_buffer_rsrc(sig, 0, 0, 0x00020000);
+  const int sig_wave = wave * (8 * 16 * 64 * 16);        // tile (4 t + wave) of the round: wave and t parts go into the scalar offset
+  unsigned slot_b[4] = {0u, (unsigned)SX_SLOT_B, 2u * SX_SLOT_B, 3u * SX_SLOT_B};
+  unsigned sat = 0u;
+  XtOps<9> P;                          // operands of the current layer (K <= 288), two tiles
+  XtOps<8> Q;                          // ... of the next layer
+  XtWin win;
+  const int rlocal = wave * 16 + (lane & 15);      // row of a tile's lane inside its half-round: row = 128 round + 64 tile + rlocal
+  long round = 0;
+  auto row_of = [&](int t) { return round * 128 + t * 64 + rlocal; };
+
+  for (int i = tid; i < NCHUNK * 4; i += 256) bias_tab[i] = Wp[sx_coff(i >> 2, LAST) + (i & 3)];
+
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+    unsigned h, m, l;
+    sx_split_pair(v0, v1, negk, h, m, l);
+    dh[q] = h;
+    dm[q] = m;
+    dl[q] = l;
+    sat = sat_acc(sat, h);
+  };
+  auto load_layer0 = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float x0[16];
+      load_features_pe10<false>(xyz, in_scale, row_of(t), M, lane, pe_scratch + (wave * 2 + t) * 1024, x0);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
+          put_pair(x0[i], x0[i + 1], P.h[t][kb], P.m[t][kb], P.l[t][kb], q);
+        }
+    }
+  };
+  // skip layer operands [softplus(h3) / sqrt 2 (13 blocks of 16) | x0 / sqrt 2 (4 blocks) | 0]: blocks 13..17 = k-block 6 second half .. 8,
+  // rebuilt from the round's encoded rows in the LDS (rows beyond M are zero like their first-layer operands)
+  auto load_skip_part = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool ok = row_of(t) < M;
+      const f4* fr4 = reinterpret_cast<const f4*>(pe_scratch + (wave * 2 + t) * 1024 + (lane & 15) * 64) + g;
+#pragma unroll
+      for (int b = 13; b < 18; ++b) {
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (b < 17) v = fr4[(b - 13) * 4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int q = (b & 1) * 2 + p;
+          const float v0 = ok ? v[2 * p] : 0.f, v1 = ok ? v[2 * p + 1] : 0.f;
+          put_pair(v0 * inv_sqrt2, v1 * inv_sqrt2, P.h[t][b >> 1], P.m[t][b >> 1], P.l[t][b >> 1], q);
+        }
+      }
+    }
+  };
+
+  auto run_layer = [&](auto LI_tag, int cb, int lrt) {
+    constexpr int LI = decltype(LI_tag)::value;
+    constexpr int K = sx_K(LI), NCH = sx_nch(LI, LAST), CB = sx_cbase(LI, LAST);
+    constexpr int WK = xt_wk(K), NPART = xt_parts(K), NFREE = 9 * NPART;
+    constexpr bool OUT = LI == 8, SKIPOUT = LI == 3;
+    constexpr int KN = sx_K(LI == 8 ? 0 : LI + 1), WKN = xt_wk(KN);
+    static_assert((NCH * NPART) % 2 == 0, "a layer has an even number of parts");
+    SxAcc acc[2], prev[2];
+    const f4* wl = Wp + sx_coff(cb, LAST);
+    const f4* wnext[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wnext[i] = Wp + sx_coff(cb + NCH + i, LAST);
+    asm volatile("" : "+s"(wl));
+    auto bias_of = [&](int c) {      // c = stream position (may run past the end once)
+      const int cc = c >= NCHUNK ? c - NCHUNK : c;
+      return bias_tab[cc * 4 + g];
+    };
+    auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
+    // epilogue of hidden chunk pj, twelve items: per value pair (tile t, register pair q) A0 / A1 = softplus (+ its sigmoid in MODE 5) of
+    // its two values, B = exact three-way split into the next layer's operand registers (+ the tile's sigmoid store behind its second pair)
+    float ev[4][2], z[2][4];
+    float sg[4][2];
+    int pj_of_items = 0;
+    // Z = the three classes of a tile's four values combined (frees the previous chunk's accumulators early)
+    auto item_z = [&](int t, const SxAcc& a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[t][r] = combine(a, r);
+    };
+    auto item_a = [&](int i, int e) {
+      const int t = i >> 1, q = i & 1;
+      float s;
+      float v = softplus100_fast(z[t][2 * q + e], &s);      // no log1p correction: |error| <= 4e-10 (mlp_engine.h)
+      if (SKIPOUT) v *= inv_sqrt2;
+      ev[i][e] = v;
+      sg[i][e] = s;
+      if constexpr (STORE)
+        if (e == 1) {    // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
+          typedef unsigned u2v __attribute__((ext_vector_type(2)));
+          unsigned voff;       // lane 16, re-derived (x6t_engine.h: xt_copy_piece)
+          asm volatile("v_subrev_u32 %0, %1, %2" : "=v"(voff) : "s"(ring_b), "v"(ring_lane));
+          int sbase = sig_wave + lrt * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
+          asm volatile("" : "+s"(sbase));
+          __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])}, sig_rsrc,
+                                                (int)voff, sbase + (t * 4 * 8 * 16 + pj_of_items) * 1024 + q * 8, 0);
+        }
+    };
+    auto item_b = [&](int i, int pj) {
+      const int t = i >> 1, q = i & 1;
+      put_pair(ev[i][0], ev[i][1], Q.h[t][pj >> 1], Q.m[t][pj >> 1], Q.l[t][pj >> 1], (pj & 1) * 2 + q);
+    };
+    // outputs through a buffer descriptor over the round's valid rows: lanes beyond it (rows >= M, columns >= 257) are dropped by the
+    // bounds check, no branch splits the chunk
+    auto output_tile = [&](int t, int pj) {
+      // byte offset of (row, column 4 g) inside the round's rows: ONE register per tile, the chunk / register part of the column goes
+      // into the instruction (17 x 4 x 2 loop-invariant offsets would be hoisted out of the round loop and spilled)
+      int base = FULL ? ((t * 64 + rlocal) * 257 + 4 * g) * 4 : (t * 64 + rlocal) * 4;
+      asm volatile("" : "+v"(base));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = combine(prev[t], r) * out_scale;
+        if constexpr (FULL) {
+          if (pj < 16) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, base, pj * 64 + r * 4, 0);
+          else if (r == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, g == 0 ? base : -1, pj * 64, 0);
+        } else {
+          if (pj == 0 && r == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, g == 0 ? base : -1, 0, 0);
+        }
+      }
+    };
+    constexpr int NE = OUT ? 2 : 13;
+    // item order: the second tile's combine (the first tile's went behind the chunk's own last run: its accumulators were complete), then
+    // per pair the two softplus halves with the previous pair's split one pair behind
+    auto ep_item = [&](int s, int pj) {
+      pj_of_items = pj;
+      if constexpr (OUT) {
+        output_tile(s, pj);
+      } else {
+        switch (s) {
+          case 0: item_z(1, prev[1]); break;
+          case 1: item_a(0, 0); break;
+          case 2: item_a(0, 1); break;
+          case 3: item_a(1, 0); break;
+          case 4: item_a(1, 1); break;
+          case 5: item_b(0, pj); break;
+          case 6: item_a(2, 0); break;
+          case 7: item_a(2, 1); break;
+          case 8: item_b(1, pj); break;
+          case 9: item_a(3, 0); break;
+          case 10: item_a(3, 1); break;
+          case 11: item_b(2, pj); break;
+          default: item_b(3, pj); break;
+        }
+      }
+    };
+    f4 bias = bias_of(cb);
+#pragma unroll
+    for (int jb = 0; jb < NCH; ++jb) {
+      // chunk jb+1 has landed once at most this wave's copies of chunk jb+2 are in flight (stores of the epilogue, younger, only make the
+      // wait stricter); past the barrier every wave has finished with chunk jb-1, whose slot the copies of chunk jb+3 reuse
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int K2 = jb + 2 < NCH ? K : sx_K(sx_layer_of(CB + jb + 2, LAST));
+      if (sx_nsw(K2) >= 7) sx_wait<7>();
+      else if (sx_nsw(K2) >= 6) sx_wait<6>();
+      else sx_wait<2>();
+#ifndef SXT_NOBAR
+      __builtin_amdgcn_s_barrier();
+#endif
+      asm volatile("" ::: "memory");
+      const int K3 = jb + 3 < NCH ? K : sx_K(sx_layer_of(CB + jb + 3, LAST));
+      const int NC3 = sx_nsw(K3);
+      const int f3 = span_first(K3);
+      const f4* src3 = (jb + 3 < NCH ? wl + (long)(jb + 3) * sx_cf4(K) : wnext[jb + 3 - NCH < 3 ? jb + 3 - NCH : 0]) + 4 + f3 * 64;
+      const unsigned dst3 = ring_b + slot_b[(jb + 3) & 3] + (unsigned)f3 * 1024u;
+      acc[0].c0 = bias;
+      acc[1].c0 = bias;
+      acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
+      const int ne = jb > 0 ? NE : 0, ni = ne + NC3;
+      auto filler = [&](int pos) {
+        const int a = xt_free_index(pos);
+        if (a < 0) return;
+#pragma unroll
+        for (int i = 0; i < 22; ++i)
+          if (i < ni && xt_item_slot(i, ni, NFREE) == a) {
+            if (i < ne) ep_item(i, jb - 1);
+            else {
+#ifndef SXT_NODMA
+              xt_copy_piece(i - ne, src3, ring_lane, ring_b, dst3);
+#endif
+            }
+          }
+      };
+      auto refill = [&](int piece, int part) {
+        const bool down = ((jb * NPART + part) & 1) != 0;
+        int slot, kb_first, count;
+        if (part + 1 < NPART) {
+          slot = jb & 3, kb_first = (part + 1) * WK, count = WK;
+        } else {
+          slot = (jb + 1) & 3, kb_first = 0, count = jb + 1 < NCH ? WK : WKN;
+        }
+#ifndef SXT_NOREAD
+        xt_request(piece == 0 ? win.h : (piece == 1 ? win.m : win.l), ring_lane + slot_b[slot], kb_first, count, piece, down);
+#endif
+      };
+      xt_chunk<K, 9>(jb * NPART, acc, win, P, filler, refill);
+      if constexpr (OUT) prev[0] = acc[0];
+      else item_z(0, acc[0]);
+      prev[1] = acc[1];
+      bias = bias_of(cb + jb + 1);
+    }
+    {   // slot 0 = the slot of the next layer's first chunk
+      constexpr int R = NCH & 3;
+      unsigned a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = slot_b[(i + R) & 3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slot_b[i] = a[i];
+    }
+#pragma unroll
+    for (int s = 0; s < NE; ++s) ep_item(s, NCH - 1);
+    if constexpr (!OUT) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+          if (SKIPOUT && kb == 6) {          // second half of k-block 6 and blocks 7, 8: load_skip_part
+            P.h[t][kb][0] = Q.h[t][kb][0], P.h[t][kb][1] = Q.h[t][kb][1];
+            P.m[t][kb][0] = Q.m[t][kb][0], P.m[t][kb][1] = Q.m[t][kb][1];
+            P.l[t][kb][0] = Q.l[t][kb][0], P.l[t][kb][1] = Q.l[t][kb][1];
+          } else if (!(SKIPOUT && kb > 6)) {
+            P.h[t][kb] = Q.h[t][kb];
+            P.m[t][kb] = Q.m[t][kb];
+            P.l[t][kb] = Q.l[t][kb];
+          }
+        }
+      if constexpr (SKIPOUT) load_skip_part();
+    }
+  };
+
+  // ---- prologue: chunks 0, 1, 2 of the stream (layer 0: K = 64, two pieces per wave), the first fragment window
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      xt_copy_piece(i, Wp + sx_coff(c, LAST) + 4 + first64 * 64, ring_lane, ring_b, ring_b + slot_b[c] + (unsigned)first64 * 1024u);
+  sx_wait<0>();
+  __syncthreads();
+  xt_request(win.h, ring_lane + slot_b[0], 0, 2, 0, true);
+  xt_request(win.m, ring_lane + slot_b[0], 0, 2, 1, true);
+  xt_request(win.l, ring_lane + slot_b[0], 0, 2, 2, true);
+
+  for (round = blockIdx.x; round < nrounds; round += gridDim.x) {
+    {
+      const long row0 = round * 128, rows = M - row0 < 128 ? M - row0 : 128;
+      out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out0 + row0 * (FULL ? 257 : 1), 0, (int)rows * (FULL ? 257 : 1) * 4, 0x00020000);
+      if constexpr (STORE) sig_rsrc = __builtin_amdgcn_make_buffer_rsrc(sig + round * (8L * 8 * 16 * 64), 0, 8 * 8 * 16 * 64 * 16, 0x00020000);
+    }
+    load_layer0();
+    // layer 0 | 1, 2 (one instance) | 3 (skip layer's own outputs) | 4 (K = 288) | 5, 6 (a second copy of the instance of 1, 2) | 7 | 8:
+    // straight-line, so that the skip layer's ninth k-block is live between layers 3 and 4 only (inside one loop over all nine layers it is
+    // carried through every iteration: 24 registers this kernel does not have)
+    run_layer(std::integral_constant<int, 0>{}, 0, 0);
+#pragma unroll 1
+    for (int l = 1; l < 3; ++l) run_layer(std::integral_constant<int, 1>{}, 16 * l, l);
+    run_layer(std::integral_constant<int, 3>{}, 48, 3);
+    run_layer(std::integral_constant<int, 4>{}, 61, 4);
+#pragma unroll 1
+    for (int l = 5; l < 7; ++l) run_layer(std::integral_constant<int, 1>{}, 16 * (l - 1) + 13, l);
+    run_layer(std::integral_constant<int, 7>{}, 109, 7);
+    run_layer(std::integral_constant<int, 8>{}, 125, 8);
+  }
+  range_report(sat, range_word);
+  sx_wait<0>();
+  __syncthreads();
+}
+
+}  // namespace rb
+
+using namespace rb;
+
+namespace rb {
+int launch_sdf_x6t(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, float* sig,
+                   int n_workgroups, hipStream_t s) {
+  const int grid = persistent_grid((M + 127) / 128, n_workgroups);
+  if (grid <= 0) return rb::fail("rb_sdf_x6_points", "device query failed");
+  unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;
+  const f4* W = (const f4*)Wp;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(k_sdf_x6t<0>, dim3(grid), dim3(256), 0, s, x, in_scale, M, W, out_scale, out0, (f4*)nullptr, rw); break;
+    case 1: hipLaunchKernelGGL(k_sdf_x6t<1>, dim3(grid), dim3(256), 0, s, x, in_scale, M, W, out_scale, out0, (f4*)nullptr, rw); break;
+    default: hipLaunchKernelGGL(k_sdf_x6t<5>, dim3(grid), dim3(256), 0, s, x, in_scale, M, W, out_scale, out0, (f4*)sig, rw); break;
+  }
+  return check_launch("k_sdf_x6t");
+}
+}  // namespace rb
