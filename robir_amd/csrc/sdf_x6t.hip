@@ -108,6 +108,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     constexpr bool OUT = LI == 8, SKIPOUT = LI == 3;
     constexpr int KN = sx_K(LI == 8 ? 0 : LI + 1), WKN = xt_wk(KN);
     static_assert((NCH * NPART) % 2 == 0, "a layer has an even number of parts");
+    constexpr int PNCH = sx_nch(LI == 0 ? 8 : LI - 1, LAST);      // chunks of the layer that runs before this one (layer 8 of the previous round)
+    // stores of the epilogue of chunk pj (pj < 0: no such chunk) of an output / a hidden layer
+    auto ep_stores = [](bool out_layer, int pj) {
+      if (pj < 0) return 0;
+      if (out_layer) return FULL ? (pj < 16 ? 8 : 2) : (pj == 0 ? 2 : 0);
+      return STORE ? 4 : 0;
+    };
     SxAcc acc[2], prev[2];
     const f4* wl = Wp + sx_coff(cb, LAST);
     const f4* wnext[3];
@@ -139,10 +146,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       if constexpr (STORE)
         if (e == 1) {    // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
           typedef unsigned u2v __attribute__((ext_vector_type(2)));
-          unsigned voff;       // lane 16, re-derived (x6t_engine.h: xt_copy_piece)
-          asm volatile("v_subrev_u32 %0, %1, %2" : "=v"(voff) : "s"(ring_b), "v"(ring_lane));
+          const unsigned voff = xt_lane16<0>();       // re-derived: x6t_engine.h
           int sbase = sig_wave + lrt * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
           asm volatile("" : "+s"(sbase));
+#ifdef SXT_ABL_STORE_FIXED              // timing ablation (wrong results): every sigmoid store of a wave goes to the same kilobyte
+          sbase = sig_wave - (t * 4 * 8 * 16 + pj_of_items) * 1024 - q * 8;
+#endif
           __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])}, sig_rsrc,
                                                 (int)voff, sbase + (t * 4 * 8 * 16 + pj_of_items) * 1024 + q * 8, 0);
         }
@@ -202,9 +211,27 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       constexpr int dummy = 0;
       (void)dummy;
       const int K2 = jb + 2 < NCH ? K : sx_K(sx_layer_of(CB + jb + 2, LAST));
-      if (sx_nsw(K2) >= 7) sx_wait<7>();
-      else if (sx_nsw(K2) >= 6) sx_wait<6>();
-      else sx_wait<2>();
+      // ... plus the stores of the epilogue items that ran beside them (exact: every store is issued, lanes out of range are dropped by
+      // the descriptor): the previous chunk carried the epilogue of the chunk before it; a layer's first chunk follows the previous
+      // layer's last chunk AND the tail epilogue of that chunk
+      int ns = 0;
+      if (jb >= 2) ns = ep_stores(OUT, jb - 2);
+      else if (jb == 0) ns = ep_stores(LI == 0, PNCH - 2) + ep_stores(LI == 0, PNCH - 1);
+      switch (sx_nsw(K2) + ns) {
+        case 2: sx_wait<2>(); break;
+        case 4: sx_wait<4>(); break;
+        case 6: sx_wait<6>(); break;
+        case 7: sx_wait<7>(); break;
+        case 8: sx_wait<8>(); break;
+        case 10: sx_wait<10>(); break;
+        case 11: sx_wait<11>(); break;
+        case 12: sx_wait<12>(); break;
+        case 14: sx_wait<14>(); break;
+        case 15: sx_wait<15>(); break;
+        case 16: sx_wait<16>(); break;
+        case 18: sx_wait<18>(); break;
+        default: sx_wait<2>(); break;      // any combination not listed: the strictest wait (safe)
+      }
 #ifndef SXT_NOBAR
       __builtin_amdgcn_s_barrier();
 #endif
@@ -214,11 +241,15 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       const int f3 = span_first(K3);
       const f4* src3 = (jb + 3 < NCH ? wl + (long)(jb + 3) * sx_cf4(K) : wnext[jb + 3 - NCH < 3 ? jb + 3 - NCH : 0]) + 4 + f3 * 64;
       const unsigned dst3 = ring_b + slot_b[(jb + 3) & 3] + (unsigned)f3 * 1024u;
+      f4 nbias;
       acc[0].c0 = bias;
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
       const int ne = jb > 0 ? NE : 0, ni = ne + NC3;
       auto filler = [&](int pos) {
+        // the next chunk's bias, requested BEFORE the last part's fragment requests: behind them, its use at the top of the next chunk
+        // would wait for all of them (lgkmcnt(0))
+        if (pos == 12 * (NPART - 1)) nbias = bias_of(cb + jb + 1);
         const int a = xt_free_index(pos);
         if (a < 0) return;
 #pragma unroll
@@ -227,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
             if (i < ne) ep_item(i, jb - 1);
             else {
 #ifndef SXT_NODMA
-              xt_copy_piece(i - ne, src3, ring_lane, ring_b, dst3);
+              xt_copy_piece(i - ne, src3, dst3);
 #endif
             }
           }
@@ -248,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       if constexpr (OUT) prev[0] = acc[0];
       else item_z(0, acc[0]);
       prev[1] = acc[1];
-      bias = bias_of(cb + jb + 1);
+      bias = nbias;
     }
     {   // slot 0 = the slot of the next layer's first chunk
       constexpr int R = NCH & 3;
@@ -284,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      xt_copy_piece(i, Wp + sx_coff(c, LAST) + 4 + first64 * 64, ring_lane, ring_b, ring_b + slot_b[c] + (unsigned)first64 * 1024u);
+      xt_copy_piece(i, Wp + sx_coff(c, LAST) + 4 + first64 * 64, ring_b + slot_b[c] + (unsigned)first64 * 1024u);
   sx_wait<0>();
   __syncthreads();
   xt_request(win.h, ring_lane + slot_b[0], 0, 2, 0, true);

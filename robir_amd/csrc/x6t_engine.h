@@ -41,23 +41,30 @@ __device__ __forceinline__ void xt_dma16_imm(const f4* gbase_uniform, unsigned l
                "s"(gbase_uniform), "n"(OFF)
                : "memory");
 }
-// piece i (0 .. sx_nsw(K) - 1) of this wave's span of a chunk copy; src / dst already point at the span's first piece.  The per-lane byte
-// offset (lane 16, + 4096 for pieces 4..7) is re-derived for every copy from the register the fragment reads use all the time
-// (ring_lane = LDS address of the ring + lane 16): a dedicated offset register is long-lived and rarely used -- the first thing the
-// register allocator spills in these 512-register kernels, and its reload (a scratch load) drains the whole copy queue.
-__device__ __forceinline__ void xt_copy_piece(int i, const f4* src_span, unsigned ring_lane, unsigned ring_base, unsigned dst_span) {
-  unsigned voff;
-  if (i < 4) asm volatile("v_subrev_u32 %0, %1, %2" : "=v"(voff) : "s"(ring_base), "v"(ring_lane));
-  else asm volatile("v_subrev_u32 %0, %1, %2" : "=v"(voff) : "s"(ring_base - 4096u), "v"(ring_lane));
+// lane 16 (+ extra) from no live register at all: a per-lane byte offset kept in a register is long-lived and rarely used -- the first
+// thing the register allocator spills in these 512-register kernels, and every reload of it (a scratch load) drains the whole copy
+// queue (s_waitcnt vmcnt(0)); a value re-derived from a register the fragment reads use (ring address + lane 16) got that register's
+// live range split and spilled the same way.  Three vector instructions per copy instead.
+template <int EXTRA>
+__device__ __forceinline__ unsigned xt_lane16() {
+  unsigned v;
+  if constexpr (EXTRA == 0)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 4, %0" : "=v"(v));
+  else
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 4, %1" : "=v"(v) : "s"(EXTRA));
+  return v;
+}
+// piece i (0 .. sx_nsw(K) - 1) of this wave's span of a chunk copy; src / dst already point at the span's first piece
+__device__ __forceinline__ void xt_copy_piece(int i, const f4* src_span, unsigned dst_span) {
   switch (i) {
-    case 0: xt_dma16_imm<0>(src_span, voff, dst_span); break;
-    case 1: xt_dma16_imm<1024>(src_span, voff, dst_span); break;
-    case 2: xt_dma16_imm<2048>(src_span, voff, dst_span); break;
-    case 3: xt_dma16_imm<3072>(src_span, voff, dst_span); break;
-    case 4: xt_dma16_imm<0>(src_span, voff, dst_span + 4096u); break;
-    case 5: xt_dma16_imm<1024>(src_span, voff, dst_span + 4096u); break;
-    case 6: xt_dma16_imm<2048>(src_span, voff, dst_span + 4096u); break;
-    default: xt_dma16_imm<3072>(src_span, voff, dst_span + 4096u); break;
+    case 0: xt_dma16_imm<0>(src_span, xt_lane16<0>(), dst_span); break;
+    case 1: xt_dma16_imm<1024>(src_span, xt_lane16<0>(), dst_span); break;
+    case 2: xt_dma16_imm<2048>(src_span, xt_lane16<0>(), dst_span); break;
+    case 3: xt_dma16_imm<3072>(src_span, xt_lane16<0>(), dst_span); break;
+    case 4: xt_dma16_imm<0>(src_span, xt_lane16<4096>(), dst_span + 4096u); break;
+    case 5: xt_dma16_imm<1024>(src_span, xt_lane16<4096>(), dst_span + 4096u); break;
+    case 6: xt_dma16_imm<2048>(src_span, xt_lane16<4096>(), dst_span + 4096u); break;
+    default: xt_dma16_imm<3072>(src_span, xt_lane16<4096>(), dst_span + 4096u); break;
   }
 }
 // first piece of wave w's span: min(w NSW, NS - NSW) (the last wave's span is shifted back into the chunk: a few pieces are copied twice)

@@ -5,6 +5,7 @@ runs on the device (rb_pack_layer); this module only decides layer order, paddin
 Weight-norm (model/neus_model.py:378-379) is folded once here: W = g * v / |v|_row.
 """
 import ctypes
+import os
 
 import torch
 
@@ -259,6 +260,8 @@ def pack_sdf_back_x6(sd, device):
     mats = [W[7].t(), W[6].t(), W[5].t(), m4, W[3].t(), W[2].t(), W[1].t(), W[0].t()]
     ls = [dict(W=m.contiguous(), b=None, n_pad=_pad16(m.shape[0]), k_pad=_pad32(m.shape[1]), perm=None) for m in mats]
     assert [l["n_pad"] for l in ls] == [256, 256, 256, 272, 256, 256, 256, 64] and ls[4]["k_pad"] == 224
+    if os.environ.get("ROBIR_SDF_X6_TILES") != "1":
+        ls[4]["k_pad"] = 256       # k_sdf_back_x6t (two tiles per wave, csrc/sdf_back_x6t.hip): every chunk of the stream has one shape
     blob = pack_layers_x6(ls, device, scale_log2=0)
     return torch.cat([blob, torch.zeros(2048, device=device)]), W[8][0].contiguous().to(device)
 
