@@ -41,8 +41,10 @@ sys.path.insert(0, ROOT)
 VIS_MACS_PER_EVAL = 229376          # 126*256 + 3*256*256 + 256*2
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
-# HBM bytes per (point, direction) pair: (2 x FETCH_SIZE + WRITE_SIZE) / pairs at 32 chunks per launch, profiles/r03_pmc_summary.md
-TRAFFIC_B_PER_PAIR = {"f16x6": 39.3, "default": 22.1}
+# HBM bytes per (point, direction) pair: (2 x FETCH_SIZE + WRITE_SIZE) / pairs at 32 chunks per launch.  DERIVED, not a counter of the
+# timed run (PMC passes cannot run inside the timed region): f16x6 from the PMC passes of this round's kernel
+# (profiles/r04_dvis_x6t_pmc.md), the split-precision kernel from profiles/r03_pmc_summary.md
+TRAFFIC_B_PER_PAIR = {"f16x6": 33.0, "default": 22.1}
 H = W = 800
 CHUNK = 1024
 
@@ -268,6 +270,55 @@ def vis_peak(vis):
     return PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)"
 
 
+def runner_loop_replay(model, uv_d, pose_d, K_d, hdr, chunk=1024):
+    """train_pbr.py:248-285 in its own shape: per 1024-pixel chunk one forward(), a few tone-mapped / detached fields kept, merged, read."""
+    from robir_amd import deferred
+    N = uv_d.shape[0]
+    mask = torch.ones(1, N, dtype=torch.bool, device=uv_d.device)
+    best = None
+    with torch.no_grad():
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = []
+            for a in range(0, N, chunk):
+                sl = slice(a, min(N, a + chunk))
+                out = model({"uv": uv_d[None, sl], "pose": pose_d[None], "intrinsics": K_d[None], "object_mask": mask[:, sl],
+                             "hdr_shift": hdr[sl]}, trainstage="Material", train_spec=True)
+                res.append({"sg_rgb": out["sg_rgb"].detach(), "indir_rgb": out["indir_rgb"].detach(), "vis_shadow": out["vis_shadow"].detach(),
+                            "normal_map": out["normal_map"].detach(), "network_object_mask": out["network_object_mask"].detach()})
+            merged = {k: torch.cat([r[k] for r in res], 0) for k in res[0]}
+            host = {k: v.cpu() for k, v in merged.items()}
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    assert host["sg_rgb"].shape[0] == N
+    return {"value": N / best, "unit": "rays/s", "ms_per_view": best * 1e3, "chunks": (N + chunk - 1) // chunk,
+            "deferred_chunks": int(model.__dict__.get("deferred_chunks", deferred.DEFAULT_CHUNKS)),
+            "note": "unchanged call shape of the runners' plot loop, default settings; best of 2"}
+
+
+def rccl_selfcheck(parallel, dev):
+    import socket
+    import torch.distributed as dist
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        parallel.init_distributed("nccl", dev)
+        tiles = torch.rand(2048, 17, device=dev)
+        ok = bool(torch.equal(parallel.gather_image(tiles, 2, 1024), tiles))
+        res = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "device": str(dev), "tile_gather_ok": ok}
+        dist.destroy_process_group()
+        return res
+    except Exception as e:  # noqa: BLE001   (reported, not fatal: the one-GPU measurement does not depend on it)
+        return {"error": repr(e)[:200]}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -283,18 +334,19 @@ def main():
     if os.environ.get("ROBIR_SHARE_GPU") == "1":
         local = 0
     backend = os.environ.get("ROBIR_DIST_BACKEND", "nccl")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    from robir_amd import ops, renderer, synth, sg_render, parallel
+    dev = parallel.bind_device(share_gpu=os.environ.get("ROBIR_SHARE_GPU") == "1")       # cuda:LOCAL_RANK
+    assert dev.index == local
     dist = None
+    rccl_check = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        parallel.init_distributed(backend, dev)
+    elif backend == "nccl" and os.environ.get("ROBIR_RCCL_SELFCHECK", "1") == "1":
+        # one GPU: run the tile gather once through RCCL with a process group of one rank (outside the timed region), so that the line
+        # says whether the collective backend of the multi-GPU path loads and runs on this box
+        rccl_check = rccl_selfcheck(parallel, dev)
 
-    from robir_amd import ops, renderer, synth, sg_render, parallel
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_configs
     vis_mode, mlp_mode, dtype = set_precision(args.precision, os.environ.get("ROBIR_VIS_PRECISION") or args.vis_precision)
@@ -376,7 +428,8 @@ def main():
                 # correction) + WRITE_SIZE on this kernel family (profiles/), scaled to this launch's pair count: well under
                 # 1 % of the HBM roofline -- the bound is the matrix pipe
                 "traffic": TRAFFIC_B_PER_PAIR.get(vis, TRAFFIC_B_PER_PAIR["default"]) * evals / max(k_n, 1),
-                "traffic_unit": "B/launch (scaled from the PMC profile)",
+                "traffic_unit": "B/launch -- DERIVED: bytes per pair of a separate PMC pass of the same kernel build (2 x FETCH_SIZE + WRITE_SIZE, "
+                                "profiles/r04_dvis_x6t_pmc.md) x the pairs of this launch; not a counter of the timed run",
                 "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                 "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
@@ -444,6 +497,7 @@ def main():
                        "octree_nodes": model.ray_tracer.sdf_octree.tables.B, "precision": args.precision, "scene": args.scene,
                        "visibility_kernel": vis_mode, "mlp_kernels": mlp_mode,
                        "ranks": world, "collective_backend": (("rccl (torch 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
+                       "rccl_selfcheck_world1": rccl_check,
                        "ranks_share_one_gpu": os.environ.get("ROBIR_SHARE_GPU") == "1" and world > 1,
                        "parallelism": f"chunk-shard x{world} of one view + all-gather"},
             "roofline": roofline if octree_line is None else octree_line,
@@ -534,6 +588,31 @@ def main():
         line["configs_note"] = ("BASELINE.json configs 1, 2, 3, 5 (tools/bench_configs.py), best of 2 repetitions after a warm-up "
                                 "(config 5: one pass over a band of chunks; `--config 5` times all 1875), single GPU, each with "
                                 "the roofline of the op that dominates it from HIP events around that op")
+    if world == 1 and not args.no_configs and args.vis == "mlp":
+        # Three figures that used to be builder-only, outside the timed region, default settings:
+        # (1) the whole BASELINE config 5 view, all 1875 chunks chunk by chunk (the `configs` entry above is a band of them)
+        extras = {}
+        with torch.no_grad():
+            r5 = bench_configs.CONFIGS[5](model, reps=1, first=0, nch=1875)
+        extras["config5_all_1875_chunks"] = {k: r5[k] for k in ("workload", "value", "unit", "ms") if k in r5}
+        # (2) the same 800x800 view with TRACED light visibility (the reference's `trace_vis` switch: OctreeVisModel as VisModel)
+        from robir_amd.octree_tracing import OctreeVisModel
+        mlp_vis = model.visibility_network
+        model.visibility_network = OctreeVisModel(model.octree_ray_tracer)
+        try:
+            def step_ov():
+                return parallel.render_view_sharded(model, uv_d, pose_d, K_d, hdr, CHUNK, plan=plan)
+            step_ov()
+            t_ov, _ = timed(step_ov, 2)
+        finally:
+            model.visibility_network = mlp_vis
+        extras["traced_visibility"] = {"value": H * W * 2 / t_ov, "unit": "rays/s", "steps": 2, "ms_per_step": t_ov / 2 * 1e3,
+                                       "note": "`bench.py --vis octree` prints this mode as its own line with its roofline"}
+        # (3) the reference's own call shape: the runners' plot loop (training/train_pbr.py:248-285) -- split_input into 1024-pixel
+        # chunks, one forward() per chunk, merge_output, read the image -- replayed with DEFAULT settings (eval-mode chunk forwards
+        # are recorded and run as passes of model.deferred_chunks chunks: robir_amd/deferred.py)
+        extras["runner_plot_loop"] = runner_loop_replay(model, uv_d, pose_d, K_d, hdr)
+        line["extras"] = extras
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline_chunks, uv, pose, K)

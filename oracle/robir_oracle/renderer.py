@@ -14,9 +14,31 @@ from . import nets, sg, octree as octree_mod, neus
 
 
 # ----------------------------------------------------------------------------- camera
+def quat_to_rot(q):
+    """rend_util.py:107-124: [B,4] (qr, qi, qj, qk), normalised first -> [B,3,3]."""
+    q = F.normalize(q, dim=1)
+    qr, qi, qj, qk = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.ones(q.shape[0], 3, 3, dtype=q.dtype)
+    R[:, 0, 0] = 1 - 2 * (qj ** 2 + qk ** 2)
+    R[:, 0, 1] = 2 * (qj * qi - qk * qr)
+    R[:, 0, 2] = 2 * (qi * qk + qr * qj)
+    R[:, 1, 0] = 2 * (qj * qi + qk * qr)
+    R[:, 1, 1] = 1 - 2 * (qi ** 2 + qk ** 2)
+    R[:, 1, 2] = 2 * (qj * qk - qi * qr)
+    R[:, 2, 0] = 2 * (qk * qi - qj * qr)
+    R[:, 2, 1] = 2 * (qj * qk + qi * qr)
+    R[:, 2, 2] = 1 - 2 * (qi ** 2 + qj ** 2)
+    return R
+
+
 def camera_rays(uv, pose, K):
-    """get_camera_params + lift, 4x4 pose branch (rend_util.py:51-97).  uv [B,N,2] (x=col,y=row),
-    pose [B,4,4] c2w, K [B,3,3] -> unit ray_dirs [B,N,3], cam_loc [B,3].  Camera looks along -z, y up."""
+    """get_camera_params + lift (rend_util.py:51-97).  uv [B,N,2] (x=col,y=row), pose [B,4,4] c2w or [B,7] = (quaternion | cam_loc)
+    (:52-57), K [B,3,3] -> unit ray_dirs [B,N,3], cam_loc [B,3].  Camera looks along -z, y up."""
+    if pose.dim() == 2 and pose.shape[1] == 7:
+        m = torch.eye(4).repeat(pose.shape[0], 1, 1)
+        m[:, :3, :3] = quat_to_rot(pose[:, :4])
+        m[:, :3, 3] = pose[:, 4:]
+        pose = m
     cam_loc = pose[:, :3, 3]
     fx, fy = K[:, 0, 0, None], K[:, 1, 1, None]
     cx, cy, sk = K[:, 0, 2, None], K[:, 1, 2, None], K[:, 0, 1, None]

@@ -213,18 +213,24 @@ __global__ void k_cast_finish(Oct T, const float* __restrict__ origins, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The same lock-step batch in ONE launch (round 3): a persistent grid (every workgroup resident: the host caps it at two per compute
-// unit) walks its rays through init / all iterations / finish; the per-iteration count of active rays -- the only thing the rays of a
+// The same lock-step batch in ONE launch (round 3): a persistent grid (every workgroup resident: the host caps it at one per compute
+// unit, 1024 threads each) walks its rays through init / all iterations / finish; the per-iteration count of active rays -- the only thing the rays of a
 // batch share (multi_samp, octree.py:545-549) -- is the device-side counter of the per-iteration launches, completed by a grid-wide
 // arrival counter (release / acquire at agent scope).  33 launches of ~33 us each per trace_radiance call (16 % of BASELINE config 5,
 // profiles/r03_config5_kernel_stats.md) become one.  A thread owns rays i = tid + k * threads for the whole cast; their state lives
 // in t / leaf / active as before (any batch size), results are those of the per-iteration kernels bit for bit.
-// counters: [max_it + 2] active counts (output), arrive: one 64-bit word per workgroup (<= 1024, zeroed).
+// counters: [max_it + 2] active counts (output), arrive: 2 x 512 64-bit words (two per workgroup, by epoch parity; zeroed).
 // ---------------------------------------------------------------------------------------------------------
 // Grid barrier + sum without same-address atomics (those serialise at the L2 at ~0.4 us each: 118 workgroups = 40 us per iteration):
 // workgroup g publishes ONE 64-bit word {epoch, its active count} in its own slot; thread k of every workgroup polls slot k until it
-// carries the epoch, and the counts are summed in the workgroup.  words[n_groups], zeroed before the launch; epochs start at 1.
+// carries the epoch, and the counts are summed in the workgroup.  The slots are DOUBLE-BUFFERED by epoch parity (words[2][512], zeroed
+// before the launch; epochs start at 1): with one slot per workgroup a fast workgroup A could pass barrier e, publish e+1 into its slot
+// and so hide epoch e from a slow poller C that had not read A's slot yet -- C would never see e, never publish e+1, and A would wait for
+// C for ever.  With two slots A can overwrite the slot of epoch e only with e+2, i.e. after passing barrier e+1, which needs C's e+1,
+// which C publishes only after it has read every slot at epoch e.
+constexpr int CC_MAX_GROUPS = 512;
 __device__ __forceinline__ int grid_sum_and_wait(unsigned long long* words, int epoch, int my_active, int n_groups, int* lds_sum) {
+  words += (epoch & 1) * CC_MAX_GROUPS;
   __threadfence();          // every thread: its own stores (ray state) are visible device-wide before the workgroup publishes
   if (threadIdx.x == 0) *lds_sum = 0;
   __syncthreads();
@@ -557,7 +563,8 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
     if (lpr != 1 && lpr != 4 && lpr != 16) lpr = 4;
   }
   const long want = (R * lpr + 1023) / 1024;
-  const unsigned grid = (unsigned)(want < cus ? want : cus);                // every workgroup resident: the grid barrier spins
+  const long cap = cus < CC_MAX_GROUPS ? cus : CC_MAX_GROUPS;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);                // every workgroup resident: the grid barrier spins
   const int it_limit = max_iter > 0 ? max_iter + 1 : max_total;
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, T, origins, dirs, R, max_iter, step, it_limit, clamp_dt, t,

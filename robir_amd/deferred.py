@@ -26,7 +26,7 @@ import weakref
 
 import torch
 
-DEFAULT_CHUNKS = int(os.environ.get("ROBIR_DEFER_CHUNKS", "0") or 0)
+DEFAULT_CHUNKS = int(os.environ.get("ROBIR_DEFER_CHUNKS", "128") or 0)      # round 4: on by default (0 = every forward() runs at once)
 _NO_TF = torch._C.DisableTorchFunctionSubclass
 _LIVE = weakref.WeakSet()            # queues with recorded chunks that have not run
 

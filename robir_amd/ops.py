@@ -481,13 +481,14 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
     return dirs, wdir, wsum
 
 
-DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
+DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6t", "f16x6-pt": "k_dvis_x6t", "f16x6-stream": "k_dvis_x6t<stream>",
+                     "f16x6-1t": "k_dvis_x6", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
                      "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
 
 
 DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
 DVIS_STREAM_MAX_POINTS = 8192     # "f16x3-auto": launches up to this many surface points take the streaming family
-DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "f16x6-pt")      # what "f16x6" runs: f16x6-pt | f16x6-stream | f16x6-1t
+DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "auto")          # what "f16x6" runs: auto | f16x6-pt | f16x6-stream | f16x6-1t
 
 
 def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argmax_vis=False, eval_count=None,
@@ -503,7 +504,9 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     X6 = ("f16x6", "f16x6-1t", "f16x6-pt", "f16x6-stream")
     assert h3 or precision == "fp32" or precision in X6, precision
     if precision == "f16x6":
-        precision = DVIS_X6_FORM
+        # "auto": the persistent tile-list form for launches up to DVIS_STREAM_MAX_POINTS points (a single 1024-pixel chunk: balanced
+        # over the CUs, 0.4 % tile padding), one workgroup per point beyond (no scratch); the two are bit-identical
+        precision = DVIS_X6_FORM if DVIS_X6_FORM != "auto" else ("f16x6-stream" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x6-pt")
     # "f16x3-v2" = second-generation split-precision kernel: two tiles per wave, one workgroup per CU, head on the matrix
     # pipe (csrc/vis_diffuse_v2.hip); "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU,
     # weights staged by LDS-DMA; "f16x6*" = exact three-piece operands: "-1t" round 3's one tile per wave, one workgroup per point
@@ -645,7 +648,7 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
     a = T.args()
     if (CAST_ONE_LAUNCH and R <= CAST_ONE_LAUNCH_MAX_RAYS) if one_launch is None else one_launch:
         counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
-        arrive = torch.zeros(1024, dtype=torch.int64, device=dev)                # one 64-bit slot per workgroup of the grid barrier
+        arrive = torch.zeros(1024, dtype=torch.int64, device=dev)                # grid barrier: two 64-bit slots per workgroup (2 x 512, by epoch parity)
         x = torch.empty(R, 3, dtype=torch.float32, device=dev)
         hit = torch.empty(R, dtype=torch.uint8, device=dev)
         t_out = torch.empty(R, dtype=torch.float32, device=dev)
@@ -772,9 +775,30 @@ def octree_cast_grouped(T, origins, dirs, group_start, max_iter=32):
     return x, hit.bool(), t
 
 
-def camera_rays(pose, K, uv):
-    """pose [4,4], K [3,3]: host arrays, or device tensors (then they are read on the device: no blocking copy); uv [N,2] device."""
+def pose_matrix(pose):
+    """The 4x4 camera-to-world matrix of a pose given as 4x4 (returned as is) or as the 7-vector (qr, qi, qj, qk | cam_loc) of
+    get_camera_params' quaternion branch (utils/rend_util.py:52-57; quat_to_rot, :107-124, normalises the quaternion first).  A host
+    array stays a host array, a device tensor a device tensor (eleven scalar products of one pose: parameter conversion, no kernel)."""
     import numpy as np
+    is_t = isinstance(pose, torch.Tensor)
+    if (pose.numel() if is_t else np.asarray(pose).size) != 7:
+        return pose
+    q = (pose.detach().float().reshape(7) if is_t else torch.from_numpy(np.asarray(pose, dtype=np.float32).reshape(7)))
+    loc = q[4:]
+    qr, qi, qj, qk = (q[:4] / torch.clamp(q[:4].norm(), min=1e-12)).unbind(0)
+    rows = [torch.stack([1 - 2 * (qj ** 2 + qk ** 2), 2 * (qj * qi - qk * qr), 2 * (qi * qk + qr * qj), loc[0]]),
+            torch.stack([2 * (qj * qi + qk * qr), 1 - 2 * (qi ** 2 + qk ** 2), 2 * (qj * qk - qi * qr), loc[1]]),
+            torch.stack([2 * (qk * qi - qj * qr), 2 * (qj * qk + qi * qr), 1 - 2 * (qi ** 2 + qj ** 2), loc[2]]),
+            torch.tensor([0.0, 0.0, 0.0, 1.0], device=q.device)]
+    m = torch.stack(rows)
+    return m if is_t else m.numpy()
+
+
+def camera_rays(pose, K, uv):
+    """pose [4,4] (or the 7-vector quaternion form: pose_matrix), K [3,3]: host arrays, or device tensors (then they are read on the
+    device: no blocking copy); uv [N,2] device."""
+    import numpy as np
+    pose = pose_matrix(pose)
     if isinstance(pose, torch.Tensor) and pose.is_cuda and isinstance(K, torch.Tensor) and K.is_cuda:
         uv = _f32(uv)
         N = uv.shape[0]

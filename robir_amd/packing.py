@@ -92,7 +92,8 @@ def pack_layers_x6(layers, device, scale_log2=H3_SCALE_LOG2):
         wmax = float(W.abs().max()) * 2.0 ** scale_log2
         if not wmax < 65504.0:
             raise ValueError("exact-operand packing: |w| * 2^%d = %.3g exceeds the f16 range; run this network with "
-                             "ROBIR_VIS_PRECISION=fp32" % (scale_log2, wmax))
+                             "ROBIR_VIS_PRECISION=fp32 (light-visibility kernel) / ROBIR_MLP_PRECISION=fp32 (SDF, colour, visibility, 512-wide and "
+                             "CESR nets)" % (scale_log2, wmax))
         keep += [W, b]
         perm = None
         if l.get("perm") is not None:

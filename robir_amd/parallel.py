@@ -5,8 +5,33 @@ specular-cone minimum) live inside a 1024-pixel chunk, so rank r renders whole c
 during rendering.  The single collective is the gather of the output tiles (RCCL all-gather over xGMI on MI355X;
 `backend="nccl"` is RCCL on ROCm; gloo on CPU for the tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def bind_device(share_gpu=False):
+    """This rank's GPU: cuda:LOCAL_RANK, as torch.distributed.run exports it (one process per GPU); share_gpu: every rank on cuda:0 (the
+    one-GPU functional runs over gloo).  Sets the current device and returns it."""
+    local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        raise RuntimeError(f"LOCAL_RANK={local} but {torch.cuda.device_count()} GPU(s) are visible: start one rank per GPU")
+    torch.cuda.set_device(local)
+    return torch.device("cuda", local)
+
+
+def init_distributed(backend="nccl", device=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run's variables; the address
+    defaults to 127.0.0.1).  backend "nccl" is RCCL on ROCm and is bound to `device` (default: bind_device()); "gloo" for CPU tests and
+    ranks that share a GPU.  Returns the device."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        device = device or bind_device()
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
+    return device
 
 
 def shard_chunks(n_chunks, rank, world, interleave=True):

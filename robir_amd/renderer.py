@@ -84,7 +84,7 @@ class IDRNetwork(nn.Module):
                                            indir_integral=ops.abs_scale(indir_integral, 2 * np.pi, take_abs=False),
                                            specular_reflectance=mat["sg_specular_reflectance"].abs(),
                                            roughness=mat["sg_roughness"], diffuse_albedo=mat["sg_diffuse_albedo"],
-                                           indir_lgtSGs=indir_lgtSGs, VisModel=self.visibility_network, fun_spec=False,
+                                           indir_lgtSGs=indir_lgtSGs, VisModel=self.visibility_network, fun_spec=fun_spec,
                                            lin_diff=False, testing=self.testing, metallic=None, draws=draws,
                                            chunk_id=chunk_id, n_chunks=n_chunks, stats=stats)
         ret.update({"normals": normals, "diffuse_albedo": mat["sg_diffuse_albedo"], "roughness": mat["sg_roughness"],
@@ -97,6 +97,9 @@ class IDRNetwork(nn.Module):
     def forward(self, input, trainstage="IDR", fun_spec=False, lin_diff=False, train_spec=False, draws=None, stats=None):
         """implicit_differentiable_renderer.py:290-479, uv/pose/intrinsics input form, batch size 1."""
         forward_only_guard(self)
+        # the runner's hook may take per-pixel texture coordinates (implicit_differentiable_renderer.py:390-392,408): kept for _shade,
+        # which hands the hit rows to the hook
+        self._tex_uv = input.get("tex_uv")
         if "intrinsics" not in input:
             return self._forward_points_dirs(input, trainstage, fun_spec, lin_diff, draws, stats)
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
@@ -110,7 +113,7 @@ class IDRNetwork(nn.Module):
         chunk = N if not chunk or N <= chunk else int(chunk)
         limit = self.__dict__.get("deferred_chunks", deferred.DEFAULT_CHUNKS)
         if (limit and not self.training and chunk == N and N <= 1024 and self.use_octree and draws is None and stats is None
-                and input.get("albedo_ratio") is None):
+                and input.get("albedo_ratio") is None and self._tex_uv is None and not fun_spec):
             return self._record_chunk(input, N, int(limit), trainstage, fun_spec, lin_diff)
         self.flush()
         return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), chunk,
@@ -173,6 +176,8 @@ class IDRNetwork(nn.Module):
         own camera centres and flattens every output to [B N, ...] (implicit_differentiable_renderer.py:299-305,324); every ray is
         traced, `object_mask` only travels along."""
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
+        if pose.dim() == 2 and pose.shape[1] == 7:       # quaternion form, one 7-vector per view (rend_util.py:52-57)
+            pose = torch.stack([ops.pose_matrix(pose[b]) for b in range(pose.shape[0])])
         B, N = uv.shape[0], uv.shape[1]
         self.flush()
         with torch.no_grad():
@@ -229,6 +234,7 @@ class IDRNetwork(nn.Module):
                                lin_diff, draws, stats, albedo_ratio)
         dev = uv.device
         N = uv.shape[0]
+        pose = ops.pose_matrix(pose)          # 4x4, or the 7-vector (quaternion | cam_loc) form of get_camera_params (rend_util.py:52-57)
         cam = pose[:3, 3].float().reshape(1, 3).contiguous()
         with torch.no_grad():
             if pose.is_cuda and K.is_cuda:        # read on the device: a .cpu() here would block every per-chunk forward()
@@ -294,22 +300,45 @@ class IDRNetwork(nn.Module):
                 kw = dict(draws=draws, chunk_id=cid, n_chunks=n_chunks, stats=stats)   # our own hooks understand these
             elif n_chunks > 1:        # a runner's own hook: render_with_all_sg learns the chunk partition from the context
                 sg_render._BATCH_CTX = (cid, n_chunks, n)
+            tex_uv, self._tex_uv = getattr(self, "_tex_uv", None), None
+            if tex_uv is not None:
+                if tex_uv.shape[0] * tex_uv.shape[1] == N:          # B views in one batch: rows are (view, pixel) like the hit mask
+                    tex_uv = tex_uv.reshape(1, N, *tex_uv.shape[2:])
+                if tex_uv.shape[1] != N:
+                    raise ValueError("input['tex_uv'] must hold one row per pixel of the call ([B, N, ...], implicit_differentiable_"
+                                     "renderer.py:390-392): got %s for %d pixels" % (tuple(tex_uv.shape), N))
+                tex_uv = tex_uv[:, hit]
             try:
                 r = self.get_sg_render(hp, view, sgs_h if hdr_shift is not None else indirect_sgs[idx],
                                        albedo_ratio=albedo_ratio, fun_spec=fun_spec, lin_diff=lin_diff, train_spec=True,
                                        indir_integral=int_h if hdr_shift is not None else indirect_integral[idx],
-                                       tex_uv=None, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
+                                       tex_uv=tex_uv, hdr_shift=hdr_shift[idx] if hdr_shift is not None else None, **kw)
             finally:
                 sg_render._BATCH_CTX = None
             if "gradient_error" in r:
                 gerr = gerr + r["gradient_error"]
+        # fun_spec (implicit_differentiable_renderer.py:417-427,455-463): the two specular terms come back as functions of a per-pixel
+        # roughness; their N-row buffers start as ones and the hit rows are filled in on call
+        spec_fn = {}
+        if fun_spec and r is not None:
+            spec_fn = {k: r[k] for k in ("sg_specular_rgb", "indir_specular_rgb") if callable(r[k])}
         # every output: ones, the hit rows scattered in -- one buffer, one fill, one scatter launch for the seventeen of them
-        srcs = [r[k] for k in keys3] + [r["metallic"], r["random_xi_metallic"], None, None] if r is not None else [None] * len(widths)
+        # (a block without a source has to come last in rb_scatter_rows' view of the buffer: the two function-valued fields scatter ones)
+        ones3 = torch.ones(n, 3, device=dev) if spec_fn else None
+        srcs = ([ones3 if k in spec_fn else r[k] for k in keys3] + [r["metallic"], r["random_xi_metallic"], None, None]
+                if r is not None else [None] * len(widths))
         outs = ops.scatter_rows(srcs + ([None] if bg is None else []), widths + ([3] if bg is None else []), idx, N)
         if bg is None:
             bg = outs.pop()
         ret.update({"gradient_error": gerr, "bg_rgb": bg, "surface_mask": hit})
         ret.update(dict(zip(keys3 + keys1, outs)))
+        if fun_spec:
+            for k in ("sg_specular_rgb", "indir_specular_rgb"):
+                def spec_values_fn(roughness, draws=None, buf=ret[k], fn=spec_fn.get(k)):
+                    if fn is not None:      # (draws: explicit uniform draws for the specular cone, robir_amd.sg_render's closures only)
+                        buf[idx] = fn(roughness[idx]) if draws is None else fn(roughness[idx], draws=draws)
+                    return buf
+                ret[k] = spec_values_fn
         return ret
 
     # ------------------------------------------------------------------ secondary rays

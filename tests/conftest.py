@@ -66,6 +66,18 @@ def rel_err(a, b):
     return float(torch.nan_to_num(e, nan=float("inf")).max())
 
 
+def rel_err_plain(a, b):
+    """max |a-b| / |b| over the entries with |b| > mean|b| -- the plain relative error where it is well defined, reported next to the
+    floored figure of rel_err (0.0 if there is no such entry)."""
+    a = torch.as_tensor(np.asarray(a) if not isinstance(a, torch.Tensor) else a).double().cpu()
+    b = torch.as_tensor(np.asarray(b) if not isinstance(b, torch.Tensor) else b).double().cpu()
+    fin = torch.isfinite(b) & torch.isfinite(a)
+    if not fin.any():
+        return 0.0
+    big = fin & (b.abs() > b[fin].abs().mean())
+    return float(((a - b).abs()[big] / b.abs()[big]).max()) if big.any() else 0.0
+
+
 def bad_frac(a, b, tol):
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
@@ -94,7 +106,8 @@ def bounded(name, a, b, tol, frac):
         _CAPS = json.load(open(path)) if os.path.exists(path) else {}
     f, m = bad_frac(a, b, tol), rel_err(a, b)
     cap = _CAPS.get(name)
-    record_metric("bounded/" + name, tol=tol, frac=f, max=m, frac_limit=frac, cap=cap if cap is not None else -1.0)
+    record_metric("bounded/" + name, tol=tol, frac=f, max=m, max_plain_rel_above_mean=rel_err_plain(a, b), frac_limit=frac,
+                  cap=cap if cap is not None else -1.0)
     assert f <= frac, (name, "fraction beyond", tol, "is", f, "limit", frac)
     if os.environ.get("ROBIR_RECORD_CAPS") == "1":
         return

@@ -86,6 +86,18 @@ def test_borrow_color_and_surface_golden(dev, synth_weights):
     t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if v.dtype.kind == "f"}
     rgb = impl.batch_borrow_color(t["bc_points"], t["bc_view"]).cpu()
     assert rel_err(rgb, g["bc_rgb"]) <= 2e-4
+    # slabs instead of the reference's batches of 8192 rays (neus_model.py:873-884): the rows are independent -- bit-identical
+    gen = torch.Generator(device=dev).manual_seed(5)
+    P = (torch.rand(20000, 3, device=dev, generator=gen) - 0.5) * 0.8
+    V = torch.nn.functional.normalize(torch.randn(20000, 3, device=dev, generator=gen), dim=-1)
+    slab = impl.batch_borrow_color(P, V)
+    old = nets.BORROW_SLAB_ROWS
+    nets.BORROW_SLAB_ROWS = 1
+    try:
+        batched = impl.batch_borrow_color(P, V, batch_size=8192)
+    finally:
+        nets.BORROW_SLAB_ROWS = old
+    assert slab.shape == (20000, 3) and torch.equal(slab, batched)
     x, n, ge = sdf_render.get_neus_surface(impl, t["ns_points"], t["ns_dirs"], t["ns_normals"])
     assert rel_err(x.cpu(), g["ns_x"]) <= 1e-4
     assert rel_err(n.cpu(), g["ns_n"]) <= 1e-4

@@ -147,6 +147,22 @@ def test_camera_rays(dev):
     assert rel_err(d, ref[0]) <= 1e-6
 
 
+def test_camera_rays_quaternion_pose_vs_reference_golden(dev):
+    """get_camera_params' 7-vector pose form (utils/rend_util.py:52-57 + quat_to_rot): reference-recorded directions / centres
+    (tests/golden/camera_quat.npz, oracle/gen_golden_r4.py), host-array and device-tensor forms, and forward() given the 7-vector."""
+    from robir_amd import ops
+    g = load_golden("camera_quat")
+    for b in range(2):
+        uv = torch.from_numpy(g["uv"][b]).to(dev)
+        for pose, K in ((g["pose7"][b], g["K"][b]), (torch.from_numpy(g["pose7"][b]).to(dev), torch.from_numpy(g["K"][b]).to(dev))):
+            d = ops.camera_rays(pose, K, uv).cpu()
+            assert rel_err(d, torch.from_numpy(g["ray_dirs"][b])) <= 1e-6
+            m = ops.pose_matrix(pose)
+            loc = m[:3, 3].cpu() if isinstance(m, torch.Tensor) else torch.from_numpy(m[:3, 3])
+            assert rel_err(loc, torch.from_numpy(g["cam_loc"][b])) <= 1e-7
+    assert ops.pose_matrix(np.eye(4, dtype=np.float32)).shape == (4, 4)      # a matrix passes through
+
+
 def test_build_second_sdf_and_mesh_box(dev):
     """Another SDF (other seed) and the mesh-bounding-box form of generate() (octree_tracing.py:33-39: root = a box
     tighter than [-1,1]^3): the device-built node structure must again equal the oracle's exactly."""

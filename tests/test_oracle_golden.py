@@ -265,3 +265,12 @@ def test_octree_vis_model(oracle_sd, oracle_octree):
         # a flipped ray changes one of 32 samples of one lobe of one point: bounded, rare
         assert bad_frac(out[k], g["out_" + k], 1e-5) <= 0.02, (k, bad_frac(out[k], g["out_" + k], 1e-5))
         assert rel_err(out[k], g["out_" + k]) <= 2e-2, (k, rel_err(out[k], g["out_" + k]))
+
+
+def test_oracle_camera_quaternion_pose():
+    """The restated get_camera_params, 7-vector pose branch (utils/rend_util.py:52-57,107-124) against the reference's own output."""
+    from robir_oracle import renderer as orend
+    g = load_golden("camera_quat")
+    d, c = orend.camera_rays(torch.from_numpy(g["uv"]), torch.from_numpy(g["pose7"]), torch.from_numpy(g["K"]))
+    assert float((d - torch.from_numpy(g["ray_dirs"])).abs().max()) <= 1e-6
+    assert float((c - torch.from_numpy(g["cam_loc"])).abs().max()) == 0.0

@@ -123,3 +123,41 @@ def test_bench_starts_its_own_ranks():
     if torch.cuda.device_count() < 2:
         assert d["config"]["ranks_share_one_gpu"] and d["config"]["collective_backend"] == "gloo"
     assert "weak_views" in d and d["roofline"]["frac"] > 0
+
+
+def _rccl_worker(port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        from robir_amd import parallel
+        dev = parallel.init_distributed("nccl")
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1          # "nccl" is RCCL on ROCm
+        assert dev.index == int(os.environ["LOCAL_RANK"]) and torch.cuda.current_device() == dev.index
+        g = torch.Generator(device=dev).manual_seed(3)
+        tiles = torch.rand(3 * 1024, 17, device=dev, generator=g)
+        out = parallel.all_gather_tiles(tiles)                                      # dist.all_gather_into_tensor over RCCL
+        assert out.shape == tiles.shape and torch.equal(out, tiles)
+        img = parallel.gather_image(tiles, 3, 1024)                                 # the strong-scaling gather at world 1
+        assert torch.equal(img, tiles)
+        ragged = parallel.gather_image(tiles[:2048], 2, 1024)
+        assert torch.equal(ragged, tiles[:2048])
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        q.put(("ok", None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("error", traceback.format_exc() + repr(e)))
+
+
+def test_rccl_branch_at_world_size_one():
+    """The collective of the multi-GPU path on its production backend as far as one GPU allows: a process group of ONE rank on
+    backend 'nccl' (= RCCL), the rank bound to cuda:LOCAL_RANK, the tile gather through dist.all_gather_into_tensor (the branch
+    robir_amd/parallel.py takes on a node).  A scaling curve needs a node; this proves the branch loads and runs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert not p.is_alive(), "RCCL world-1 worker hung"
+    status, msg = q.get(timeout=5)
+    assert status == "ok", msg

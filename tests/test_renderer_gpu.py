@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, bad_frac, load_golden, bounded
+from conftest import rel_err, bad_frac, load_golden, bounded, record_metric
 
 pytestmark = pytest.mark.gpu
 
@@ -163,6 +163,9 @@ def test_forward_material_second_weight_set(dev):
             assert frac <= 0.005 and worst <= 1e-3, (k, frac, worst)
 
 
+SPREAD_FACTOR = 4.0
+
+
 def test_forward_material_vs_reference_golden(dev, model):
     """End to end with the device-built octree against the reference's own output (looser: PE amplifies the ~1e-6
     hit-position noise of two independently built octrees 512-fold -- DESIGN.md 'Parity tolerances')."""
@@ -180,6 +183,20 @@ def test_forward_material_vs_reference_golden(dev, model):
         bounded("forward_material_vs_reference_golden/" + k, out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 1e-4, 0.002)
     for k in FIELDS:
         bounded("forward_material_vs_reference_golden/" + k, out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same], 2e-3, 0.003)
+    # ... and against the yardstick of this comparison: what an INDEPENDENT octree build alone does to each field.  tests/golden/
+    # self_spread.json (oracle/gen_golden_r4.py) holds, per field, the distance between this golden output (the reference on its own
+    # octree) and the CPU oracle on the oracle's own octree build, same draws -- the oracle reproduces the reference to 0.0 on the
+    # reference's octree tables, so that distance is the octree build's doing.  The HIP path (device-built octree, kernels' fp32
+    # evaluation order) stays within SPREAD_FACTOR of it on every field (measured on an MI355X: 1.2-3.7, most fields 1.9-2.3 -- the hit
+    # positions themselves sit 1.9 x the oracle's own-build distance from the reference's).
+    import json
+    import os
+    spread = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "self_spread.json")))["fields"]
+    for k in ("points", "sdf_output") + tuple(FIELDS):
+        if spread.get(k, 0.0) > 0.0:
+            m = rel_err(out[k].cpu()[same], torch.from_numpy(g["out_" + k])[same])
+            record_metric("self_spread_ratio/" + k, hip_vs_reference=m, self_spread=spread[k], ratio=m / spread[k])
+            assert m <= SPREAD_FACTOR * spread[k], (k, m, spread[k])
 
 
 def test_batched_chunks_equal_per_chunk_forward(dev, model):
@@ -399,3 +416,50 @@ def test_exact_and_split_precision_forward_agree(dev, model, monkeypatch):
     for k in FIELDS:
         assert bad_frac(a[k].cpu(), b[k].cpu(), 1e-4) <= 0.005, (k, bad_frac(a[k].cpu(), b[k].cpu(), 1e-4))
         assert rel_err(a[k].cpu(), b[k].cpu()) <= 1e-3, (k, rel_err(a[k].cpu(), b[k].cpu()))
+
+
+@pytest.mark.gpu
+def test_forward_fun_spec_and_tex_uv(dev, model):
+    """forward(fun_spec=True) returns the two specular terms as functions of a per-pixel roughness (implicit_differentiable_renderer.py:
+    417-427,455-463); input['tex_uv'] reaches the hook as its hit rows (:390-392,408)."""
+    from robir_amd import synth
+    uv, pose, K = synth.synth_camera(64, 64)
+    sl = slice(1024, 2048)
+    inp = {"uv": torch.from_numpy(uv[sl])[None].to(dev), "pose": torch.from_numpy(pose)[None].to(dev),
+           "intrinsics": torch.from_numpy(K)[None].to(dev), "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+           "hdr_shift": torch.full((1024, 1), 0.5, device=dev)}
+    pre = model(inp, trainstage="Illum", draws={"illum_randn": None, "normal_randn": None})
+    hit = pre["network_object_mask"]
+    nhit = int(hit.sum())
+    assert nhit > 100
+    dr = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(0, nhit, chunk_id=1).items()}
+    plain = model(inp, trainstage="Material", train_spec=True, draws=dr)
+    fun = model(inp, trainstage="Material", train_spec=True, fun_spec=True, draws=dr)
+    assert callable(fun["sg_specular_rgb"]) and callable(fun["indir_specular_rgb"])
+    rough = plain["roughness"][:, :1].contiguous()
+    for k, tag in (("sg_specular_rgb", "dir"), ("indir_specular_rgb", "ind")):
+        # the closure re-draws the specular cone's samples: hand it the draws the plain call used for this term
+        got = fun[k](rough, draws={"svis_theta": dr["svis_theta_" + tag], "svis_phi": dr["svis_phi_" + tag]})
+        assert got.shape == plain[k].shape
+        assert rel_err(got.cpu(), plain[k].cpu()) <= 1e-6, k
+        assert bool((got[~hit] == 1.0).all())                      # non-hit rows keep the buffer's ones
+    assert rel_err(fun["sg_diffuse_rgb"].cpu(), plain["sg_diffuse_rgb"].cpu()) <= 1e-6
+    # tex_uv: a runner-style hook sees the hit rows of the per-pixel coordinates
+    seen = {}
+    orig = model.get_sg_render
+
+    def hook(*a, **k):
+        seen["tex_uv"] = k.get("tex_uv")
+        return orig(*a, **k)
+    hook.robir_native = True
+    tex = torch.rand(1, 1024, 2, device=dev)
+    model.get_sg_render = hook
+    try:
+        model(dict(inp, tex_uv=tex), trainstage="Material", train_spec=True, draws=dr)
+        assert seen["tex_uv"] is not None and torch.equal(seen["tex_uv"], tex[:, hit])
+        model(inp, trainstage="Material", train_spec=True, draws=dr)
+        assert seen["tex_uv"] is None                                # nothing lingers from the previous call
+        with pytest.raises(ValueError):
+            model(dict(inp, tex_uv=tex[:, :100]), trainstage="Material", train_spec=True, draws=dr)
+    finally:
+        del model.get_sg_render

@@ -46,8 +46,13 @@ def dev():
 
 @pytest.fixture(scope="module")
 def model(dev):
+    """These tests seed torch before EACH chunk forward and compare call by call, i.e. they test the immediate call shape: deferred
+    chunk forwards (the default since round 4; robir_amd/deferred.py draws when a pass of recorded chunks runs) are switched off here --
+    tests/test_deferred_gpu.py covers the recorded form."""
     from robir_amd import renderer
-    return renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+    m = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+    m.deferred_chunks = 0
+    return m
 
 
 def _unit(v, eps):

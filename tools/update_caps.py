@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """tests/golden/measured_caps.json from gpurun_out/test_metrics.jsonl: cap = 2 x the maximum the GPU tests measured for every
-`bounded(...)` comparison (floored at the comparison's own tolerance), i.e. "measured max x 2" instead of an unbounded
-outlier allowance.  Run the GPU tests with ROBIR_RECORD_CAPS=1 first (records without asserting the caps)."""
+`bounded(...)` comparison -- nothing else: round 3 floored every cap at the comparison's own tolerance, which made "2 x measured"
+read `max(2 x measured, 2e-3)` for most fields; the floor is gone (a comparison that measured exactly 0 gets the fp32 unit
+roundoff, 1.2e-7, so that a last-bit change of a library does not fail it).  Run the GPU tests with ROBIR_RECORD_CAPS=1 first
+(records without asserting the caps), under every precision policy the suite is run with: the maxima of all recorded runs count."""
 import json
 import os
 import sys
@@ -14,7 +16,7 @@ for line in open(src):
     if d["name"].startswith("bounded/"):
         n = d["name"][len("bounded/"):]
         meas[n] = max(meas.get(n, 0.0), d["max"])
-        caps[n] = max(2.0 * meas[n], d["tol"])
+        caps[n] = max(2.0 * meas[n], 1.2e-7)
 dst = os.path.join(ROOT, "tests", "golden", "measured_caps.json")
 old = json.load(open(dst)) if os.path.exists(dst) and "--fresh" not in sys.argv else {}
 if "--raise-only" in sys.argv:         # a re-measurement after an arithmetic change: never tighten what another policy / run needed
