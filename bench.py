@@ -246,8 +246,9 @@ def self_launch(args):
     # stdout carries ONE JSON line: anything else the ranks' libraries print there (gloo announces its peers on stdout) goes to stderr
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
-        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
-        sys.stdout.flush()
+        out = (REAL_STDOUT or sys.stdout) if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     raise SystemExit(proc.wait())
 
 
@@ -268,6 +269,15 @@ def vis_peak(vis):
     if vis == "f16x6":
         return PEAK_F16_MFMA_TFLOPS / 6.0, "dense f16 MFMA 2500 TFLOP/s / 6 products per multiply-add (exact three-piece operands)"
     return PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)"
+
+
+REAL_STDOUT = None
+
+
+def emit(line):
+    out = REAL_STDOUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
 
 
 def runner_loop_replay(model, uv_d, pose_d, K_d, hdr, chunk=1024):
@@ -320,6 +330,12 @@ def rccl_selfcheck(parallel, dev):
 
 
 def main():
+    # stdout carries ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for the whole run (RCCL prints a version
+    # banner from C at communicator creation, the octree build prints like the reference), the line goes out through a saved duplicate
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -376,7 +392,7 @@ def main():
                            **{k: v for k, v in r.items() if k not in ("workload", "value", "unit", "ms", "roofline", "config")}},
                 "roofline": r["roofline"],
                 "note": "best of the timed repetitions; the headline metric is the default line (--config 4)"}
-        print(json.dumps(line), flush=True)
+        emit(line)
         return
 
     timer = KernelTimer()
@@ -619,7 +635,7 @@ def main():
             # the reference's runners pin torch to one thread (training/train_pbr.py:24): that figure too, on a smaller sample
             one = cpu_baseline(model, 1, uv, pose, K, cores=1, pixels=args.cpu_baseline_1thread_pixels)
             line["cpu_baseline"]["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample", "hit_rays_per_s")}
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 4
+#define RB_ABI_VERSION 5
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -143,6 +143,12 @@ int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* 
  * operands too (csrc/sdf_back_x6.hip; Wt / w8row = packing.pack_sdf_back_x6; same scratch). */
 int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
                      rb_stream_t stream);
+/* rb_sdf_x6_points with TWO 16-row tiles per wave (csrc/sdf_x6t.hip + x6t_engine.h, round 4): a weight fragment read from the LDS feeds
+ * two MFMAs per product, a pass of the weights serves 128 rows.  Same arguments, same blob, same arithmetic (the products of a class are
+ * summed part by part: results agree with rb_sdf_x6_points to fp32 summation order).  The host mirror takes it for >= 32768 rows (below
+ * that the one-tile kernel's rounds of 64 rows fill the chip better). */
+int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
+                      rb_stream_t stream);
 /* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
 int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
@@ -157,6 +163,10 @@ int rb_wide_x6(const float* X /* feature rows [M,64] */, long M, const float* Wp
 int rb_cesr_net_x6_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, int n_workgroups, rb_stream_t stream);
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
+/* ... with two tiles per wave in the value and the reverse pass (csrc/sdf_x6t.hip, sdf_back_x6t.hip); Wt = the transposed layers packed
+ * with W3^T's K padded to 256 (packing.pack_sdf_back_x6(two_tile=True)).  Same scratch. */
+int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);
 int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);

@@ -45,7 +45,7 @@ def lib():
         _lib.rb_packed_layer_x6_floats.restype = ctypes.c_long
         _lib.rb_sdf_value_grad_scratch_floats.restype = ctypes.c_long
         _lib.rb_sdf_value_grad_f32_scratch_floats.restype = ctypes.c_long
-        if _lib.rb_abi_version() != 4:
+        if _lib.rb_abi_version() != 5:
             raise RobirHipError("librobir_hip.so ABI version mismatch")
         if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
             _lib.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))

@@ -633,6 +633,26 @@ extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scal
   return check_launch("k_pe_grad_points");
 }
 
+// ... with two 16-row tiles per wave in both passes (k_sdf_x6t<5>, csrc/sdf_x6t.hip; k_sdf_back_x6t, csrc/sdf_back_x6t.hip, Wt =
+// packing.pack_sdf_back_x6(two_tile=True): W3^T's K padded to 256): same arguments, same scratch.
+extern "C" int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
+                                            float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                                            rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && Wt && w8row && out0 && grad && scratch, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long tiles = (M + 127) / 128 * 8;
+  float* sig = scratch;
+  float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
+  int rc = launch_sdf_x6t(x, M, in_scale, Wp, 5, out_scale, out0, sig, 0, s);
+  if (rc) return rc;
+  rc = launch_sdf_back_x6t(sig, M, Wt, w8row, gfeat, s);
+  if (rc) return rc;
+  const long n = 3 * M;
+  hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);
+  return check_launch("k_pe_grad_points");
+}
+
 extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
                                  rb_stream_t stream) {

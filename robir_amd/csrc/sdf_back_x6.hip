@@ -315,10 +315,6 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6(const f4* __restrict__ s
 
 // host-side launcher for sdf_back.hip (rb_sdf_value_grad_x6_points)
 int launch_sdf_back_x6(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s) {
-  // round 4: two tiles per wave (sdf_back_x6t.hip; its blob pads W3^T's K to 256: packing.pack_sdf_back_x6 follows the same switch);
-  // ROBIR_SDF_X6_TILES=1 keeps this file's one-tile kernel
-  static const char* const tiles = getenv("ROBIR_SDF_X6_TILES");
-  if (!(tiles && tiles[0] == '1')) return launch_sdf_back_x6t(sig, M, Wt, w8row, gfeat, s);
   const int pg = persistent_grid((M + 63) / 64, 0);
   if (pg <= 0) return rb::fail(__func__, "device query failed");
   const unsigned grid = (unsigned)pg;

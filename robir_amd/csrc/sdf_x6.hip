@@ -399,9 +399,6 @@ namespace {
 int sx_grid(long M, int n_workgroups) { return persistent_grid((M + 63) / 64, n_workgroups); }
 int sx_launch(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, float* sig, int n_workgroups,
               hipStream_t s) {
-  // round 4: two tiles per wave (sdf_x6t.hip); ROBIR_SDF_X6_TILES=1 keeps this file's one-tile kernel (A/B, bisecting)
-  static const char* const tiles = getenv("ROBIR_SDF_X6_TILES");
-  if (!(tiles && tiles[0] == '1')) return launch_sdf_x6t(x, M, in_scale, Wp, mode, out_scale, out0, sig, n_workgroups, s);
   const int grid = sx_grid(M, n_workgroups);
   if (grid <= 0) return rb::fail("rb_sdf_x6_points", "device query failed");
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SDF : nullptr;

@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
   XtOps<9> P;                          // operands of the current layer (K <= 288), two tiles
   XtOps<8> Q;                          // ... of the next layer
   XtWin win;
+  // epilogue state that crosses a layer boundary: the LAST chunk of a hidden layer is finished beside the first chunk of the next layer
+  // (its softplus + split would otherwise run with the matrix pipe idle: ~1400 cycles per layer, 5 % of a round)
+  SxAcc prev[2];
+  float z[2][4];
   const int rlocal = wave * 16 + (lane & 15);      // row of a tile's lane inside its half-round: row = 128 round + 64 tile + rlocal
   long round = 0;
   auto row_of = [&](int t) { return round * 128 + t * 64 + rlocal; };
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       if (out_layer) return FULL ? (pj < 16 ? 8 : 2) : (pj == 0 ? 2 : 0);
       return STORE ? 4 : 0;
     };
-    SxAcc acc[2], prev[2];
+    SxAcc acc[2];
+    constexpr bool PREV_SKIPOUT = LI == 4, PEND = LI != 0;      // the layer before this one: its outputs are scaled (layer 3) / it left its last chunk pending (every hidden layer)
     const f4* wl = Wp + sx_coff(cb, LAST);
     const f4* wnext[3];
 #pragma unroll
@@ -128,37 +133,38 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
     // epilogue of hidden chunk pj, twelve items: per value pair (tile t, register pair q) A0 / A1 = softplus (+ its sigmoid in MODE 5) of
     // its two values, B = exact three-way split into the next layer's operand registers (+ the tile's sigmoid store behind its second pair)
-    float ev[4][2], z[2][4];
+    float ev[4][2];
     float sg[4][2];
-    int pj_of_items = 0;
     // Z = the three classes of a tile's four values combined (frees the previous chunk's accumulators early)
     auto item_z = [&](int t, const SxAcc& a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) z[t][r] = combine(a, r);
     };
-    auto item_a = [&](int i, int e) {
+    // sk: the chunk's layer feeds the skip concatenation (its outputs / sqrt 2); lr: that layer's index (sigmoid tiles); Y: the operand
+    // set the split writes (the next layer's -- or, for a chunk finished across the layer boundary, the running layer's own inputs)
+    auto item_a = [&](int i, int e, int pj, bool sk, int lr) {
       const int t = i >> 1, q = i & 1;
       float s;
       float v = softplus100_fast(z[t][2 * q + e], &s);      // no log1p correction: |error| <= 4e-10 (mlp_engine.h)
-      if (SKIPOUT) v *= inv_sqrt2;
+      if (sk) v *= inv_sqrt2;
       ev[i][e] = v;
       sg[i][e] = s;
       if constexpr (STORE)
         if (e == 1) {    // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
           typedef unsigned u2v __attribute__((ext_vector_type(2)));
           const unsigned voff = xt_lane16<0>();       // re-derived: x6t_engine.h
-          int sbase = sig_wave + lrt * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
+          int sbase = sig_wave + lr * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
           asm volatile("" : "+s"(sbase));
 #ifdef SXT_ABL_STORE_FIXED              // timing ablation (wrong results): every sigmoid store of a wave goes to the same kilobyte
-          sbase = sig_wave - (t * 4 * 8 * 16 + pj_of_items) * 1024 - q * 8;
+          sbase = sig_wave - (t * 4 * 8 * 16 + pj) * 1024 - q * 8;
 #endif
           __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])}, sig_rsrc,
-                                                (int)voff, sbase + (t * 4 * 8 * 16 + pj_of_items) * 1024 + q * 8, 0);
+                                                (int)voff, sbase + (t * 4 * 8 * 16 + pj) * 1024 + q * 8, 0);
         }
     };
-    auto item_b = [&](int i, int pj) {
+    auto item_b = [&](int i, int pj, auto& Y) {
       const int t = i >> 1, q = i & 1;
-      put_pair(ev[i][0], ev[i][1], Q.h[t][pj >> 1], Q.m[t][pj >> 1], Q.l[t][pj >> 1], (pj & 1) * 2 + q);
+      put_pair(ev[i][0], ev[i][1], Y.h[t][pj >> 1], Y.m[t][pj >> 1], Y.l[t][pj >> 1], (pj & 1) * 2 + q);
     };
     // outputs through a buffer descriptor over the round's valid rows: lanes beyond it (rows >= M, columns >= 257) are dropped by the
     // bounds check, no branch splits the chunk
@@ -181,26 +187,29 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     constexpr int NE = OUT ? 2 : 13;
     // item order: the second tile's combine (the first tile's went behind the chunk's own last run: its accumulators were complete), then
     // per pair the two softplus halves with the previous pair's split one pair behind
+    auto hidden_item = [&](int s, int pj, bool sk, int lr, auto& Y) {
+      switch (s) {
+        case 0: item_z(1, prev[1]); break;
+        case 1: item_a(0, 0, pj, sk, lr); break;
+        case 2: item_a(0, 1, pj, sk, lr); break;
+        case 3: item_a(1, 0, pj, sk, lr); break;
+        case 4: item_a(1, 1, pj, sk, lr); break;
+        case 5: item_b(0, pj, Y); break;
+        case 6: item_a(2, 0, pj, sk, lr); break;
+        case 7: item_a(2, 1, pj, sk, lr); break;
+        case 8: item_b(1, pj, Y); break;
+        case 9: item_a(3, 0, pj, sk, lr); break;
+        case 10: item_a(3, 1, pj, sk, lr); break;
+        case 11: item_b(2, pj, Y); break;
+        default: item_b(3, pj, Y); break;
+      }
+    };
+    // epilogue item s of this layer's chunk pj
     auto ep_item = [&](int s, int pj) {
-      pj_of_items = pj;
       if constexpr (OUT) {
-        output_tile(s, pj);
+        if (s < 2) output_tile(s, pj);
       } else {
-        switch (s) {
-          case 0: item_z(1, prev[1]); break;
-          case 1: item_a(0, 0); break;
-          case 2: item_a(0, 1); break;
-          case 3: item_a(1, 0); break;
-          case 4: item_a(1, 1); break;
-          case 5: item_b(0, pj); break;
-          case 6: item_a(2, 0); break;
-          case 7: item_a(2, 1); break;
-          case 8: item_b(1, pj); break;
-          case 9: item_a(3, 0); break;
-          case 10: item_a(3, 1); break;
-          case 11: item_b(2, pj); break;
-          default: item_b(3, pj); break;
-        }
+        hidden_item(s, pj, SKIPOUT, lrt, Q);
       }
     };
     f4 bias = bias_of(cb);
@@ -216,7 +225,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       // layer's last chunk AND the tail epilogue of that chunk
       int ns = 0;
       if (jb >= 2) ns = ep_stores(OUT, jb - 2);
-      else if (jb == 0) ns = ep_stores(LI == 0, PNCH - 2) + ep_stores(LI == 0, PNCH - 1);
+      else if (jb == 1) ns = PEND ? ep_stores(false, 0) : 0;          // chunk 0 carried the previous layer's pending last chunk
+      else ns = ep_stores(LI == 0, PNCH - 2) + (LI == 0 ? ep_stores(true, PNCH - 1) : 0);      // an output layer finishes its last chunk at once
       switch (sx_nsw(K2) + ns) {
         case 2: sx_wait<2>(); break;
         case 4: sx_wait<4>(); break;
@@ -252,11 +262,27 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
         if (pos == 12 * (NPART - 1)) nbias = bias_of(cb + jb + 1);
         const int a = xt_free_index(pos);
         if (a < 0) return;
+        if (jb == 0 && PEND) {
+          // the previous layer's last chunk, finished here: its outputs are this layer's operands of the LAST k-blocks, which the
+          // second part reads from its first run on -- all thirteen items go into the first part, the copies behind them
+#pragma unroll
+          for (int i = 0; i < 13; ++i)
+            if (xt_item_slot(i, 13, 9) == a) hidden_item(i, PNCH - 1, PREV_SKIPOUT, lrt - 1, P);      // straight into this layer's own operands
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (i < NC3 && 9 + xt_item_slot(i, NC3, NFREE - 9) == a) {
+#ifndef SXT_NODMA
+              xt_copy_piece(i, src3, dst3);
+#endif
+            }
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 22; ++i)
           if (i < ni && xt_item_slot(i, ni, NFREE) == a) {
-            if (i < ne) ep_item(i, jb - 1);
-            else {
+            if (i < ne) {
+              if (jb > 0) ep_item(i, jb - 1);
+            } else {
 #ifndef SXT_NODMA
               xt_copy_piece(i - ne, src3, dst3);
 #endif
@@ -289,8 +315,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 #pragma unroll
       for (int i = 0; i < 4; ++i) slot_b[i] = a[i];
     }
+    if constexpr (OUT) {      // hidden layers leave their last chunk (z[0], prev[1]) to the next layer's first chunk
 #pragma unroll
-    for (int s = 0; s < NE; ++s) ep_item(s, NCH - 1);
+      for (int s = 0; s < NE; ++s) ep_item(s, NCH - 1);
+    }
     if constexpr (!OUT) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -366,3 +394,11 @@ int launch_sdf_x6t(const float* x, long M, float in_scale, const float* Wp, int 
   return check_launch("k_sdf_x6t");
 }
 }  // namespace rb
+
+extern "C" int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0,
+                                 int n_workgroups, rb_stream_t stream) {
+  if (M <= 0) return 0;
+  RB_REQUIRE(x && Wp && out0, "null pointer");
+  RB_REQUIRE(mode == 0 || mode == 1, "mode: 0 signed distance only (blob packed with full = 0), 1 all 257 outputs");
+  return rb::launch_sdf_x6t(x, M, in_scale, Wp, mode, out_scale, out0, nullptr, n_workgroups, (hipStream_t)stream);
+}

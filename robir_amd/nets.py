@@ -497,7 +497,10 @@ class SDFNetwork(nn.Module):
 
     def packed_back_x6(self):
         assert self.kind == "neus"
-        return self._packed.get("back_x6", self, lambda sd: packing.pack_sdf_back_x6(self._sd(sd), _dev(self)))
+        def both(sd):
+            wt, w8 = packing.pack_sdf_back_x6(self._sd(sd), _dev(self))
+            return wt, w8, packing.pack_sdf_back_x6(self._sd(sd), _dev(self), two_tile=True)[0]
+        return self._packed.get("back_x6", self, both)
 
     def packed_back(self):
         assert self.kind == "neus"

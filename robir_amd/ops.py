@@ -354,20 +354,32 @@ def sdf_value_grad_f32(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     return out0, grad
 
 
+SDF_TWO_TILE_MIN_ROWS = int(os.environ.get("ROBIR_SDF_TWO_TILE_MIN_ROWS", "32768"))
+
+
+def sdf_two_tile(M):
+    """The exact-operand SDF kernels come in two forms: two 16-row tiles per wave (rounds of 128 rows, half the LDS traffic per MFMA:
+    csrc/sdf_x6t.hip, sdf_back_x6t.hip) once a launch fills the chip with them (>= 128 rows x 256 CUs), one tile per wave (rounds of 64
+    rows, more and shorter rounds) below.  The two agree to fp32 summation order."""
+    return M >= SDF_TWO_TILE_MIN_ROWS
+
+
 def sdf_points_x6(x, M, blob, full, in_scale=1.0, out_scale=1.0):
-    """SDF value rows on exact three-piece operands (csrc/sdf_x6.hip): x [M,3] -> out [M,257] | [M]; blob = packing.pack_sdf_x6(full)."""
+    """SDF value rows on exact three-piece operands (csrc/sdf_x6.hip, sdf_x6t.hip): x [M,3] -> out [M,257] | [M]; blob = packing.pack_sdf_x6(full)."""
     x = _f32(x)
     out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
     if M > 0:
-        call("rb_sdf_x6_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_float(out_scale), ptr(out0),
+        call("rb_sdf_x6t_points" if sdf_two_tile(M) else "rb_sdf_x6_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_float(out_scale), ptr(out0),
              c_int(0), stream_ptr())
     return out0
 
 
 def sdf_value_grad_x6(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     """sdf_value_grad_f32 with both passes on exact three-piece operands (blob = packing.pack_sdf_x6(full=True), back =
-    packing.pack_sdf_back_x6)."""
-    wt, w8 = back
+    (packing.pack_sdf_back_x6(...), packing.pack_sdf_back_x6(..., two_tile=True)[0]) -- the one-tile kernel's transposed layers, the
+    head row, the two-tile kernel's transposed layers; a 2-tuple (round 3's form) runs the one-tile kernels at every size)."""
+    wt, w8 = back[0], back[1]
+    wt2 = back[2] if len(back) > 2 else None
     out0 = torch.empty(M, 257, dtype=torch.float32, device=x.device)
     grad = torch.empty(M, 3, dtype=torch.float32, device=x.device)
     if M == 0:
@@ -381,7 +393,9 @@ def sdf_value_grad_x6(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     x = _f32(x)
     for a in range(0, M, slab):
         n = min(slab, M - a)
-        call("rb_sdf_value_grad_x6_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob), ptr(wt), ptr(w8),
+        two = wt2 is not None and sdf_two_tile(n)
+        call("rb_sdf_value_grad_x6t_points" if two else "rb_sdf_value_grad_x6_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob),
+             ptr(wt2 if two else wt), ptr(w8),
              c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), stream_ptr())
     return out0, grad
 

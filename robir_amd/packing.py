@@ -251,8 +251,9 @@ def pack_sdf_back(sd, device):
     return pack_layers(ls, device), W[8][0].contiguous().to(device)
 
 
-def pack_sdf_back_x6(sd, device):
-    """pack_sdf_back with every weight as three halves, scale 2^0 (k_sdf_back_x6, csrc/sdf_back_x6.hip): W3^T's K 193 -> 224."""
+def pack_sdf_back_x6(sd, device, two_tile=False):
+    """pack_sdf_back with every weight as three halves, scale 2^0 (k_sdf_back_x6, csrc/sdf_back_x6.hip): W3^T's K 193 -> 224;
+    two_tile: K -> 256, every chunk of the stream one shape (k_sdf_back_x6t, csrc/sdf_back_x6t.hip)."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(SDF)}
     W = [_fold_wn(sdt, SDF + "lin%d." % l) for l in range(9)]
     m4 = torch.zeros(272, 256)
@@ -261,8 +262,8 @@ def pack_sdf_back_x6(sd, device):
     mats = [W[7].t(), W[6].t(), W[5].t(), m4, W[3].t(), W[2].t(), W[1].t(), W[0].t()]
     ls = [dict(W=m.contiguous(), b=None, n_pad=_pad16(m.shape[0]), k_pad=_pad32(m.shape[1]), perm=None) for m in mats]
     assert [l["n_pad"] for l in ls] == [256, 256, 256, 272, 256, 256, 256, 64] and ls[4]["k_pad"] == 224
-    if os.environ.get("ROBIR_SDF_X6_TILES") != "1":
-        ls[4]["k_pad"] = 256       # k_sdf_back_x6t (two tiles per wave, csrc/sdf_back_x6t.hip): every chunk of the stream has one shape
+    if two_tile:
+        ls[4]["k_pad"] = 256
     blob = pack_layers_x6(ls, device, scale_log2=0)
     return torch.cat([blob, torch.zeros(2048, device=device)]), W[8][0].contiguous().to(device)
 

@@ -14,7 +14,7 @@ def test_library_exports_header_symbols():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     L = _lib.lib()
-    assert L.rb_abi_version() == 4
+    assert L.rb_abi_version() == 5
     hdr = open(os.path.join(ROOT, "include", "robir_hip.h")).read()
     syms = sorted(set(re.findall(r"\b(rb_[a-z0-9_]+)\s*\(", hdr)))
     assert len(syms) >= 40

@@ -668,8 +668,9 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
     sd = synth_weights if weights == "init" else _trained_like(synth_weights, 5)
     g = torch.Generator().manual_seed(91)
     b32, back = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf_back(sd, dev)
-    x6f, x6d, back6 = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False), packing.pack_sdf_back_x6(sd, dev)
-    for n in (1, 15, 64, 65, 1000, 40000, 300001):
+    x6f, x6d = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False)
+    back6 = packing.pack_sdf_back_x6(sd, dev) + (packing.pack_sdf_back_x6(sd, dev, two_tile=True)[0],)     # as nets.packed_back_x6
+    for n in (1, 15, 64, 65, 1000, 40000, 300001):      # from 32768 rows on: the two-tile kernels (ops.sdf_two_tile)
         x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
         ref = ops.sdf_mlp_points(x, n, b32, 1, 2.0, 0.5, 1.0)[0]
         out = ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)
@@ -683,6 +684,19 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
             _, g32 = ops.sdf_value_grad_f32(x, n, b32, back, 2.0, 0.5)
             assert rel_err(grad.cpu(), g32.cpu()) <= 2e-5, (n, rel_err(grad.cpu(), g32.cpu()))
             assert torch.equal(grad, ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)[1]), n
+    # the two forms against each other on the same rows (another fp32 summation order), on both sides of the switch and ragged
+    for n in (100, 33000, 70001):
+        x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
+        res = {}
+        for rows in (1, 1 << 60):
+            old, ops.SDF_TWO_TILE_MIN_ROWS = ops.SDF_TWO_TILE_MIN_ROWS, rows
+            try:
+                res[rows] = (ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5),) + ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)
+            finally:
+                ops.SDF_TWO_TILE_MIN_ROWS = old
+        two, one = res[1], res[1 << 60]
+        assert rel_err(two[0].cpu(), one[0].cpu()) <= 2e-6 and rel_err(two[1].cpu(), one[1].cpu()) <= 2e-6, n
+        assert rel_err(two[2].cpu(), one[2].cpu()) <= 2e-5, (n, rel_err(two[2].cpu(), one[2].cpu()))
     x = ((torch.rand(300, 3, generator=g) - 0.5) * 1.2)
     osd = on.as_torch(sd)
     out = ops.sdf_points_x6(x.to(dev), 300, x6f, True, 2.0, 0.5)

@@ -42,7 +42,7 @@ out.append(f"dist {t:.3f} ms ({2 * (mac0 + 256 * 16) * n / t / 1e9 / 416.7:.3f})
 t = timed(lambda: ops.sdf_points_x6(p, n, b1, True))
 out.append(f"full {t:.3f} ms ({2 * (mac0 + 256 * 272) * n / t / 1e9 / 416.7:.3f})")
 if "grad" in sys.argv[3:]:
-    back = packing.pack_sdf_back_x6(w, dev)
+    back = packing.pack_sdf_back_x6(w, dev) + (packing.pack_sdf_back_x6(w, dev, two_tile=True)[0],)
     t = timed(lambda: ops.sdf_value_grad_x6(p, n, b1, back))
     out.append(f"value+grad {t:.3f} ms")
     v, gr = ops.sdf_value_grad_x6(p, n, b1, back)

@@ -21,7 +21,7 @@ x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
 v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
 feat = torch.randn(n, 257, generator=g).to(dev)
 hdr = torch.rand(n, 1, generator=g).to(dev)
-x6f, back6 = packing.pack_sdf_x6(w, dev, full=True), packing.pack_sdf_back_x6(w, dev)
+x6f, back6 = packing.pack_sdf_x6(w, dev, full=True), packing.pack_sdf_back_x6(w, dev) + (packing.pack_sdf_back_x6(w, dev, two_tile=True)[0],)
 col6, vis6, ill6 = packing.pack_color_x6(w, dev), packing.pack_vis_x6(w, dev), packing.pack_illum_x6(w, dev)
 sh6 = packing.pack_softplus512_x6({"net." + k: t for k, t in c["shadow_net"].items()}, "net.", 191, dev)
 no6 = packing.pack_softplus512_x6({"net." + k: t for k, t in c["normal_net"].items()}, "net.", 63, dev)
