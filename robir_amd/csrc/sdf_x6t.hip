@@ -150,7 +150,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       ev[i][e] = v;
       sg[i][e] = s;
       if constexpr (STORE)
-        if (e == 1) {    // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
+#ifdef SXT_ABL_HALF_STORES              // timing ablation (wrong results): only the first pair of a tile's float4 is stored
+        if (e == 1 && q == 0) {
+#else
+        if (e == 1) {
+#endif
+          // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
           typedef unsigned u2v __attribute__((ext_vector_type(2)));
           const unsigned voff = xt_lane16<0>();       // re-derived: x6t_engine.h
           int sbase = sig_wave + lr * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
@@ -224,7 +229,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       // the descriptor): the previous chunk carried the epilogue of the chunk before it; a layer's first chunk follows the previous
       // layer's last chunk AND the tail epilogue of that chunk
       int ns = 0;
-      if (jb >= 2) ns = ep_stores(OUT, jb - 2);
+      if (jb >= 3) ns = ep_stores(OUT, jb - 2) + ep_stores(OUT, jb - 3);      // copies first: the stores of two chunks may be in flight
+      else if (jb == 2) ns = ep_stores(OUT, jb - 2);
       else if (jb == 1) ns = PEND ? ep_stores(false, 0) : 0;          // chunk 0 carried the previous layer's pending last chunk
       else ns = ep_stores(LI == 0, PNCH - 2) + (LI == 0 ? ep_stores(true, PNCH - 1) : 0);      // an output layer finishes its last chunk at once
       switch (sx_nsw(K2) + ns) {
@@ -240,6 +246,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
         case 15: sx_wait<15>(); break;
         case 16: sx_wait<16>(); break;
         case 18: sx_wait<18>(); break;
+        case 22: sx_wait<22>(); break;
+        case 23: sx_wait<23>(); break;
         default: sx_wait<2>(); break;      // any combination not listed: the strictest wait (safe)
       }
 #ifndef SXT_NOBAR
@@ -277,9 +285,12 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
             }
           return;
         }
+        // the copies take the chunk's first free positions, the epilogue items the rest: a store of the epilogue is then younger than
+        // the copies of its own chunk and has two chunks to retire before a counted wait needs it, not one (stores and copies share
+        // the in-order vmcnt queue; the sigmoid tiles go to HBM)
 #pragma unroll
         for (int i = 0; i < 22; ++i)
-          if (i < ni && xt_item_slot(i, ni, NFREE) == a) {
+          if (i < ni && (i < ne ? NC3 + xt_item_slot(i, ne > 0 ? ne : 1, NFREE - NC3) : i - ne) == a) {
             if (i < ne) {
               if (jb > 0) ep_item(i, jb - 1);
             } else {
