@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import rel_err
+
 pytestmark = pytest.mark.gpu
 KEYS = ("sg_rgb", "indir_rgb", "vis_shadow", "diffuse_albedo", "roughness", "normal_map", "points", "sdf_output")
 
@@ -196,8 +198,10 @@ def test_config2_render_neus_400x400(dev, synth_weights):
 
 
 def test_config1_sdf_forward_64x64x64(dev, synth_weights):
-    """64x64 crop, 64 samples per ray: the SDF network on 262 144 points equals itself evaluated in 1024-row chunks (the
-    reference's own chunk loop, neus_model.py:398-415)."""
+    """64x64 crop, 64 samples per ray: the SDF network on 262 144 points against itself evaluated in 1024-row chunks (the
+    reference's own chunk loop, neus_model.py:398-415).  Since round 4 the exact-operand net has two kernel forms -- two tiles per wave
+    from 32768 rows on, one tile below (ops.sdf_two_tile) -- which sum a weight class's products in different orders: the whole batch
+    and its 1024-row chunks agree to fp32 summation order (<= 2e-6 of the largest output), each form with itself bit for bit."""
     from robir_amd import nets, ops, synth
     m = nets.NeuSModel()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
@@ -210,7 +214,14 @@ def test_config1_sdf_forward_64x64x64(dev, synth_weights):
     full = net(pts)
     assert full.shape == (64 * 64 * 64, 257) and bool(torch.isfinite(full).all())
     part = torch.cat([net(pts[i:i + 1024]) for i in range(0, 8192, 1024)])
-    assert torch.equal(part, full[:8192])
+    assert rel_err(part.cpu(), full[:8192].cpu()) <= 2e-6
+    assert torch.equal(full, net(pts))                                                        # run to run
+    assert torch.equal(part[:4096], torch.cat([net(pts[i:i + 2048]) for i in range(0, 4096, 2048)]))      # any chunking below the switch
+    old, ops.SDF_TWO_TILE_MIN_ROWS = ops.SDF_TWO_TILE_MIN_ROWS, 1 << 60
+    try:
+        assert torch.equal(part, net(pts)[:8192])                                             # one form at both sizes: bit-identical
+    finally:
+        ops.SDF_TWO_TILE_MIN_ROWS = old
 
 
 def test_config5_cesr_chunks_of_1600x1200(dev):

@@ -3,7 +3,7 @@
 # of the dominant kernels, per-chunk / deferred rates.  usage: bash tools/run_final_profiles.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/final
 mkdir -p $O
 prof() {  # name, command...
@@ -37,7 +37,7 @@ unset ROBIR_PRECISION
 python tools/prof_perchunk.py 2>/dev/null | grep per-chunk | sed 's/^/exact policy: /' >> $O/${TAG}_perchunk_rate.txt
 for C in 2 3 5; do RB_CONFIG_REPS=1 prof config${C}_exact python tools/bench_configs.py $C; done
 RB_CONFIG_REPS=1 pmc config2_exact "sdf_x6\|sdf_back_x6\|color_x6" python tools/bench_configs.py 2
-pmc dvis_x6 "dvis_x6" python tools/prof_dvis.py f16x6 32
+pmc dvis_x6t "dvis_x6t" python tools/prof_dvis.py f16x6 32
 pmc dvis_v2 "dvis_v2" python tools/prof_dvis.py f16x3-v2 32
 export ROBIR_PRECISION=split RB_CONFIG_REPS=1
 pmc config2 "sdf_ring8\|sdf_back\|color_mlp\|color_ring" python tools/bench_configs.py 2
