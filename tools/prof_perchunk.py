@@ -3,6 +3,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from robir_amd import renderer, synth
 dev = torch.device("cuda:0")
 model = renderer.build_synthetic_model(dev)
+model.deferred_chunks = 0        # the IMMEDIATE call shape: every forward() runs at once (the default since round 4 records eval-mode chunks:
+                                 # tools/prof_deferred.py and bench.py's `extras.runner_plot_loop` time that form)
 uv, pose, K = synth.synth_camera(800, 800)
 uv_d = torch.from_numpy(uv).to(dev); pose_d = torch.from_numpy(pose).to(dev)[None]; K_d = torch.from_numpy(K).to(dev)[None]
 om = torch.ones(1, 1024, dtype=torch.bool, device=dev); hdr = torch.full((1024, 1), 0.5, device=dev)
