@@ -56,6 +56,9 @@ PRECISIONS = {
               "fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the 32 -> 128 "
               "-> 16 auto-encoder decoders on the f32-input MFMA) -- not narrower than the reference's fp32"),
     "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
+    "f16": ("f16x1", "f16x6", "f16 (light-visibility MLP: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
+                              "every other net as under `exact`) -- NARROWER than the reference's fp32: a labelled throughput mode "
+                              "(BASELINE.json configs[4]: 'fp16 MLP weights on MFMA'), not a parity claim; error table in DESIGN.md"),
     "split": ("f16x3-auto", "f16x3", "f32 operands as 22-bit f16 hi/lo pairs, 3 f16 MFMA products per multiply-add, fp32 accumulate "
                                      "(parity-tested throughput mode; NARROWER than fp32)"),
 }
@@ -73,7 +76,7 @@ def parse():
                     help="arithmetic of the MLP layers.  exact (default, the headline): not narrower than fp32 -- the light-visibility "
                          "MLP with exact three-piece f16 operands (6 MFMA products per multiply-add), the other MLPs on the "
                          "f32-input MFMA; fp32-mfma: everything on the f32-input MFMA; split: 22-bit hi/lo operand pairs, 3 "
-                         "products (faster, narrower than fp32)")
+                         "products (faster, narrower than fp32); f16: the light-visibility MLP in plain f16, one product (throughput mode, NARROWER)")
     ap.add_argument("--chunks-per-batch", type=int, default=625,
                     help="1024-pixel chunks rendered per kernel pass (625 = the whole 800x800 view; 2.7 GB of tables)")
     ap.add_argument("--cpu-baseline-chunks", type=int, default=4)
@@ -266,6 +269,8 @@ def vis_peak(vis):
     """Peak of the pipe the light-visibility kernel runs on, per ALGORITHMIC flop."""
     if vis == "fp32":
         return PEAK_FP32_MFMA_TFLOPS, "dense f32-input MFMA (v_mfma_f32_16x16x4_f32)"
+    if vis == "f16x1":
+        return PEAK_F16_MFMA_TFLOPS, "dense f16 MFMA 2500 TFLOP/s, one product per multiply-add (plain f16 operands: NARROWER than fp32)"
     if vis == "f16x6":
         return PEAK_F16_MFMA_TFLOPS / 6.0, "dense f16 MFMA 2500 TFLOP/s / 6 products per multiply-add (exact three-piece operands)"
     return PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)"

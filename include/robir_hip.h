@@ -314,6 +314,14 @@ int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long n, const f
                       const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                       unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
                       int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* The same stage in PLAIN f16 (csrc/vis_diffuse_f16t.hip, round 4): ONE f16 MFMA product per multiply-add, fp32 accumulation, weights
+ * = the round-to-nearest f16 of the fp32 weights (the h pieces of the blob rb_dvis_stream_x6 takes), activations truncated to f16
+ * between the layers -- the labelled throughput mode BASELINE.json configs[4] names, NARROWER than the reference's fp32, never a
+ * default (ROBIR_PRECISION=f16 only).  Arguments and scratch of rb_dvis_stream_x6. */
+int rb_dvis_stream_f16(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                       const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
+                       unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
+                       int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
  *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
  *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point

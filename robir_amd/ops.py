@@ -496,7 +496,7 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
 
 
 DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6t", "f16x6-pt": "k_dvis_x6t", "f16x6-stream": "k_dvis_x6t<stream>",
-                     "f16x6-1t": "k_dvis_x6", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
+                     "f16x6-1t": "k_dvis_x6", "f16x1": "k_dvis_f16t", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
                      "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
 
 
@@ -516,7 +516,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
     h3 = precision.startswith("f16x3")
     X6 = ("f16x6", "f16x6-1t", "f16x6-pt", "f16x6-stream")
-    assert h3 or precision == "fp32" or precision in X6, precision
+    assert h3 or precision in ("fp32", "f16x1") or precision in X6, precision
     if precision == "f16x6":
         # "auto": the persistent tile-list form for launches up to DVIS_STREAM_MAX_POINTS points (a single 1024-pixel chunk: balanced
         # over the CUs, 0.4 % tile padding), one workgroup per point beyond (no scratch); the two are bit-identical
@@ -530,7 +530,7 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     out = torch.empty(n, L, dtype=torch.float32, device=normals.device)
     if chunk_id is not None:
         assert chunk_id.dtype == torch.int32
-    if precision in ("f16x3-v3", "f16x6-stream"):
+    if precision in ("f16x3-v3", "f16x6-stream", "f16x1"):
         # streaming form: global tile list + persistent grid (csrc/vis_diffuse_v3.hip, vis_diffuse_x6t.hip); scratch sized for the
         # worst case (every direction front-facing) so that nothing has to be read back to the host
         LS = L * nsamp
@@ -540,8 +540,8 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         tile_info = torch.empty(n * LS // 16, 2, dtype=torch.int32, device=dev)
         point_info = torch.empty(n, 2, dtype=torch.int32, device=dev)
         counters = torch.empty(2, dtype=torch.int64, device=dev)
-        x6 = precision == "f16x6-stream"
-        call("rb_dvis_stream_x6" if x6 else "rb_dvis_stream", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+        x6 = precision in ("f16x6-stream", "f16x1")      # "f16x1": plain f16, one product (csrc/vis_diffuse_f16t.hip): NARROWER than fp32
+        call("rb_dvis_stream_f16" if precision == "f16x1" else ("rb_dvis_stream_x6" if x6 else "rb_dvis_stream"), ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
              ptr(split["hidden_x6_head" if x6 else "hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["x6_head_scale_log2" if x6 else "h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())

@@ -9,18 +9,24 @@
   ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
                                     2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
                                     guarded by the activation-range sentinel (ops.range_check).
+  ROBIR_PRECISION=f16               the labelled THROUGHPUT mode `BASELINE.json configs[4]` names ("fp16 MLP weights on MFMA"), round 4:
+                                    the light-visibility MLP in PLAIN f16 -- one f16 MFMA product per multiply-add, f16 weights
+                                    (round-to-nearest) and f16 activations (truncated between the layers), fp32 accumulation
+                                    (csrc/vis_diffuse_f16t.hip); every other net as under `exact` (no one-product kernels exist for
+                                    them).  NARROWER than the reference's fp32: never a default, never a parity claim; its measured
+                                    error against the oracle is in DESIGN.md and printed by tests/test_precision_gpu.py.
 ROBIR_VIS_PRECISION / ROBIR_MLP_PRECISION override the two halves of the policy separately (A/B runs, tests).
 """
 import os
 
-POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3")}
-VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3")
+POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3"), "f16": ("f16x1", "f16x6")}
+VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3", "f16x1", "f16x6-1t", "f16x6-pt", "f16x6-stream")
 
 
 def policy():
     p = os.environ.get("ROBIR_PRECISION", "exact")
     if p not in POLICIES:
-        raise ValueError("ROBIR_PRECISION must be exact or split")
+        raise ValueError("ROBIR_PRECISION must be exact, split or f16")
     return p
 
 

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, load_golden
+from conftest import record_metric, rel_err, load_golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -237,6 +237,46 @@ def test_fused_visibility_is_deterministic(dev, vis_net):
         d3 = float((outs["f16x3-v2"] - outs["fp32"]).abs().max())
         print(f"max |vis - vis_fp32|: f16x6 {d6:.2e}, f16x3-v2 {d3:.2e}")
         assert d6 <= 2e-6, d6
+    finally:
+        sg_render.VIS_PRECISION = old
+
+
+def test_f16_throughput_mode_error_is_measured(dev, vis_net):
+    """ROBIR_PRECISION=f16 (BASELINE.json configs[4]: "fp16 MLP weights on MFMA"): the light-visibility MLP with ONE f16 product per
+    multiply-add, f16 weights and f16 activations (csrc/vis_diffuse_f16t.hip).  NARROWER than fp32 by construction -- this test does
+    not claim parity: it MEASURES the per-lobe visibility against the f32-input-MFMA kernel on the same points, directions and draws
+    (median / 99th percentile / maximum absolute difference of values in [0, 1], recorded in gpurun_out/test_metrics.jsonl; DESIGN.md
+    quotes them) and holds the mode to a sanity band and to run-to-run bit-identity."""
+    from robir_amd import sg_render, synth
+    g = np.random.Generator(np.random.PCG64(8))
+    n = 3000
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32)).to(dev)
+    nrm = torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128)).to(dev)
+    u = torch.from_numpy(g.random((2, 3, 128, 32), dtype=np.float32)).to(dev)
+    cid = (torch.arange(n, dtype=torch.int32, device=dev) % 3).contiguous()
+    old = sg_render.VIS_PRECISION
+    try:
+        outs = {}
+        for mode in ("f16x1", "f16x6", "fp32"):
+            sg_render.VIS_PRECISION = mode
+            outs[mode] = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, 3, None)
+        sg_render.VIS_PRECISION = "f16x1"
+        again = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, 3, None)
+        assert torch.equal(again, outs["f16x1"])
+        for am in (False, True):       # the argmax form (testing=True paths): a flipped sample moves a lobe by 1 / 32
+            sg_render.VIS_PRECISION = "f16x1"
+            a = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, am, cid, 3, None)
+            sg_render.VIS_PRECISION = "fp32"
+            b = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, am, cid, 3, None)
+            d = (a - b).abs().flatten().double()
+            q = torch.quantile(d[torch.randperm(d.numel(), device=d.device)[:200000]], torch.tensor([0.5, 0.99], device=d.device, dtype=torch.float64))
+            record_metric("f16_mode/light_visibility_" + ("argmax" if am else "softmax"), median=float(q[0]), p99=float(q[1]), max=float(d.max()),
+                          exact_operand_max=float((outs["f16x6"] - outs["fp32"]).abs().max()))
+            print(f"f16 mode, {'argmax' if am else 'softmax'} visibility vs f32-MFMA: median {float(q[0]):.2e}  p99 {float(q[1]):.2e}  max {float(d.max()):.2e}")
+            if not am:
+                assert float(q[0]) <= 2e-3 and float(q[1]) <= 2e-2 and float(d.max()) <= 0.25, (float(q[0]), float(q[1]), float(d.max()))
     finally:
         sg_render.VIS_PRECISION = old
 
