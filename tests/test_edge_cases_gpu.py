@@ -298,3 +298,64 @@ def test_round3_second_half_entry_points_on_empty_tiny_and_bad_inputs(dev, synth
     none = ops.scatter_rows([src3[:0], None], [3, 1], idx[:0], 4, fill=0.5)
     assert all(bool((t == 0.5).all()) for t in none) and none[0].shape == (4, 3)
     ops.range_check(sync=True)
+
+
+def test_round4_entry_points_on_empty_tiny_and_ragged_inputs(dev, synth_weights):
+    """The two-tile exact-operand kernels through the C ABI at the edges: zero rows (no launch), one row, rows that do not fill a
+    128-row round or a 16-row tile, a point whose normal culls every direction, bad arguments (an error code and a message, no launch);
+    the per-point and the tile-list form of the light-visibility kernel on the same tiny input; the f16 throughput mode on it."""
+    import ctypes
+    from robir_amd import _lib, ops, packing, renderer, sg_render, synth
+    x6f, x6d = packing.pack_sdf_x6(synth_weights, dev, full=True), packing.pack_sdf_x6(synth_weights, dev, full=False)
+    back6 = packing.pack_sdf_back_x6(synth_weights, dev) + (packing.pack_sdf_back_x6(synth_weights, dev, two_tile=True)[0],)
+    g = torch.Generator().manual_seed(11)
+    old_min = ops.SDF_TWO_TILE_MIN_ROWS
+    try:
+        for n in (0, 1, 17, 127, 129, 300):
+            x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.0).to(dev)
+            ops.SDF_TWO_TILE_MIN_ROWS = 1 << 60
+            ref_v, ref_g = ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)
+            ref_d = ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5)
+            ops.SDF_TWO_TILE_MIN_ROWS = 0            # force the two-tile kernels at every size
+            v, gr = ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)
+            d = ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5)
+            assert v.shape == (n, 257) and gr.shape == (n, 3) and d.shape == (n,)
+            if n:
+                assert rel_err(v.cpu(), ref_v.cpu()) <= 2e-6 and rel_err(d.cpu(), ref_d.cpu()) <= 2e-6, n
+                assert rel_err(gr.cpu(), ref_g.cpu()) <= 2e-5, n
+                assert torch.equal(d, v[:, 0]) and torch.equal(v, ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)), n
+    finally:
+        ops.SDF_TWO_TILE_MIN_ROWS = old_min
+    L = _lib.lib()
+    one = torch.zeros(1, 3, device=dev)
+    out = torch.zeros(257, device=dev)
+    rc = L.rb_sdf_x6t_points(_lib.ptr(one), ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(7), ctypes.c_float(1.0),
+                             _lib.ptr(out), ctypes.c_int(0), _lib.stream_ptr())
+    assert rc != 0 and b"mode" in L.rb_last_error()
+    rc = L.rb_sdf_x6t_points(None, ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(1), ctypes.c_float(1.0),
+                             _lib.ptr(out), ctypes.c_int(0), _lib.stream_ptr())
+    assert rc != 0 and b"null" in L.rb_last_error()
+    assert L.rb_sdf_x6t_points(None, ctypes.c_long(0), ctypes.c_float(1.0), None, ctypes.c_int(1), ctypes.c_float(1.0), None,
+                               ctypes.c_int(0), _lib.stream_ptr()) == 0          # zero rows: nothing to do, not an error
+    # light visibility: 8 lobes x 4 samples, three points (one whose normal faces away from every direction: all culled)
+    m = renderer.build_synthetic_model(dev, build_octrees=False)
+    lgt = torch.from_numpy(synth.synth_light_sgs(0, 128))[:8].to(dev)
+    u = torch.rand(2, 8, 4, generator=g).to(dev)
+    pts = torch.tensor([[0.05, -0.1, 0.2], [0.0, 0.1, 0.25], [0.1, 0.1, 0.1]], device=dev)
+    nrm = torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.0, 0.0], [0.6, 0.0, 0.8]], device=dev)
+    old, old_form = sg_render.VIS_PRECISION, ops.DVIS_X6_FORM
+    try:
+        res = {}
+        for form in ("f16x6-pt", "f16x6-stream", "f16x6-1t", "fp32", "f16x1"):
+            sg_render.VIS_PRECISION = form
+            res[form] = [sg_render._diffuse_vis_core(pts, nrm, m.visibility_network, lgt, u[0], u[1], 1.0, am, None, 1, None) for am in (False, True)]
+            assert res[form][0].shape == (3, 8) and float(res[form][0][1].abs().max()) == 0.0, form     # the culled point: zeros, like the reference
+            e3 = torch.zeros(0, 3, device=dev)
+            assert sg_render._diffuse_vis_core(e3, e3, m.visibility_network, lgt, u[0], u[1], 1.0, False, None, 1, None).shape == (0, 8)
+        for am in (0, 1):
+            assert torch.equal(res["f16x6-pt"][am], res["f16x6-stream"][am])                         # two forms of one kernel body
+            assert float((res["f16x6-pt"][am] - res["fp32"][am]).abs().max()) <= 2e-6
+            assert float((res["f16x6-1t"][am] - res["fp32"][am]).abs().max()) <= 2e-6
+        assert float((res["f16x1"][0] - res["fp32"][0]).abs().max()) <= 5e-3                         # the narrower mode: sane, not equal
+    finally:
+        sg_render.VIS_PRECISION, ops.DVIS_X6_FORM = old, old_form
