@@ -18,7 +18,11 @@ for line in open(src):
         meas[n] = max(meas.get(n, 0.0), d["max"])
         caps[n] = max(2.0 * meas[n], 1.2e-7)
 dst = os.path.join(ROOT, "tests", "golden", "measured_caps.json")
-old = json.load(open(dst)) if os.path.exists(dst) and "--fresh" not in sys.argv else {}
+prev = json.load(open(dst)) if os.path.exists(dst) else {}
+if "--fresh" in sys.argv and len(caps) < len(prev):      # a metrics file of a partial run (gpurun merges the LAST call's file): keep the caps
+    sys.exit(f"{src} holds {len(caps)} bounded comparisons, the caps file {len(prev)}: run the whole GPU suite (both precision policies) "
+             "with ROBIR_RECORD_CAPS=1 before --fresh")
+old = prev if "--fresh" not in sys.argv else {}
 if "--raise-only" in sys.argv:         # a re-measurement after an arithmetic change: never tighten what another policy / run needed
     caps = {k: max(v, old.get(k, 0.0)) for k, v in caps.items()}
 old.update(caps)                      # comparisons not re-measured in this run keep their recorded cap
