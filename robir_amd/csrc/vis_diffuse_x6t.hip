@@ -237,23 +237,31 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
   // direction index, 0xFFFF = padding), looked up at the top of a round and used by the fetches of its head
   int tpn[2] = {-1, -1}, tbn[2] = {0, 0}, jn2[2] = {0xFFFF, 0xFFFF};
   const unsigned arow_b = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)a_rows);
+  // (branch-free: a conditional load makes the compiler wait for the record at the join, i.e. at the top of the round; loaded
+  // unconditionally from a clamped index the record is waited for where the head uses it, a round later)
+  XtTile recn[2] = {{-1, 0}, {-1, 0}};
+  bool okn[2] = {false, false};
   auto tile_lookup = [&](long round) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const long T = round * 8 + wave * 2 + t;
-      XtTile rec{-1, 0};
-      int j = 0xFFFF;
-      if (round < total_rounds && T < total_tiles) {
-        rec = a.tile_info[T];                                  // wave-uniform address: scalar load
-        j = (int)a.pair_j[T * 16 + (lane & 15)];
-      }
-      tpn[t] = __builtin_amdgcn_readfirstlane(rec.point);
-      tbn[t] = __builtin_amdgcn_readfirstlane(rec.dir_base);
-      jn2[t] = j;
+      okn[t] = round < total_rounds && T < total_tiles;
+      const long Tc = T < total_tiles ? T : total_tiles - 1;   // total_tiles >= 1 here
+      recn[t] = a.tile_info[Tc];                               // wave-uniform address: scalar load
+      jn2[t] = (int)a.pair_j[Tc * 16 + (lane & 15)];
+    }
+  };
+  auto tile_resolve = [&]() {      // at the point of use (the head)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      tpn[t] = okn[t] ? __builtin_amdgcn_readfirstlane(recn[t].point) : -1;
+      tbn[t] = okn[t] ? __builtin_amdgcn_readfirstlane(recn[t].dir_base) : 0;
+      if (!okn[t]) jn2[t] = 0xFFFF;
     }
   };
   auto fetch_rows = [&](long rd_next, int parity_next) {
     if constexpr (STREAM) {
+      tile_resolve();
       // the A rows of the next round's two tiles -> this wave's private slots by LDS-DMA (1 KB per tile): OLDER than the row loads
       // below, whose wait the compiler places in front of the layer-0 split
 #pragma unroll
