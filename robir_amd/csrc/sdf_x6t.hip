@@ -5,9 +5,13 @@
 //
 // Persistent workgroups of four waves, rounds of 128 rows (wave w, tile t: rows 128 r + 64 t + 16 w ..).  Per chunk: s_waitcnt + s_barrier
 // at its top, K / 32 / WK parts of twelve MFMA runs (WK = 2 / 4 / 3 k-blocks for K = 64 / 256 / 288), the fragment window refilled piece
-// by piece, the copies of the chunk three ahead and the previous chunk's epilogue (softplus + exact three-way split of four value pairs:
-// twelve items) spread over the runs that carry no refill.  The biases of all chunks are resident in the LDS (9 KB), the encoded rows of
-// a round too (32 KB: the skip layer's input part is rebuilt from them, the operand registers are all taken).
+// by piece, the copies of the chunk three ahead FIRST (a store of the epilogue is then younger than its chunk's copies and has two
+// chunks to retire in the shared in-order vmcnt queue) and the previous chunk's epilogue (softplus + exact three-way split of four value
+// pairs: thirteen items) over the runs that carry no refill; a hidden layer's LAST chunk is finished beside the next layer's first
+// chunk, written straight into that layer's own operands.  The biases of all chunks are resident in the LDS (9 KB), the encoded rows of
+// a round too (32 KB: the skip layer's input part is rebuilt from them, the operand registers are all taken); outputs and sigmoid tiles
+// leave through per-round buffer descriptors (one address register, lanes out of range dropped: no branch splits a chunk); the lane
+// offset of a copy is re-derived per copy (x6t_engine.h: xt_lane16).
 // MODE 0: signed distance only -> out0[M].   MODE 1: all 257 outputs -> out0[M,257].   MODE 5: MODE 1 + sigmoid(100 z) of every hidden
 // pre-activation -> sig [tile = row / 16][layer 8][chunk 16][lane 64] float4, the layout k_sdf_back_* read.
 // The products of a class are summed part by part, not product by product over the whole chunk as in k_sdf_x6: another fp32 summation
