@@ -152,6 +152,10 @@ int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, i
 /* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
 int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
+/* rb_color_x6_points with TWO 16-row tiles per wave (csrc/color_x6t.hip + x6t_engine.h, round 4): same arguments, same blob, results agree
+ * with rb_color_x6_points to fp32 summation order.  The host mirror takes it for >= 32768 rows. */
+int rb_color_x6t_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
 /* The visibility MLP on exact three-piece operands (csrc/vis_x6.hip; Wp = packing.pack_vis_x6): the arguments of rb_vis_mlp_points. */
 int rb_vis_x6_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, int n_workgroups, rb_stream_t stream);
 /* The 512-wide ReLU nets (SparseAE encoder: raw latent [M,32]; indirect-illumination decoder: raw SG outputs [M,144]) on exact

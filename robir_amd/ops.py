@@ -236,13 +236,16 @@ def color_mlp_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0):
     return rgb
 
 
-def color_x6_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0):
-    """color_mlp_points on exact three-piece operands (csrc/color_x6.hip; blob = packing.pack_color_x6)."""
+def color_x6_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0, two_tile=None):
+    """color_mlp_points on exact three-piece operands (blob = packing.pack_color_x6): csrc/color_x6t.hip (two tiles per wave, rounds of 128
+    rows) from SDF_TWO_TILE_MIN_ROWS rows on, csrc/color_x6.hip (one tile, rounds of 64) below; two_tile forces either."""
     x, view, normal = _f32(x), _f32(view), _f32(normal)
     assert feat.dtype == torch.float32 and feat.stride(-1) == 1
     M = x.shape[0]
     rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
-    call("rb_color_x6_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
+    if two_tile is None:
+        two_tile = sdf_two_tile(M)
+    call("rb_color_x6t_points" if two_tile else "rb_color_x6_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
          ptr(view), ptr(normal), c_long(M), ptr(blob), ptr(rgb), c_int(0), stream_ptr())
     return rgb
 

@@ -707,19 +707,20 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
 
 
 def test_color_exact_operand_kernel(dev, synth_weights):
-    """k_color_x6 (csrc/color_x6.hip) against the f32-input-MFMA colour kernel on the same inputs: ragged sizes, many rounds, run to run."""
+    """k_color_x6 / k_color_x6t (csrc/color_x6.hip, color_x6t.hip) against the f32-input-MFMA colour kernel on the same inputs: ragged sizes, many rounds, run to run."""
     from robir_amd import ops, packing
     g = torch.Generator().manual_seed(97)
     b32, x6 = packing.pack_color(synth_weights, dev), packing.pack_color_x6(synth_weights, dev)
-    for n in (1, 15, 64, 65, 5000, 300001):
+    for n in (1, 15, 64, 65, 129, 5000, 300001):
         x = ((torch.rand(n, 3, generator=g) - 0.5)).to(dev)
         v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         nr = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
         out = torch.randn(n, 257, generator=g).to(dev)
         ref = ops.color_mlp_points(x, v, nr, out[:, 1:], b32, x_scale=2.0, feat_scale=2.0)
-        a = ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0)
-        assert float((a - ref).abs().max()) <= 2e-6, (n, float((a - ref).abs().max()))
-        assert torch.equal(a, ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0)), n
+        for two in (False, True):       # one tile per wave (color_x6.hip) | two (color_x6t.hip): either form at every size
+            a = ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0, two_tile=two)
+            assert float((a - ref).abs().max()) <= 2e-6, (n, two, float((a - ref).abs().max()))
+            assert torch.equal(a, ops.color_x6_points(x, v, nr, out[:, 1:], x6, x_scale=2.0, feat_scale=2.0, two_tile=two)), (n, two)
     ops.range_check(sync=True)
 
 
