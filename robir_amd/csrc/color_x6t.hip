@@ -263,6 +263,9 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
       const long row0 = round * 128, rows = M - row0 < 128 ? M - row0 : 128;
       out_rsrc = __builtin_amdgcn_make_buffer_rsrc(rgb + row0 * 3, 0, (int)rows * 12, 0x00020000);
     }
+#ifdef CT_ABL_LOAD_ONCE               // timing ablation (wrong results): the input stage only in a workgroup's first round
+    if (round == (long)blockIdx.x)
+#endif
     load_layer0();
     // layer 0 (K = 320) | 1, 2 (one instance) | 3 (followed by the output chunk and the next round's first chunks) | 4: straight-line
     run_layer(std::integral_constant<int, 0>{}, 0);

@@ -48,6 +48,9 @@ class ForwardOnlyError(RuntimeError):
     pass
 
 
+PRECISE_GRAD_SPLIT = os.environ.get("ROBIR_PRECISE_GRAD", "split") == "split"      # "jvp": value and gradient in one f32-input pass (round 3)
+
+
 def forward_only_guard(module):
     """The HIP kernels have no backward: a training-mode call that autograd would have to differentiate must not silently
     return detached tensors (loss.backward() would then train only whatever still carries a graph)."""
@@ -521,6 +524,11 @@ class SDFNetwork(nn.Module):
             return ops.sdf_value_grad(x, M, self.packed_h3(True), self.packed_back_h3(), packing.H3_SCALE_LOG2, in_scale,
                                       out_scale)
         x6 = mlp_precision() == "f16x6"
+        if grad and precise and not full and x6 and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse" and PRECISE_GRAD_SPLIT:
+            # the octree's cell table (octree_tracing.build): the VALUE with the library-grade softplus (one row per point on the f32-input
+            # MFMA), the GRADIENT by the policy's reverse pass on exact operands -- not three more tangent rows per point on the slow pipe
+            val = ops.sdf_mlp_points(x, M, self.packed(False), 4, in_scale, out_scale, out_scale * in_scale)[0]
+            return val, ops.sdf_value_grad_x6(x, M, self.packed_x6(True), self.packed_back_x6(), in_scale, out_scale)[1]
         if (grad and not precise and mlp_precision() in ("fp32", "f16x6") and ops.SDF_FUSED_PE and ops.SDF_GRAD == "reverse"
                 and M >= (1 if x6 else ops.SDF_GRAD_F32_MIN_POINTS)):      # exact operands: three launches of 0.07 ms beat 0.31
             # the same at the reference's precision: value pass on exact three-piece operands (or the f32-input MFMA) + one pass over

@@ -8,6 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("ROBIR_AB_LIB"):
+    from robir_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["ROBIR_AB_LIB"])
 from robir_amd import ops, packing, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
