@@ -135,6 +135,10 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
     (roughness, draws) and sg_rgb = the diffuse term (sg_render.py:413,544-551).
     lgt_sgs [n,M,7].  draws: dict with 'dvis_theta','dvis_phi' [M,32] (comp_vis only) and
     'svis_theta','svis_phi' [n,8]."""
+    if viewdirs.dim() == 3:
+        return _render_with_sg_multi_view(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws,
+                                          comp_vis, vis_fn, lin_diff, testing, indir_integral, metallic, argmax_vis, stats, diffuse_vis,
+                                          prefit, fun_spec)
     n, M = lgt_sgs.shape[0], lgt_sgs.shape[1]
     supervise = torch.tensor(0.0)
     l_lobe = lgt_sgs[..., :3] / (lgt_sgs[..., :3].norm(dim=-1, keepdim=True) + TINY)
@@ -184,8 +188,50 @@ def render_with_sg(points, normal, viewdirs, lgt_sgs, specular_reflectance, roug
             "supervise": supervise}
 
 
+def _warped_lobe(nrm, view, roughness):
+    """The BRDF lobe of `roughness` around the normal, warped to the view (sg_render.py:416-428) -> lobe [n,M,3], lambda [n,M,1]."""
+    n, M = nrm.shape[0], nrm.shape[1]
+    r4 = 2.0 / (roughness * roughness * roughness * roughness)
+    vdl = (nrm * view).sum(-1, keepdim=True).clamp(min=0.0)
+    w_lobe = 2 * vdl * nrm - view
+    return w_lobe / (w_lobe.norm(dim=-1, keepdim=True) + TINY), r4.unsqueeze(1).expand(n, M, 1) / (4 * vdl + TINY)
+
+
+def _render_with_sg_multi_view(points, normal, viewdirs, lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws, comp_vis, vis_fn,
+                               lin_diff, testing, indir_integral, metallic, argmax_vis, stats, diffuse_vis, prefit, fun_spec):
+    """MULTI_VIEW form of render_with_sg: viewdirs [V,n,3] (sg_render.py:356, 375-378, 465-470; get_specular_visibility's multi_view
+    branches, :227-231 and :247-258).  Light visibility, diffuse term, shadow and supervision do not see the view: computed once, [n,.].
+    The specular term is the single-view formula of every view, except for its sampled visibility: ONE set of draws [n,nsamp] serves all
+    views, the cone range comes from the smallest sharpness over ALL views and points (:222), and the branch always takes the arg-max of
+    the two logits -- never inverted, never the soft-max, whatever inv / argmax_vis say (:257).  -> sg_specular_rgb, sg_rgb [V,n,3].
+    In the reference's broadcast form the rows of view v are rows v n .. v n + n - 1 of one batch: restated that way."""
+    V, n, M = viewdirs.shape[0], lgt_sgs.shape[0], lgt_sgs.shape[1]
+    base = render_with_sg(points, normal, viewdirs[0], lgt_sgs, specular_reflectance, roughness, diffuse_albedo, draws, comp_vis=comp_vis,
+                          vis_fn=vis_fn, lin_diff=lin_diff, testing=testing, indir_integral=indir_integral, metallic=metallic,
+                          argmax_vis=argmax_vis, stats=stats, diffuse_vis=diffuse_vis, prefit=prefit, fun_spec=True)
+    l_lobe = lgt_sgs[..., :3] / (lgt_sgs[..., :3].norm(dim=-1, keepdim=True) + TINY)
+    l_lam, l_mu0 = lgt_sgs[..., 3:4].abs(), lgt_sgs[..., -3:].abs()
+    nrm = normal.unsqueeze(-2).expand(n, M, 3)
+    f0 = specular_reflectance.unsqueeze(1).expand(n, M, 3)
+
+    def specular_rgb_fn(roughness, draws=draws):
+        views = [viewdirs[v].unsqueeze(-2).expand(n, M, 3) for v in range(V)]
+        warped = [_warped_lobe(nrm, vw, roughness) for vw in views]
+        bvis = specular_visibility(points.repeat(V, 1), normal.repeat(V, 1), viewdirs.reshape(V * n, 3), vis_fn,
+                                   torch.cat([w[0][:, 0] for w in warped]), torch.cat([w[1][:, 0] for w in warped]),
+                                   draws["svis_theta"].repeat(V, 1), draws["svis_phi"].repeat(V, 1), testing=testing, inv=False,
+                                   argmax_vis=True).reshape(V, n)
+        return torch.stack([_specular(points, nrm, views[v], f0, roughness, diffuse_albedo, metallic, l_lobe, l_lam, l_mu0, vis_fn, draws,
+                                      testing, comp_vis, argmax_vis, bvis=bvis[v]) for v in range(V)])
+
+    if fun_spec:
+        return dict(base, sg_specular_rgb=specular_rgb_fn)
+    spec = specular_rgb_fn(roughness)
+    return dict(base, sg_rgb=spec + base["sg_diffuse_rgb"], sg_specular_rgb=spec)
+
+
 def _specular(points, nrm, view, f0, roughness, diffuse_albedo, metallic, l_lobe, l_lam, l_mu0, vis_fn, draws, testing, comp_vis,
-              argmax_vis):
+              argmax_vis, bvis=None):
     """specular_rgb_fn (sg_render.py:413-500): warped BRDF lobe of `roughness`, its sampled visibility, product with the light SGs and
     the clamped cosine, hemisphere integral."""
     n, M = nrm.shape[0], nrm.shape[1]
@@ -210,9 +256,10 @@ def _specular(points, nrm, view, f0, roughness, diffuse_albedo, metallic, l_lobe
     k = ((roughness + 1.0) * (roughness + 1.0) / 8.0).unsqueeze(1).expand(n, M, 1)
     G = (d1 / (d1 * (1 - k) + k + TINY)) * (d2 / (d2 * (1 - k) + k + TINY))
     w_mu = b_mu * (Fr * G / (4 * d1 * d2 + TINY))
-    bvis = specular_visibility(points, nrm[:, 0, :], view[:, 0, :], vis_fn, w_lobe[:, 0], w_lam[:, 0],
-                               draws["svis_theta"], draws["svis_phi"], testing=testing, inv=not comp_vis,
-                               argmax_vis=argmax_vis)
+    if bvis is None:
+        bvis = specular_visibility(points, nrm[:, 0, :], view[:, 0, :], vis_fn, w_lobe[:, 0], w_lam[:, 0],
+                                   draws["svis_theta"], draws["svis_phi"], testing=testing, inv=not comp_vis,
+                                   argmax_vis=argmax_vis)
     l_mu_s = l_mu0 * bvis[:, None, None]
     f_lobe, f_lam, f_mu = sg_product(l_lobe, l_lam, l_mu_s, w_lobe, w_lam, w_mu)
     p_lobe, p_lam, p_mu = sg_product(nrm, LAMBDA_COS, MU_COS, f_lobe, f_lam, f_mu)

@@ -204,13 +204,20 @@ def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p,
 
 def get_specular_visibility(points, normals, viewdirs, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=24, multi_view=False,
                             testing=False, inv=False, argmax_vis=False, *, roughness=None, draws=None):
-    """Single-view branch of sg_render.py:198-301.  The HIP path derives the warped lobe from (normal, view,
+    """sg_render.py:198-301 (single view, or multi_view=True with viewdirs [V,n,3]).  The HIP path derives the warped lobe from (normal, view,
     roughness), so callers outside render_with_sg must pass `roughness`."""
-    if multi_view:
-        raise NotImplementedError("multi_view specular visibility is not on the hot path (MULTI_VIEW never set)")
     if roughness is None:
         raise NotImplementedError("pass roughness= (the warped BRDF lobe is recomputed on the device)")
     n = points.shape[0]
+    if multi_view:
+        # viewdirs [V,n,3] -> [V,n]: one batch of V n rows, the draws [n,nsamp] shared by the views, always the arg-max of the logits
+        # (sg_render.py:227-231, 247-258: inv / argmax_vis are not read in this branch)
+        V = viewdirs.shape[0]
+        if draws is None:
+            draws = _rand((n, nsamp), points.device), _rand((n, nsamp), points.device)
+        return _specular_vis_core(points.float().repeat(V, 1), normals.float().repeat(V, 1), viewdirs.float().reshape(V * n, 3).contiguous(),
+                                  VisModel, roughness.float().reshape(-1).repeat(V), draws[0].repeat(V, 1), draws[1].repeat(V, 1), testing,
+                                  False, True, None, 1).reshape(V, n)
     if draws is None:
         u_t, u_p = _rand((n, nsamp), points.device), _rand((n, nsamp), points.device)
     else:
@@ -230,11 +237,13 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
                    VisModel=None, fun_spec=False, lin_diff=False, testing=False, indir_integral=None, metallic=None,
                    diffuse_vis=None, prefit=False, argmax_vis=False, *, draws=None, chunk_id=None, n_chunks=1,
                    stats=None):
-    """sg_render.py:343-565 (single view).  lgtSGs [n,M,7] (or [M,7]).  fun_spec=True (sg_render.py:413,544-551): the specular term
+    """sg_render.py:343-565.  viewdirs [n,3], or [V,n,3] for the MULTI_VIEW form (_render_with_sg_multi_view).  lgtSGs [n,M,7] (or [M,7]).  fun_spec=True (sg_render.py:413,544-551): the specular term
     comes back as a function of a roughness tensor (its specular visibility is sampled at every call, like the reference's closure;
     `draws=` pins the samples), `sg_rgb` is then the diffuse term alone."""
     if viewdirs.dim() == 3:
-        raise NotImplementedError("multi-view shading is not on the hot path")
+        return _render_with_sg_multi_view(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo, comp_vis,
+                                          VisModel, fun_spec, lin_diff, testing, indir_integral, metallic, diffuse_vis, prefit,
+                                          argmax_vis, draws, chunk_id, n_chunks, stats)
     dev = points.device
     n = points.shape[0]
     cid, C = _chunks(chunk_id, n_chunks, n)
@@ -288,6 +297,47 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, rough
                 "supervise": supervise}
     rgb, spec, diff, shadow = shade(rough, draws)
     return {"sg_rgb": rgb, "sg_specular_rgb": spec, "sg_diffuse_rgb": diff, "vis_shadow": shadow, "supervise": supervise}
+
+
+def _render_with_sg_multi_view(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo, comp_vis, VisModel,
+                               fun_spec, lin_diff, testing, indir_integral, metallic, diffuse_vis, prefit, argmax_vis, draws, chunk_id,
+                               n_chunks, stats):
+    """MULTI_VIEW form (sg_render.py:356, 375-378, 465-470; get_specular_visibility's multi_view branches, :227-231, 247-258): viewdirs
+    [V,n,3].  Light visibility, diffuse term, shadow and supervision do not see the view (computed once, [n,.]); the specular term of
+    every view comes from ONE batch of V n rows (row v n + i = point i seen from view v) through the single-view kernels: one set of
+    draws [n,16] serves all views, the cone range takes the smallest sharpness of the whole batch, and the sampled visibility is always
+    the arg-max of the logits, never inverted (the reference's branch ignores inv / argmax_vis) -> sg_specular_rgb, sg_rgb [V,n,3].
+    (With exactly three views the reference's `torch.cross(z_axis, ref_dir)` -- no dim= -- crosses along the VIEW axis, the first of size
+    3: this mirror always crosses along xyz.)"""
+    if n_chunks != 1:
+        raise ValueError("multi-view shading is one lock-step batch (n_chunks = 1)")
+    V, n = viewdirs.shape[0], points.shape[0]
+    dev = points.device
+    base = render_with_sg(points, normal, viewdirs[0], lgtSGs, specular_reflectance, roughness, diffuse_albedo, comp_vis=comp_vis,
+                          VisModel=VisModel, fun_spec=True, lin_diff=lin_diff, testing=testing, indir_integral=indir_integral,
+                          metallic=metallic, diffuse_vis=diffuse_vis, prefit=prefit, argmax_vis=argmax_vis, draws=draws, stats=stats)
+    pts = points.float().repeat(V, 1)
+    nrm = normal.float().repeat(V, 1)
+    vd = viewdirs.float().reshape(V * n, 3).contiguous()
+    alb = diffuse_albedo.float().repeat(V, 1)
+    met = metallic.float().reshape(n, -1).repeat(V, 1) if metallic is not None else None
+    shared = lgtSGs.dim() == 2 or lgtSGs.stride(0) == 0
+    lgt = ((lgtSGs if lgtSGs.dim() == 2 else lgtSGs[0]) if shared else lgtSGs.repeat(V, 1, 1)).float().contiguous()
+
+    def specular_rgb_fn(roughness, draws=draws):
+        draws = draws or {}
+        rough = roughness.float().reshape(-1).repeat(V)
+        u_t, u_p = draws.get("svis_theta"), draws.get("svis_phi")
+        if u_t is None:
+            u_t, u_p = _rand((n, 16), dev), _rand((n, 16), dev)      # nsamp = 16 in this branch (:467)
+        bvis = _specular_vis_core(pts, nrm, vd, VisModel, rough, u_t.to(dev).repeat(V, 1), u_p.to(dev).repeat(V, 1), testing, False,
+                                  True, None, 1)
+        return ops.sg_shade(nrm, vd, lgt, specular_reflectance, rough, alb, bvis, metallic=met, lin_diff=lin_diff)[1].reshape(V, n, 3)
+
+    if fun_spec:
+        return dict(base, sg_specular_rgb=specular_rgb_fn)
+    spec = specular_rgb_fn(roughness)
+    return dict(base, sg_rgb=spec + base["sg_diffuse_rgb"], sg_specular_rgb=spec)
 
 
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, roughness, diffuse_albedo,

@@ -223,6 +223,23 @@ def test_tone_mapping():
             assert rel_err(renderer.ldr2hdr(y * 0.7, sh, hm), g["hdr_" + key + tag]) == 0.0
 
 
+def test_sg_shading_multi_view(oracle_sd):
+    """MULTI_VIEW form of render_with_all_sg (viewdirs [V,n,3]: model/sg_render.py:356, 375-378, 465-470, 227-231, 247-258) against the
+    reference's outputs (oracle/gen_golden_r4.py): view-independent fields [n,3], specular and totals [V,n,3]."""
+    from robir_oracle import nets, sg
+    g, mv = load_golden("sg_init"), load_golden("sg_multi_view")
+    assert str(g["weights"]) == str(mv["weights"])
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.dtype.kind == "f"}
+    draws = {k[5:]: torch.from_numpy(mv[k]) for k in mv if k.startswith("draw_")}
+    out = sg.render_with_all_sg(t["points"], t["normal"], torch.from_numpy(mv["view"]), t["lgtSGs"], t["f0"], t["roughness"], t["albedo"],
+                                draws, indir_integral=t["indir_int"], indir_lgt_sgs=t["indir_sgs"],
+                                vis_fn=lambda p, d: nets.vis_logits(oracle_sd, p, d), testing=True)
+    for k in ("sg_rgb", "sg_specular_rgb", "sg_diffuse_rgb", "vis_shadow", "indir_rgb", "indir_diffuse_rgb", "indir_specular_rgb"):
+        assert tuple(out[k].shape) == mv["out_" + k].shape, k
+        assert rel_err(out[k], mv["out_" + k]) <= TOL, k
+    assert out["sg_rgb"].shape == (2, 40, 3) and out["sg_diffuse_rgb"].shape == (40, 3)
+
+
 def test_sg_algebra_helpers():
     """hemisphere_int / lambda_trick (model/sg_render.py:62-104): the oracle's restatement AND the public helpers of
     robir_amd.sg_render (plain element-wise torch, device-agnostic) against the reference's outputs."""

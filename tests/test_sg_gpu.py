@@ -49,6 +49,33 @@ def test_render_with_all_sg_golden(dev, vis_net, tag, precision):
         assert rel_err(out[k].cpu(), g["out_" + k]) <= TOL, (k, rel_err(out[k].cpu(), g["out_" + k]))
 
 
+def test_render_with_all_sg_multi_view_golden(dev, vis_net):
+    """MULTI_VIEW shading (viewdirs [V,n,3]: model/sg_render.py:356, 375-378, 465-470; get_specular_visibility's multi_view branches)
+    against the reference's outputs for two views of the sg_init points: view-independent fields [n,3], specular and totals [V,n,3]; the
+    function form (fun_spec) and get_specular_visibility(multi_view=True) give the same numbers."""
+    from robir_amd import sg_render
+    g, mv = load_golden("sg_init"), load_golden("sg_multi_view")
+    t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if v.dtype.kind == "f"}
+    view = torch.from_numpy(mv["view"]).to(dev)
+    draws = {k[5:]: torch.from_numpy(mv[k]).to(dev) for k in mv if k.startswith("draw_")}
+    args = (t["points"], t["normal"], view, t["lgtSGs"], t["f0"], t["roughness"], t["albedo"])
+    kw = dict(indir_integral=t["indir_int"], indir_lgtSGs=t["indir_sgs"], VisModel=vis_net, testing=True, draws=draws)
+    out = sg_render.render_with_all_sg(*args, **kw)
+    torch.cuda.synchronize()
+    for k in ("vis_shadow", "sg_diffuse_rgb", "sg_specular_rgb", "sg_rgb", "indir_diffuse_rgb", "indir_specular_rgb", "indir_rgb"):
+        assert tuple(out[k].shape) == mv["out_" + k].shape, k
+        assert rel_err(out[k].cpu(), mv["out_" + k]) <= TOL, (k, rel_err(out[k].cpu(), mv["out_" + k]))
+    fn = sg_render.render_with_all_sg(*args, fun_spec=True, **kw)
+    assert torch.equal(fn["sg_rgb"], out["sg_diffuse_rgb"])
+    spec = fn["sg_specular_rgb"](t["roughness"], {"svis_theta": draws["svis_theta_dir"], "svis_phi": draws["svis_phi_dir"]})
+    assert torch.equal(spec, out["sg_specular_rgb"])
+    bvis = sg_render.get_specular_visibility(t["points"], t["normal"], view, vis_net, None, None, nsamp=16, multi_view=True, testing=True,
+                                             roughness=t["roughness"], draws=(draws["svis_theta_dir"], draws["svis_phi_dir"]))
+    assert bvis.shape == (2, 40) and bool(((bvis >= 0) & (bvis <= 1)).all())
+    with pytest.raises(ValueError):
+        sg_render.render_with_sg(*args, VisModel=vis_net, chunk_id=torch.zeros(40, dtype=torch.int32, device=dev), n_chunks=2)
+
+
 def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd, precision):
     """Fused kernel against the oracle on more points than one block row, two chunks with different draws."""
     from robir_amd import sg_render, synth
