@@ -11,6 +11,9 @@ TEST INFRASTRUCTURE ONLY (build container; /root/reference does not exist on the
                                  tables the oracle reproduces that output to 0.0 on every shading field (PINNING.json), so this is what
                                  an independent octree build alone does to the outputs: the yardstick the GPU test holds the HIP path
                                  (device-built octree) to.  Needs no reference run: the golden file and the oracle.
+  tests/golden/raytracing_train_{r1,r045}.npz   RayTracing.forward with the module in TRAINING mode (model/ray_tracing.py:68-100, 256,
+                                 299-326) on the rays of raytracing_{r1,r045}.npz, an object mask with holes, the uniform draws of
+                                 minimal_sdf_points replayed from the seed -> points, hit, dist
   oracle/PINNING_r4.json         oracle-vs-reference distances of this run
 
   tests/golden/sg_multi_view.npz render_with_all_sg with viewdirs [V=2, n, 3] (MULTI_VIEW, model/sg_render.py:356,375-378,465-470 and
@@ -89,6 +92,34 @@ def main():
     print(rep["sg_multi_view"])
     np.savez_compressed(os.path.join(GOLD, "sg_multi_view.npz"), weights=si["weights"], view=view,
                         **{"draw_" + k: v for k, v in dr.items()}, **{"out_" + k: ref[k].detach().numpy() for k in keys})
+
+    # ------------------------------------------------------------------ RayTracing in TRAINING mode (ray_tracing.py:68-100, 256, 299-326)
+    from robir_oracle import raytracing as ort
+    from model.ray_tracing import RayTracing
+    with ref_shim.CpuMode():
+        rt_conf = ref_shim.hotdog_model_conf().get_config("ray_tracer")
+        rt = RayTracing(**{k: rt_conf[k] for k in rt_conf.keys()})
+        rt.train()
+        impl = net.implicit_network
+        sdf_ref = lambda x: impl(x)[:, 0]
+        for tag in ("r1", "r045"):
+            rg = dict(np.load(os.path.join(GOLD, "raytracing_%s.npz" % tag), allow_pickle=False))
+            radius = float(rg["radius"])
+            rt.object_bounding_sphere = radius
+            cam, dirs = torch.from_numpy(rg["cam"]), torch.from_numpy(rg["dirs"])
+            obj = torch.from_numpy(g.uniform(0.0, 1.0, dirs.shape[0]) > 0.3)          # an object mask with holes: in / out rays exist
+            seed = 41 if tag == "r1" else 42
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                rx, rh, rdist = rt(sdf=sdf_ref, cam_loc=cam[None], object_mask=obj, ray_directions=dirs[None])
+            torch.manual_seed(seed)
+            steps_u = torch.empty(rt.n_steps).uniform_(0.0, 1.0)                       # the only draw of the call (:305), replayed
+            ox, oh, od = ort.trace(lambda x: on.implicit_forward(sdt, x)[:, 0], cam, dirs, obj, r=radius, training=True, steps_u=steps_u)
+            rep["raytracing_train_" + tag] = dict(hits=int(rh.sum()), hit_mismatch=int((rh != oh).sum()), dist=g1.relerr(od, rdist),
+                                                  pts=g1.relerr(ox, rx), no_surface_rays=int((~rh).sum()))
+            print(tag, rep["raytracing_train_" + tag])
+            np.savez_compressed(os.path.join(GOLD, "raytracing_train_%s.npz" % tag), weights=si["weights"], radius=radius, object_mask=obj.numpy(),
+                                steps_u=steps_u.numpy(), points=rx.numpy(), hit=rh.numpy(), dist=rdist.numpy())
 
     # ------------------------------------------------------------------ self-spread of forward('Material') under an independent octree build
     from robir_oracle import octree as ooct

@@ -1,6 +1,8 @@
 """IDR sphere tracer with sampler + secant root finding -- the `use_octree=False` ray tracer
-(model/ray_tracing.py:26-297, eval-mode path; utils/rend_util.py:141-163).  Every ray is independent; the SDF network is
-called inside the loops.  The training-mode tail (:73-100, minimal_sdf_points with uniform_ draws) is out of scope."""
+(model/ray_tracing.py:26-326; utils/rend_util.py:141-163).  Every ray is independent; the SDF network is called inside the
+loops.  training=True adds the module's training-mode behaviour: the secant runs only on rays the object mask agrees with (:256) and
+the rays without a surface get the tail of :73-100 (projection of the camera onto rays that miss the bounding sphere, minimal_sdf_points
+with its n_steps uniform draws, :299-326)."""
 import torch
 
 
@@ -16,14 +18,16 @@ def sphere_intersection(cam_loc, dirs, r=1.0):
 
 
 def trace(sdf_fn, cam_loc, dirs, object_mask, r=1.0, thr=5.0e-5, line_step=0.5, line_iters=3, trace_iters=10,
-          n_steps=100, n_secant=32):
-    """RayTracing.forward in eval mode.  cam_loc [3]; dirs [N,3]; object_mask [N] bool.  -> points [N,3], hit [N], dist [N]."""
+          n_steps=100, n_secant=32, training=False, steps_u=None):
+    """RayTracing.forward.  cam_loc [3]; dirs [N,3]; object_mask [N] bool.  -> points [N,3], hit [N], dist [N].
+    training=True: the module in training mode; steps_u [n_steps] = the uniform draws of minimal_sdf_points (:305)."""
     N = dirs.shape[0]
     t01, inter = sphere_intersection(cam_loc, dirs, r)
     at = lambda t: cam_loc[None, :] + t[:, None] * dirs
     un_s, un_e = inter.clone(), inter.clone()
     acc_s = torch.where(inter, t01[:, 0], torch.zeros(N))
     acc_e = torch.where(inter, t01[:, 1], torch.zeros(N))
+    min_dis, max_dis = acc_s.clone(), acc_e.clone()                     # :124-126
     p_s = torch.where(inter[:, None], at(t01[:, 0]), torch.zeros(N, 3))
     p_e = torch.where(inter[:, None], at(t01[:, 1]), torch.zeros(N, 3))
 
@@ -78,8 +82,9 @@ def trace(sdf_fn, cam_loc, dirs, object_mask, r=1.0, thr=5.0e-5, line_step=0.5, 
         if out.any():                                                    # minimal-SDF point for rays that found no surface
             j = torch.argmin(s[out], -1)
             sp[out], sd[out] = P[out][torch.arange(int(out.sum())), j], z[out][torch.arange(int(out.sum())), j]
-        hit_s = torch.ones(idx.numel(), dtype=torch.bool)
-        hit_s[~neg] = False
+        hit_s = neg.clone()
+        if training:                                                     # :256: only rays the object mask agrees with are refined
+            neg = neg & object_mask[idx]
         if neg.any():                                                    # secant refinement between the bracketing samples
             r_ = rows[neg]
             z_hi, s_hi = z[r_, first[neg]].clone(), s[r_, first[neg]].clone()
@@ -94,4 +99,24 @@ def trace(sdf_fn, cam_loc, dirs, object_mask, r=1.0, thr=5.0e-5, line_step=0.5, 
                 zp = (-s_lo * (z_hi - z_lo) / (s_hi - s_lo + 1e-8) + z_lo).clamp(0.0, 2e1)
             sp[neg], sd[neg] = cam_loc[None, :] + zp[:, None] * d_, zp
         pts[idx], dist[idx], hit[idx] = sp, sd, hit_s
+    if not training:
+        return pts, hit, dist
+    # ---- training-mode tail (:73-100)
+    in_mask = ~hit & object_mask & ~un_s
+    out_mask = ~object_mask & ~un_s
+    left = (in_mask | out_mask) & ~inter                                  # rays that miss the bounding sphere: foot of the camera on the ray
+    if left.any():
+        dist[left] = -(dirs[left] * cam_loc[None, :]).sum(-1)
+        pts[left] = cam_loc[None, :] + dist[left][:, None] * dirs[left]
+    m = (in_mask | out_mask) & inter
+    if m.any():
+        sel = hit & out_mask
+        min_dis[sel] = dist[sel]
+        lo, hi = min_dis[m][:, None], max_dis[m][:, None]
+        zt = steps_u[None, :].repeat(int(m.sum()), 1) * (hi - lo) + lo                    # minimal_sdf_points (:299-326)
+        Pa = cam_loc[None, None, :].repeat(int(m.sum()), n_steps, 1) + zt[..., None] * dirs[m][:, None, :].repeat(1, n_steps, 1)
+        sv = sdf_fn(Pa.reshape(-1, 3)).reshape(-1, n_steps)
+        j = sv.argmin(-1)
+        rr = torch.arange(int(m.sum()))
+        pts[m], dist[m] = Pa[rr, j], zt[rr, j]
     return pts, hit, dist

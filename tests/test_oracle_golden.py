@@ -223,6 +223,19 @@ def test_tone_mapping():
             assert rel_err(renderer.ldr2hdr(y * 0.7, sh, hm), g["hdr_" + key + tag]) == 0.0
 
 
+@pytest.mark.parametrize("tag", ["r1", "r045"])
+def test_raytracing_training_mode(oracle_sd, tag):
+    """RayTracing.forward with the module in training mode (model/ray_tracing.py:68-100, 256, 299-326): the oracle on the reference's
+    rays, object mask and uniform draws against the reference's points / hit mask / distances (oracle/gen_golden_r4.py)."""
+    from robir_oracle import nets, raytracing
+    g, t = load_golden("raytracing_" + tag), load_golden("raytracing_train_" + tag)
+    x, hit, dist = raytracing.trace(lambda p: nets.implicit_forward(oracle_sd, p)[:, 0], torch.from_numpy(g["cam"]), torch.from_numpy(g["dirs"]),
+                                    torch.from_numpy(t["object_mask"]), r=float(g["radius"]), training=True,
+                                    steps_u=torch.from_numpy(t["steps_u"]))
+    assert torch.equal(hit, torch.from_numpy(t["hit"]))
+    assert bad_frac(dist, t["dist"], TOL) <= 0.01 and bad_frac(x, t["points"], TOL) <= 0.01
+
+
 def test_sg_shading_multi_view(oracle_sd):
     """MULTI_VIEW form of render_with_all_sg (viewdirs [V,n,3]: model/sg_render.py:356, 375-378, 465-470, 227-231, 247-258) against the
     reference's outputs (oracle/gen_golden_r4.py): view-independent fields [n,3], specular and totals [V,n,3]."""

@@ -48,6 +48,38 @@ def test_matches_reference_golden(dev, implicit, tag):
     bounded("raytracing_%s/miss_dist" % tag, dist[~both], g["dist"][~both], 1e-2, 0.05)
 
 
+@pytest.mark.parametrize("tag", ["r1", "r045"])
+def test_training_mode_matches_reference_golden(dev, implicit, oracle_sd, tag):
+    """The module in TRAINING mode (model/ray_tracing.py:68-100, 256, 299-326) on the rays of the eval-mode golden with an object mask
+    with holes: hit mask equal, the points / distances of every ray -- surface rays, rays that miss the sphere, minimal-SDF points of
+    the rays without a surface -- against the reference's, and against the oracle on the same draws."""
+    from robir_oracle import nets as on, raytracing
+    g, t = load_golden("raytracing_" + tag), load_golden("raytracing_train_" + tag)
+    dirs = torch.from_numpy(g["dirs"]).to(dev)
+    cam = torch.from_numpy(g["cam"]).to(dev).reshape(1, 3)
+    obj = torch.from_numpy(t["object_mask"])
+    tr = _tracer(float(g["radius"])).train()
+    tr.min_sdf_steps = torch.from_numpy(t["steps_u"])
+    x, hit, dist = tr(implicit.sdf_only, cam, obj.to(dev), dirs[None])
+    x, hit, dist = x.cpu(), hit.cpu(), dist.cpu()
+    gh = torch.from_numpy(t["hit"])
+    assert int((hit != gh).sum()) <= 1
+    assert int((~gh).sum()) >= 100 and int((~obj).sum()) >= 200                 # the tail is exercised
+    same = (hit == gh).numpy()
+    # near-ties of the minimal-SDF sample / the secant bracket move single rays by a sample spacing (the oracle differs from the reference
+    # on 6-7 of these 1024 rays the same way: oracle/PINNING_r4.json)
+    assert bad_frac(dist[same], t["dist"][same], TOL) <= 0.012, bad_frac(dist[same], t["dist"][same], TOL)
+    assert bad_frac(x[same], t["points"][same], TOL) <= 0.012
+    xo, ho, do = raytracing.trace(lambda p: on.implicit_forward(oracle_sd, p)[:, 0], cam.cpu()[0], dirs.cpu(), obj, r=float(g["radius"]),
+                                  training=True, steps_u=torch.from_numpy(t["steps_u"]))
+    assert int((hit != ho).sum()) <= 1
+    assert bad_frac(dist, do, TOL) <= 0.012 and bad_frac(x, xo, TOL) <= 0.012
+    # eval mode is unchanged by the attribute
+    tr.eval()
+    x2, hit2, _ = tr(implicit.sdf_only, cam, obj.to(dev), dirs[None])
+    assert torch.equal(hit2.cpu(), hit)
+
+
 def test_matches_oracle_other_view_and_mask(dev, implicit, oracle_sd):
     """A second view, an object mask with holes, and per-ray origins (the 'points'/'dirs' input form)."""
     from robir_oracle import nets as on, raytracing
