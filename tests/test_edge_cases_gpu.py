@@ -337,6 +337,20 @@ def test_round4_entry_points_on_empty_tiny_and_ragged_inputs(dev, synth_weights)
     assert rc != 0 and b"null" in L.rb_last_error()
     assert L.rb_sdf_x6t_points(None, ctypes.c_long(0), ctypes.c_float(1.0), None, ctypes.c_int(1), ctypes.c_float(1.0), None,
                                ctypes.c_int(0), _lib.stream_ptr()) == 0          # zero rows: nothing to do, not an error
+    # the two-tile colour kernel: zero rows, one row, rows that do not fill a round; null pointers refused
+    col6 = packing.pack_color_x6(synth_weights, dev)
+    for n in (0, 1, 17, 129):
+        x = (torch.rand(n, 3, generator=g) - 0.5).to(dev)
+        v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+        feat = torch.randn(n, 257, generator=g).to(dev)
+        a, b = (ops.color_x6_points(x, v, v, feat[:, 1:], col6, two_tile=t) for t in (False, True))
+        assert a.shape == b.shape == (n, 3) and (n == 0 or float((a - b).abs().max()) <= 2e-6), n
+    y3 = torch.zeros(3, device=dev)
+    rc = L.rb_color_x6t_points(None, ctypes.c_long(256), ctypes.c_float(1.0), _lib.ptr(y3), ctypes.c_float(1.0), _lib.ptr(y3), _lib.ptr(y3),
+                               ctypes.c_long(1), _lib.ptr(col6), _lib.ptr(y3), ctypes.c_int(0), _lib.stream_ptr())
+    assert rc != 0 and b"null" in L.rb_last_error()
+    assert L.rb_color_x6t_points(None, ctypes.c_long(256), ctypes.c_float(1.0), None, ctypes.c_float(1.0), None, None, ctypes.c_long(0), None,
+                                 None, ctypes.c_int(0), _lib.stream_ptr()) == 0
     # light visibility: 8 lobes x 4 samples, three points (one whose normal faces away from every direction: all culled)
     m = renderer.build_synthetic_model(dev, build_octrees=False)
     lgt = torch.from_numpy(synth.synth_light_sgs(0, 128))[:8].to(dev)
