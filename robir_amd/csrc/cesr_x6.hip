@@ -81,13 +81,21 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
   long rrow = 0;
   int label = -1;
 
-  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+  // range sentinel: `sat` in the domain of sat_acc_nonneg (hidden activations are >= 0: one instruction per pair); the signed inputs
+  // of a round go through sat_acc into `sat_in`, folded into `sat` behind them
+  unsigned sat_in = 0u;
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q, auto nonneg) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    sat = sat_acc(sat, h);
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
+    else sat_in = sat_acc(sat_in, h);
+  };
+  auto fold_sat_in = [&]() {
+    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
+    sat_in = 0u;
   };
   // input value k of this lane's row (k = 16 blk + 4 g + r): the encoder's LDS row, then the one-hot block from column 63 on
   auto x0_block = [&](int blk, float scale, float (&v)[4]) {
@@ -116,9 +124,10 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       for (int hb = 0; hb < 2; ++hb) {
         float v[4];
         x0_block(2 * kb + hb, 1.0f, v);
-        put_pair(v[0], v[1], xh[kb], xm[kb], xl[kb], hb * 2);
-        put_pair(v[2], v[3], xh[kb], xm[kb], xl[kb], hb * 2 + 1);
+        put_pair(v[0], v[1], xh[kb], xm[kb], xl[kb], hb * 2, std::false_type{});
+        put_pair(v[2], v[3], xh[kb], xm[kb], xl[kb], hb * 2 + 1, std::false_type{});
       }
+    fold_sat_in();
   };
   // the skip layer's operands: [softplus(h3) / sqrt 2 (in y) | x0 / sqrt 2 | 0]
   auto build_skip_operands = [&]() {
@@ -144,8 +153,8 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           } else if (b < B3 + K0P / 16) {
             float v[4];
             x0_block(b - B3, inv_sqrt2, v);
-            put_pair(v[0], v[1], xh[kb], xm[kb], xl[kb], hb * 2);
-            put_pair(v[2], v[3], xh[kb], xm[kb], xl[kb], hb * 2 + 1);
+            put_pair(v[0], v[1], xh[kb], xm[kb], xl[kb], hb * 2, std::false_type{});
+            put_pair(v[2], v[3], xh[kb], xm[kb], xl[kb], hb * 2 + 1, std::false_type{});
           } else {
             xh[kb][hb * 2] = xh[kb][hb * 2 + 1] = 0u;
             xm[kb][hb * 2] = xm[kb][hb * 2 + 1] = 0u;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
         v0 *= inv_sqrt2;
         v1 *= inv_sqrt2;
       }
-      put_pair(v0, v1, yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+      put_pair(v0, v1, yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q, std::true_type{});
     };
     auto epilogue = [&](const SxAcc& a, int pj, int q) {
       if (OUT) {
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     epilogue(last, NCH - 1, 1);
     if constexpr (SKIPOUT) {
       build_skip_operands();
+      fold_sat_in();
     } else if constexpr (!OUT) {
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       else run_layer(std::integral_constant<int, 1>{}, ub);
     }
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

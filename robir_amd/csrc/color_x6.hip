@@ -49,13 +49,21 @@ __global__ __launch_bounds__(256, 1) void k_color_x6(const float* __restrict__ f
   u4 yh[8], ym[8], yl[8];              // ... of the next layer
   long rrow = 0;
 
-  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+  // range sentinel: `sat` in the domain of sat_acc_nonneg (hidden activations are >= 0: one instruction per pair); the signed inputs
+  // of a round go through sat_acc into `sat_in`, folded into `sat` behind them
+  unsigned sat_in = 0u;
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q, auto nonneg) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    sat = sat_acc(sat, h);
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
+    else sat_in = sat_acc(sat_in, h);
+  };
+  auto fold_sat_in = [&]() {
+    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
+    sat_in = 0u;
   };
   // this round's rows -> operands of layer 0: features in place (x feat_scale), tail encoded by the four lane groups of a row
   auto load_layer0 = [&]() {
@@ -111,8 +119,9 @@ __global__ __launch_bounds__(256, 1) void k_color_x6(const float* __restrict__ f
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
-        put_pair(in0[i], in0[i + 1], xh[kb], xm[kb], xl[kb], q);
+        put_pair(in0[i], in0[i + 1], xh[kb], xm[kb], xl[kb], q, std::false_type{});
       }
+    fold_sat_in();
   };
 
   auto run_layer = [&](auto LI_tag, int cb) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6(const float* __restrict__ f
     };
     auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
     auto hidden_pair = [&](const SxAcc& a, int pj, int q) {
-      put_pair(fmaxf(combine(a, 2 * q), 0.f), fmaxf(combine(a, 2 * q + 1), 0.f), yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+      put_pair(fmaxf(combine(a, 2 * q), 0.f), fmaxf(combine(a, 2 * q + 1), 0.f), yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q, std::true_type{});
     };
     zero_acc(accs[0], bias_of(0));
 #pragma unroll
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6(const float* __restrict__ f
       else run_layer(std::integral_constant<int, 1>{}, 16 * l);
     }
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
   const int first320 = xt_span_first(320, wave), first256 = xt_span_first(256, wave);
   auto span_first = [&](int K_) { return K_ == 320 ? first320 : first256; };
   unsigned slot_b[4] = {0u, (unsigned)CT_SLOT_B, 2u * CT_SLOT_B, 3u * CT_SLOT_B};
-  unsigned sat = 0u;
+  unsigned sat = 0u;                   // range sentinel, in the domain of sat_acc_nonneg (>= 0x7bff in a half = out of range)
   XtOps<10> P;                         // operands of the current layer (K <= 320), two tiles
   XtOps<8> Q;                          // ... of the next layer
   XtWin win;
@@ -59,16 +59,20 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
 
   for (int i = tid; i < CT_NCHUNK * 4; i += 256) bias_tab[i] = Wp[ct_coff(i >> 2) + (i & 3)];
 
-  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+  // NONNEG: relu outputs (>= 0: the raw pattern of the h piece orders like the value, one instruction: mlp_engine.h)
+  unsigned sat_in = 0u;                // ... of a round's signed inputs (sat_acc's domain): folded into `sat` at the end of the input stage
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q, auto nonneg) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    sat = sat_acc(sat, h);
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
+    else sat_in = sat_acc(sat_in, h);
   };
   // this round's rows -> operands of layer 0: features in place (x feat_scale), tail encoded by the four lane groups of a row
   auto load_layer0 = [&]() {
+    sat_in = 0u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const long rrow = round * 128 + t * 64 + rlocal;
@@ -124,9 +128,10 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
-          put_pair(in0[i], in0[i + 1], P.h[t][kb], P.m[t][kb], P.l[t][kb], q);
+          put_pair(in0[i], in0[i + 1], P.h[t][kb], P.m[t][kb], P.l[t][kb], q, std::false_type{});
         }
     }
+    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
   };
 
   auto run_layer = [&](auto LI_tag, int cb) {
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
         item_z(1, prev[1]);
       } else {
         const int i = s - 1, t = i >> 1, q = i & 1;
-        put_pair(z[t][2 * q], z[t][2 * q + 1], Q.h[t][pj >> 1], Q.m[t][pj >> 1], Q.l[t][pj >> 1], (pj & 1) * 2 + q);
+        put_pair(z[t][2 * q], z[t][2 * q + 1], Q.h[t][pj >> 1], Q.m[t][pj >> 1], Q.l[t][pj >> 1], (pj & 1) * 2 + q, std::true_type{});
       }
     };
     constexpr int NE = 5;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
     run_layer(std::integral_constant<int, 3>{}, 48);
     run_layer(std::integral_constant<int, 4>{}, 64);
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

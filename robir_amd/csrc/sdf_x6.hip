@@ -53,13 +53,21 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
   u4 skh[3], skm[3], skl[3];           // skip layer, k-blocks 6 (second half), 7, 8: the net's inputs / sqrt 2, once per round
   long rrow = 0;
 
-  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+  // range sentinel: `sat` in the domain of sat_acc_nonneg (hidden activations are >= 0: one instruction per pair); the signed inputs
+  // of a round go through sat_acc into `sat_in`, folded into `sat` behind them
+  unsigned sat_in = 0u;
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q, auto nonneg) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    sat = sat_acc(sat, h);
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
+    else sat_in = sat_acc(sat_in, h);
+  };
+  auto fold_sat_in = [&]() {
+    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
+    sat_in = 0u;
   };
   auto load_layer0 = [&]() {
     float x0[16];
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
-        put_pair(x0[i], x0[i + 1], xh[kb], xm[kb], xl[kb], q);
+        put_pair(x0[i], x0[i + 1], xh[kb], xm[kb], xl[kb], q, std::false_type{});
       }
     // skip layer operands [softplus(h3) (13 blocks of 16) | x0 (4 blocks) | 0] / sqrt 2: blocks 13..17 = k-block 6 second half .. 8
 #pragma unroll
@@ -83,8 +91,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int q = (b & 1) * 2 + p, i = (b - 13) * 4 + p * 2;
-        put_pair(x0[i] * inv_sqrt2, x0[i + 1] * inv_sqrt2, skh[(b >> 1) - 6], skm[(b >> 1) - 6], skl[(b >> 1) - 6], q);
+        put_pair(x0[i] * inv_sqrt2, x0[i + 1] * inv_sqrt2, skh[(b >> 1) - 6], skm[(b >> 1) - 6], skl[(b >> 1) - 6], q, std::false_type{});
       }
+    fold_sat_in();
   };
 
   auto run_layer = [&](auto LI_tag, int cb, int lrt) {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
       ev1[q] = v1;
     };
 #endif
-    auto stage_b = [&](int pj, int q) { put_pair(ev0[q], ev1[q], yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q); };
+    auto stage_b = [&](int pj, int q) { put_pair(ev0[q], ev1[q], yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q, std::true_type{}); };
     auto store_sig = [&](int pj, const f4& sg) {
       if constexpr (STORE) sig[((rrow >> 4) * 8 + lrt) * (16L * 64) + pj * 64 + lane] = sg;
     };
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
       else run_layer(std::integral_constant<int, 1>{}, cb, l);
     }
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

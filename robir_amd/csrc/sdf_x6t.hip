@@ -66,13 +66,21 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 
   for (int i = tid; i < NCHUNK * 4; i += 256) bias_tab[i] = Wp[sx_coff(i >> 2, LAST) + (i & 3)];
 
-  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
+  // range sentinel: `sat` in the domain of sat_acc_nonneg (softplus outputs are >= 0: the raw pattern of the h piece orders like the value,
+  // one instruction per pair); the signed inputs of a round (encoded rows) go through sat_acc into `sat_in`, folded into `sat` behind them
+  unsigned sat_in = 0u;
+  auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q, auto nonneg) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    sat = sat_acc(sat, h);
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
+    else sat_in = sat_acc(sat_in, h);
+  };
+  auto fold_sat_in = [&]() {
+    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
+    sat_in = 0u;
   };
   auto load_layer0 = [&]() {
 #pragma unroll
@@ -84,9 +92,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
-          put_pair(x0[i], x0[i + 1], P.h[t][kb], P.m[t][kb], P.l[t][kb], q);
+          put_pair(x0[i], x0[i + 1], P.h[t][kb], P.m[t][kb], P.l[t][kb], q, std::false_type{});
         }
     }
+    fold_sat_in();
   };
   // skip layer operands [softplus(h3) / sqrt 2 (13 blocks of 16) | x0 / sqrt 2 (4 blocks) | 0]: blocks 13..17 = k-block 6 second half .. 8,
   // rebuilt from the round's encoded rows in the LDS (rows beyond M are zero like their first-layer operands)
@@ -103,10 +112,11 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
         for (int p = 0; p < 2; ++p) {
           const int q = (b & 1) * 2 + p;
           const float v0 = ok ? v[2 * p] : 0.f, v1 = ok ? v[2 * p + 1] : 0.f;
-          put_pair(v0 * inv_sqrt2, v1 * inv_sqrt2, P.h[t][b >> 1], P.m[t][b >> 1], P.l[t][b >> 1], q);
+          put_pair(v0 * inv_sqrt2, v1 * inv_sqrt2, P.h[t][b >> 1], P.m[t][b >> 1], P.l[t][b >> 1], q, std::false_type{});
         }
       }
     }
+    fold_sat_in();
   };
 
   auto run_layer = [&](auto LI_tag, int cb, int lrt) {
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     };
     auto item_b = [&](int i, int pj, auto& Y) {
       const int t = i >> 1, q = i & 1;
-      put_pair(ev[i][0], ev[i][1], Y.h[t][pj >> 1], Y.m[t][pj >> 1], Y.l[t][pj >> 1], (pj & 1) * 2 + q);
+      put_pair(ev[i][0], ev[i][1], Y.h[t][pj >> 1], Y.m[t][pj >> 1], Y.l[t][pj >> 1], (pj & 1) * 2 + q, std::true_type{});
     };
     // outputs through a buffer descriptor over the round's valid rows: lanes beyond it (rows >= M, columns >= 257) are dropped by the
     // bounds check, no branch splits the chunk
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     run_layer(std::integral_constant<int, 7>{}, 109, 7);
     run_layer(std::integral_constant<int, 8>{}, 125, 8);
   }
-  range_report(sat, range_word);
+  range_report<true>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

@@ -706,6 +706,46 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
     ops.range_check(sync=True)
 
 
+def test_exact_operand_kernels_report_range_overflow(dev, synth_weights):
+    """The range sentinel of the exact-operand SDF / colour kernels, both forms: a hidden activation beyond the f16 range of the leading
+    piece (the >= 0 activations are tracked by their raw pattern, one instruction per pair) and an input beyond it (the signed inputs of a
+    round, folded in behind them) are reported by rb_range_check; the unscaled net reports nothing."""
+    from robir_amd import ops, packing, _lib
+    g = torch.Generator().manual_seed(7)
+    n = 300
+    x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
+    v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    feat = torch.randn(n, 257, generator=g).to(dev)
+    big = dict(synth_weights)
+    for k in list(big):                                  # layers 0 and 1 of the SDF net and of the colour net x 3000: layer 1 puts out ~1e7
+        if k.endswith((".lin0.weight_g", ".lin1.weight_g", ".lin0.bias", ".lin1.bias")) and ("sdf_network" in k or "color_network" in k):
+            big[k] = big[k] * 3000.0
+    ops.range_check(sync=True)
+    for two in (False, True):
+        old, ops.SDF_TWO_TILE_MIN_ROWS = ops.SDF_TWO_TILE_MIN_ROWS, (0 if two else 1 << 60)
+        try:
+            ops.sdf_points_x6(x, n, packing.pack_sdf_x6(synth_weights, dev, full=True), True, 2.0, 0.5)
+            ops.color_x6_points(x, v, v, feat[:, 1:], packing.pack_color_x6(synth_weights, dev))
+            ops.range_check(sync=True)                                                   # in range: nothing to report
+            ops.sdf_points_x6(x, n, packing.pack_sdf_x6(big, dev, full=True), True, 2.0, 0.5)
+            with pytest.raises(_lib.RobirHipError, match="overflowed its activation range") as e:
+                ops.range_check(sync=True)
+            assert "SDF" in str(e.value), str(e.value)
+            ops.color_x6_points(x, v, v, feat[:, 1:], packing.pack_color_x6(big, dev))
+            with pytest.raises(_lib.RobirHipError, match="overflowed its activation range") as e:
+                ops.range_check(sync=True)
+            assert "colour" in str(e.value), str(e.value)
+            ops.sdf_points_x6(x * 1.0e6, n, packing.pack_sdf_x6(synth_weights, dev, full=True), True, 2.0, 0.5)      # an input beyond the range
+            with pytest.raises(_lib.RobirHipError, match="overflowed its activation range"):
+                ops.range_check(sync=True)
+            ops.color_x6_points(x, v, v, feat[:, 1:] * 1.0e6, packing.pack_color_x6(synth_weights, dev))
+            with pytest.raises(_lib.RobirHipError, match="overflowed its activation range"):
+                ops.range_check(sync=True)
+        finally:
+            ops.SDF_TWO_TILE_MIN_ROWS = old
+    ops.range_check(sync=True)
+
+
 def test_color_exact_operand_kernel(dev, synth_weights):
     """k_color_x6 / k_color_x6t (csrc/color_x6.hip, color_x6t.hip) against the f32-input-MFMA colour kernel on the same inputs: ragged sizes, many rounds, run to run."""
     from robir_amd import ops, packing
