@@ -190,13 +190,14 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
       const int ne = (jb > 0 && !OUT) ? NE : 0;
+      unsigned lv = 0u;             // lane offset of this chunk's copies, carried from piece to piece (x6t_engine.h)
       auto filler = [&](int pos) {
         if (pos == 12 * (NPART - 1)) nbias = bias_of(cb + jb + 1);       // before the last part's fragment requests (no lgkmcnt(0) at its use)
         const int a = xt_free_index(pos);
         if (a < 0) return;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (i < NC3 && i == a) xt_copy_piece(i, src3, dst3);            // the copies first
+          if (i < NC3 && i == a) xt_copy_piece_seq(i, src3, dst3, lv);            // the copies first
 #pragma unroll
         for (int i = 0; i < NE; ++i)
           if (i < ne && NC3 + xt_item_slot(i, NE, NFREE - NC3) == a) ep_item(i, jb > 0 ? jb - 1 : 0);

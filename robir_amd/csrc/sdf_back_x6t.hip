@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
       acc[0].c0 = acc[1].c0 = acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
       const int ne = jb > 0 ? NE : 0, ni = ne + 8;
       const unsigned ep_gslot = gslot_b[(jb + 5) % 6];    // = slot of chunk jb-1
+      unsigned lv = 0u;             // lane offset of this chunk's copies, carried from piece to piece (x6t_engine.h)
       auto filler = [&](int pos) {
         const int a = xt_free_index(pos);
         if (a < 0) return;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
           if (i < ni && xt_item_slot(i, ni, NFREE) == a) {
             if (i < ne) ep_item(i, jb - 1, ep_gslot);
             else if (i - ne < 2) gate_copy(i - ne, g_layer, g_chunk, g_slot, nl && LI == 7);
-            else xt_copy_piece(i - ne - 2, src3, dst3);
+            else xt_copy_piece_seq(i - ne - 2, src3, dst3, lv);
           }
       };
       auto refill = [&](int piece, int part) {

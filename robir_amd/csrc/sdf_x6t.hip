@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
       const int ne = jb > 0 ? NE : 0, ni = ne + NC3;
+      unsigned lv = 0u;             // lane offset of this chunk's copies, carried from piece to piece (x6t_engine.h)
       auto filler = [&](int pos) {
         // the next chunk's bias, requested BEFORE the last part's fragment requests: behind them, its use at the top of the next chunk
         // would wait for all of them (lgkmcnt(0))
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
           for (int i = 0; i < 8; ++i)
             if (i < NC3 && 9 + xt_item_slot(i, NC3, NFREE - 9) == a) {
 #ifndef SXT_NODMA
-              xt_copy_piece(i, src3, dst3);
+              xt_copy_piece_seq(i, src3, dst3, lv);
 #endif
             }
           return;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
               if (jb > 0) ep_item(i, jb - 1);
             } else {
 #ifndef SXT_NODMA
-              xt_copy_piece(i - ne, src3, dst3);
+              xt_copy_piece_seq(i - ne, src3, dst3, lv);
 #endif
             }
           }

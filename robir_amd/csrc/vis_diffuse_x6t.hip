@@ -43,6 +43,11 @@ __device__ __forceinline__ void xt_dma16_imm(const f4* gbase_uniform, unsigned l
                : "memory");
 }
 
+template <int OFF>
+__device__ __forceinline__ void xt_dma16_m0kept(const f4* gbase_uniform, unsigned lane_byte_off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane_byte_off), "s"(gbase_uniform), "n"(OFF) : "memory");
+}
+
 struct XtTile {     // = V3Tile (vis_diffuse_v3.hip): record of a 16-sample tile of the global list
   int point;        // -1: no such tile
   int dir_base;     // first row of the point's chunk in dirs / Bd (chunk id * L * nsamp)
@@ -335,11 +340,23 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
 #if defined(XT_ABL_NODMA)            // timing ablation (wrong results): no weight copies
 #define XT_COPY(I) do { } while (0)
 #else
+  // pieces 0..5 are issued in this order in the chunk's second half with no other LDS-DMA between them: M0 is set by pieces 0 and 4
+  // and carried (two scalar issue slots less for the other four)
+#ifdef XT_M0_EVERY_PIECE             // A/B switch: M0 written by every piece (the round-4 form before this change)
 #define XT_COPY(I)                                                                  \
   do {                                                                              \
     if ((I) < 4) xt_dma16_imm<((I) & 3) * 1024>(dsrc, voff_a, ddst);                \
     else xt_dma16_imm<((I) & 3) * 1024>(dsrc, voff_b, ddst + 4096u);                \
   } while (0)
+#else
+#define XT_COPY(I)                                                                  \
+  do {                                                                              \
+    if ((I) == 0) xt_dma16_imm<0>(dsrc, voff_a, ddst);                              \
+    else if ((I) < 4) xt_dma16_m0kept<((I) & 3) * 1024>(dsrc, voff_a);              \
+    else if ((I) == 4) xt_dma16_imm<0>(dsrc, voff_b, ddst + 4096u);                 \
+    else xt_dma16_m0kept<((I) & 3) * 1024>(dsrc, voff_b);                           \
+  } while (0)
+#endif
 #endif
 #define XT_FENCE __builtin_amdgcn_sched_barrier(0)
 #ifdef XT_ABL_NOLDS                   // timing ablation (wrong results): no fragment reads

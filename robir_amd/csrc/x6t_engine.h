@@ -67,6 +67,34 @@ __device__ __forceinline__ void xt_copy_piece(int i, const f4* src_span, unsigne
     default: xt_dma16_imm<3072>(src_span, xt_lane16<4096>(), dst_span + 4096u); break;
   }
 }
+// The same pieces issued IN ORDER i = 0, 1, 2, ... by one wave within a chunk (the x6t kernels place them in consecutive filler
+// positions): six issue slots per piece (three for the lane offset, M0, the hazard nop, the copy) were 12 % of a K = 256 chunk's slots
+// (-DSXT_NODMA: 4.50 -> 3.88 ms per 2^20 points).  Piece 0 derives the lane offset and sets M0, piece 4 advances both by 4 KB, every
+// other piece is ONE instruction: the offset register `lv` and M0 are carried from piece to piece.  Nothing else between the pieces of
+// a chunk may write M0: no other instruction of these kernels does (checked in the ISA; sdf_back_x6t's gate copies, which set M0,
+// are issued before piece 0).
+template <int OFF>
+__device__ __forceinline__ void xt_dma16_keep(const f4* gbase_uniform, unsigned lane_byte_off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane_byte_off), "s"(gbase_uniform), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void xt_copy_piece_seq(int i, const f4* src_span, unsigned dst_span, unsigned& lv) {
+  switch (i) {
+    case 0:
+      lv = xt_lane16<0>();
+      xt_dma16_imm<0>(src_span, lv, dst_span);
+      break;
+    case 1: xt_dma16_keep<1024>(src_span, lv); break;
+    case 2: xt_dma16_keep<2048>(src_span, lv); break;
+    case 3: xt_dma16_keep<3072>(src_span, lv); break;
+    case 4:
+      lv += 4096u;
+      xt_dma16_imm<0>(src_span, lv, dst_span + 4096u);
+      break;
+    case 5: xt_dma16_keep<1024>(src_span, lv); break;
+    case 6: xt_dma16_keep<2048>(src_span, lv); break;
+    default: xt_dma16_keep<3072>(src_span, lv); break;
+  }
+}
 // first piece of wave w's span: min(w NSW, NS - NSW) (the last wave's span is shifted back into the chunk: a few pieces are copied twice)
 __device__ __forceinline__ int xt_span_first(int K_, int wave) {
   const int ns = 3 * K_ / 32, nsw = (ns + 3) / 4;
