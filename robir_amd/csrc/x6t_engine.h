@@ -119,8 +119,29 @@ __device__ __forceinline__ void xt_chunk(int part0, SxAcc (&acc)[2], XtWin& w, c
     const int k = down ? WK - 1 - k_ : k_;             \
     XT_MFMA_(ACC, WP[k], XP[kb0 + k]);                 \
   }
+  // Experiment switch (default off): interleave up to XT_MIX instructions of a position's fillers with the MFMAs of the run in front
+  // of them through sched_group_barrier.  A wave that owns its SIMD issues in order, and tools/microbench/mfma_order.hip measures 17.9
+  // cycles per MFMA with two independent vector instructions behind EVERY MFMA against 23.8 with eight behind every fourth -- but in
+  // these kernels the interleaved stream draws more hazard wait states (fillers that write registers an MFMA in flight still reads)
+  // and finer lgkmcnt waits than it hides: colour net unchanged for every mask and count, SDF distance 4.35 -> 4.55 ms.
+#ifndef XT_MIX
+#define XT_MIX 0
+#endif
+#ifndef XT_MIX_MASK
+#define XT_MIX_MASK 0x002
+#endif
+#if XT_MIX > 0
+#define XT_MIX_                                                      \
+  _Pragma("unroll") for (int k_ = 0; k_ < WK; ++k_) {                \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
+    __builtin_amdgcn_sched_group_barrier(XT_MIX_MASK, XT_MIX, 0);    \
+  }
+#else
+#define XT_MIX_
+#endif
 #define XT_END_(POS)            \
   filler(part * 12 + (POS));    \
+  XT_MIX_                       \
   __builtin_amdgcn_sched_barrier(0)
     XT_RUN_(acc[0].c0, w.h, x.h[0]);
     XT_END_(0);
@@ -151,6 +172,7 @@ __device__ __forceinline__ void xt_chunk(int part0, SxAcc (&acc)[2], XtWin& w, c
     XT_END_(11);
 #undef XT_RUN_
 #undef XT_END_
+#undef XT_MIX_
   }
 }
 
