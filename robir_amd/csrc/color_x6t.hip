@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
       const int K2 = jb + 2 < NCH ? K : ct_K(ct_layer_of(CB + jb + 2));
       if (sx_nsw(K2) >= 8) sx_wait<8>();
       else sx_wait<6>();
+#ifndef CT_ABL_NOBAR                   // timing ablations (wrong results): no per-chunk barrier | no epilogue | no copies | no fragment reads
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
       const int K3 = jb + 3 < NCH ? K : ct_K(ct_layer_of(CB + jb + 3));
       const int NC3 = sx_nsw(K3);
@@ -189,7 +191,11 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
       acc[0].c0 = bias;
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
+#ifdef CT_ABL_NOEP
+      const int ne = 0;
+#else
       const int ne = (jb > 0 && !OUT) ? NE : 0;
+#endif
       unsigned lv = 0u;             // lane offset of this chunk's copies, carried from piece to piece (x6t_engine.h)
       auto filler = [&](int pos) {
         if (pos == 12 * (NPART - 1)) nbias = bias_of(cb + jb + 1);       // before the last part's fragment requests (no lgkmcnt(0) at its use)
@@ -197,7 +203,9 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
         if (a < 0) return;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
+#ifndef CT_ABL_NODMA
           if (i < NC3 && i == a) xt_copy_piece_seq(i, src3, dst3, lv);            // the copies first
+#endif
 #pragma unroll
         for (int i = 0; i < NE; ++i)
           if (i < ne && NC3 + xt_item_slot(i, NE, NFREE - NC3) == a) ep_item(i, jb > 0 ? jb - 1 : 0);
@@ -210,7 +218,17 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
         } else {
           slot = (jb + 1) & 3, kb_first = 0, count = jb + 1 < NCH ? WK : WKN;
         }
+#ifdef CT_ABL_NOREAD
+        {
+          u4(&d)[4] = piece == 0 ? win.h : (piece == 1 ? win.m : win.l);
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < count) asm volatile("" : "+v"(d[k]));
+          (void)slot; (void)kb_first; (void)down;
+        }
+#else
         xt_request(piece == 0 ? win.h : (piece == 1 ? win.m : win.l), ring_lane + slot_b[slot], kb_first, count, piece, down);
+#endif
       };
       xt_chunk<K, 10>(jb * NPART, acc, win, P, filler, refill);
       if constexpr (OUT) prev[0] = acc[0];
