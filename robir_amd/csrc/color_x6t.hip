@@ -73,25 +73,31 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
   // this round's rows -> operands of layer 0: features in place (x feat_scale), tail encoded by the four lane groups of a row
   auto load_layer0 = [&]() {
     sat_in = 0u;
+    // both tiles' feature rows are requested before either is split: one HBM latency per round, the second tile's under the first's
+    // vector work.  Rows beyond M read row 0 (valid memory, finite values): their rgb rows are dropped by the output descriptor.
+    ct_f4u fv[2][16];
+    long rr[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const long rrow = round * 128 + t * 64 + rlocal;
-      const bool ok = rrow < M;
-      const long rr = ok ? rrow : 0;
+      rr[t] = rrow < M ? rrow : 0;
+      const float* pf = feat + rr[t] * feat_stride + g * 4;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) fv[t][kb] = *reinterpret_cast<const ct_f4u*>(pf + kb * 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
       float in0[80];
-      const float* pf = feat + rr * feat_stride + g * 4;
 #pragma unroll
-      for (int kb = 0; kb < 16; ++kb) {
-        const ct_f4u v = *reinterpret_cast<const ct_f4u*>(pf + kb * 16);
+      for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) in0[kb * 4 + r] = ok ? v[r] * feat_scale : 0.f;
-      }
+        for (int r = 0; r < 4; ++r) in0[kb * 4 + r] = fv[t][kb][r] * feat_scale;
       float pv[3], px[3], pn[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        pv[c] = pview[3 * rr + c];
-        px[c] = pxyz[3 * rr + c];
-        pn[c] = pnormal[3 * rr + c];
+        pv[c] = pview[3 * rr[t] + c];
+        px[c] = pxyz[3 * rr[t] + c];
+        pn[c] = pnormal[3 * rr[t] + c];
       }
       float* trow = tail_lds + ((wave * 2 + t) * 16 + (lane & 15)) * 48;
       if (g == 0) {
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
       const f4* pt = reinterpret_cast<const f4*>(trow) + g;
 #pragma unroll
       for (int kb = 0; kb < 3; ++kb) {
-        const f4 v = ok ? pt[kb * 4] : f4{0.f, 0.f, 0.f, 0.f};
+        const f4 v = pt[kb * 4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) in0[64 + kb * 4 + r] = v[r];
       }
