@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
   };
   // the gates of (stream layer, chunk) for both tiles -> this wave's gate slots; layer < 0: the next round's stream layer 0 ... which has no
   // gate of its own; none: a dummy copy (every chunk issues the same number of copies)
-  auto gate_copy = [&](int t, int gate_layer, int chunk, unsigned gslot, bool next_round) {
+  // lv: the lane offset of the chunk's copies (derived by the first gate copy, reused by the second and by the weight pieces)
+  auto gate_copy = [&](int t, int gate_layer, int chunk, unsigned gslot, bool next_round, unsigned& lv) {
     const f4* base = (next_round ? sig_wave_next : sig_wave) + t * 4 * TILE_F4;
 #ifdef BT_ABL_GATE_FIXED              // timing ablation (wrong results): every gate copy reads the same (cache-resident) kilobyte
     const f4* src = sig;
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
 #else
     const f4* src = gate_layer >= 0 ? base + ((long)gate_layer * 16 + chunk) * 64 : base;
 #endif
-    xt_dma16_imm<0>(src, xt_lane16<0>(), gate_b + (unsigned)t * 6144u + gslot);
+    if (t == 0) lv = xt_lane16<0>();
+    xt_dma16_imm<0>(src, lv, gate_b + (unsigned)t * 6144u + gslot);
   };
 
   // gate: sigmoid layer that gates this stream layer's outputs (stream layers 0..6: 6 - l); gate_next: ... the next stream layer's
@@ -180,8 +182,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
         for (int i = 0; i < 13; ++i)
           if (i < ni && xt_item_slot(i, ni, NFREE) == a) {
             if (i < ne) ep_item(i, jb - 1, ep_gslot);
-            else if (i - ne < 2) gate_copy(i - ne, g_layer, g_chunk, g_slot, nl && LI == 7);
-            else xt_copy_piece_seq(i - ne - 2, src3, dst3, lv);
+            else if (i - ne < 2) gate_copy(i - ne, g_layer, g_chunk, g_slot, nl && LI == 7, lv);
+            else xt_copy_piece_seq(i - ne - 2, src3, dst3, lv, true);
           }
       };
       auto refill = [&](int piece, int part) {
@@ -236,8 +238,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_back_x6t(const f4* __restrict__ 
       xt_copy_piece(i, Wt + bt_coff(c) + 4 + first * 64, ring_b + slot_b[c] + (unsigned)first * 1024u);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    gate_copy(0, 6, c, gslot_b[c], false);
-    gate_copy(1, 6, c, gslot_b[c], false);
+    unsigned lv0;
+    gate_copy(0, 6, c, gslot_b[c], false, lv0);
+    gate_copy(1, 6, c, gslot_b[c], false, lv0);
   }
   sx_wait<0>();
   __syncthreads();

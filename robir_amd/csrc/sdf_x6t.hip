@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     // its two values, B = exact three-way split into the next layer's operand registers (+ the tile's sigmoid store behind its second pair)
     float ev[4][2];
     float sg[4][2];
+    unsigned lv = 0u;              // lane offset of the running chunk's copies, carried from piece to piece (x6t_engine.h)
+    bool ep_own_voff = true;       // the epilogue item that runs has no copy of this chunk in front of it
+    int ep_voff_adj = 0;           // 4096 once piece 4 of the chunk's copies has advanced lv
     // Z = the three classes of a tile's four values combined (frees the previous chunk's accumulators early)
     auto item_z = [&](int t, const SxAcc& a) {
 #pragma unroll
@@ -171,11 +174,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 #endif
           // [tile = row / 16][layer 8][chunk 16][lane 64] float4 (a pair = 8 bytes of it), through the round's descriptor
           typedef unsigned u2v __attribute__((ext_vector_type(2)));
-          const unsigned voff = xt_lane16<0>();       // re-derived: x6t_engine.h
-          int sbase = sig_wave + lr * (16 * 1024);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
+          // lane offset: the one this chunk's copies carry (they are issued in front of the epilogue: lane 16, + 4 KB once piece 4
+          // has gone), or re-derived where the epilogue runs in front of the copies (x6t_engine.h: no long-lived register)
+          const unsigned voff = ep_own_voff ? xt_lane16<0>() : lv;
+          int sbase = sig_wave + lr * (16 * 1024) - (ep_own_voff ? 0 : ep_voff_adj);      // formed here: hoisted out of the round loop the scalar offsets of a layer's 64 stores would not fit the SGPR file
           asm volatile("" : "+s"(sbase));
 #ifdef SXT_ABL_STORE_FIXED              // timing ablation (wrong results): every sigmoid store of a wave goes to the same kilobyte
-          sbase = sig_wave - (t * 4 * 8 * 16 + pj) * 1024 - q * 8;
+          sbase = sig_wave - (t * 4 * 8 * 16 + pj) * 1024 - q * 8 - (ep_own_voff ? 0 : ep_voff_adj);
 #endif
           __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])}, sig_rsrc,
                                                 (int)voff, sbase + (t * 4 * 8 * 16 + pj) * 1024 + q * 8, 0);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
       const int ne = jb > 0 ? NE : 0, ni = ne + NC3;
-      unsigned lv = 0u;             // lane offset of this chunk's copies, carried from piece to piece (x6t_engine.h)
+      ep_voff_adj = NC3 > 4 ? 4096 : 0;
       auto filler = [&](int pos) {
         // the next chunk's bias, requested BEFORE the last part's fragment requests: behind them, its use at the top of the next chunk
         // would wait for all of them (lgkmcnt(0))
@@ -290,7 +295,10 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
           // second part reads from its first run on -- all thirteen items go into the first part, the copies behind them
 #pragma unroll
           for (int i = 0; i < 13; ++i)
-            if (xt_item_slot(i, 13, 9) == a) hidden_item(i, PNCH - 1, PREV_SKIPOUT, lrt - 1, P);      // straight into this layer's own operands
+            if (xt_item_slot(i, 13, 9) == a) {
+              ep_own_voff = true;
+              hidden_item(i, PNCH - 1, PREV_SKIPOUT, lrt - 1, P);      // straight into this layer's own operands
+            }
 #pragma unroll
           for (int i = 0; i < 8; ++i)
             if (i < NC3 && 9 + xt_item_slot(i, NC3, NFREE - 9) == a) {
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
         for (int i = 0; i < 22; ++i)
           if (i < ni && (i < ne ? NC3 + xt_item_slot(i, ne > 0 ? ne : 1, NFREE - NC3) : i - ne) == a) {
             if (i < ne) {
+              ep_own_voff = NC3 == 0;
               if (jb > 0) ep_item(i, jb - 1);
             } else {
 #ifndef SXT_NODMA

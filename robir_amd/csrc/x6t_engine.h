@@ -77,10 +77,11 @@ template <int OFF>
 __device__ __forceinline__ void xt_dma16_keep(const f4* gbase_uniform, unsigned lane_byte_off) {
   asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(lane_byte_off), "s"(gbase_uniform), "n"(OFF) : "memory");
 }
-__device__ __forceinline__ void xt_copy_piece_seq(int i, const f4* src_span, unsigned dst_span, unsigned& lv) {
+// have_lv: `lv` already holds lane 16 (a copy issued earlier in the chunk derived it: sdf_back_x6t's gate copies)
+__device__ __forceinline__ void xt_copy_piece_seq(int i, const f4* src_span, unsigned dst_span, unsigned& lv, bool have_lv = false) {
   switch (i) {
     case 0:
-      lv = xt_lane16<0>();
+      if (!have_lv) lv = xt_lane16<0>();
       xt_dma16_imm<0>(src_span, lv, dst_span);
       break;
     case 1: xt_dma16_keep<1024>(src_span, lv); break;
