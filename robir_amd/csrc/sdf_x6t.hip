@@ -24,6 +24,10 @@
 #include "x6t_engine.h"
 #include <type_traits>
 
+#ifndef SXT_STORE128
+#define SXT_STORE128 0      // 1: one 16-byte sigmoid store per tile and chunk instead of two 8-byte ones: measured equal (11.14 vs 11.09 ms value + gradient), more spills
+#endif
+
 namespace rb {
 
 template <int MODE>
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     auto ep_stores = [](bool out_layer, int pj) {
       if (pj < 0) return 0;
       if (out_layer) return FULL ? (pj < 16 ? 8 : 2) : (pj == 0 ? 2 : 0);
-      return STORE ? 4 : 0;
+      return STORE ? (SXT_STORE128 ? 2 : 4) : 0;
     };
     SxAcc acc[2];
     constexpr bool PREV_SKIPOUT = LI == 4, PEND = LI != 0;      // the layer before this one: its outputs are scaled (layer 3) / it left its last chunk pending (every hidden layer)
@@ -182,8 +186,15 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 #ifdef SXT_ABL_STORE_FIXED              // timing ablation (wrong results): every sigmoid store of a wave goes to the same kilobyte
           sbase = sig_wave - (t * 4 * 8 * 16 + pj) * 1024 - q * 8 - (ep_own_voff ? 0 : ep_voff_adj);
 #endif
+#if SXT_STORE128                        // one 16-byte store per tile and chunk behind its second pair: whole lines, half the store instructions
+          if (q == 1)
+            __builtin_amdgcn_raw_buffer_store_b128(u4{__builtin_bit_cast(unsigned, sg[i - 1][0]), __builtin_bit_cast(unsigned, sg[i - 1][1]),
+                                                      __builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])},
+                                                   sig_rsrc, (int)voff, sbase + (t * 4 * 8 * 16 + pj) * 1024, 0);
+#else
           __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sg[i][0]), __builtin_bit_cast(unsigned, sg[i][1])}, sig_rsrc,
                                                 (int)voff, sbase + (t * 4 * 8 * 16 + pj) * 1024 + q * 8, 0);
+#endif
         }
     };
     auto item_b = [&](int i, int pj, auto& Y) {
@@ -254,19 +265,28 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       else ns = ep_stores(LI == 0, PNCH - 2) + (LI == 0 ? ep_stores(true, PNCH - 1) : 0);      // an output layer finishes its last chunk at once
       switch (sx_nsw(K2) + ns) {
         case 2: sx_wait<2>(); break;
+        case 3: sx_wait<3>(); break;
         case 4: sx_wait<4>(); break;
+        case 5: sx_wait<5>(); break;
         case 6: sx_wait<6>(); break;
         case 7: sx_wait<7>(); break;
         case 8: sx_wait<8>(); break;
+        case 9: sx_wait<9>(); break;
         case 10: sx_wait<10>(); break;
         case 11: sx_wait<11>(); break;
         case 12: sx_wait<12>(); break;
+        case 13: sx_wait<13>(); break;
         case 14: sx_wait<14>(); break;
         case 15: sx_wait<15>(); break;
         case 16: sx_wait<16>(); break;
+        case 17: sx_wait<17>(); break;
         case 18: sx_wait<18>(); break;
+        case 19: sx_wait<19>(); break;
+        case 20: sx_wait<20>(); break;
+        case 21: sx_wait<21>(); break;
         case 22: sx_wait<22>(); break;
         case 23: sx_wait<23>(); break;
+        case 24: sx_wait<24>(); break;
         default: sx_wait<2>(); break;      // any combination not listed: the strictest wait (safe)
       }
 #ifndef SXT_NOBAR
