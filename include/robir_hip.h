@@ -145,15 +145,16 @@ int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, in
                      rb_stream_t stream);
 /* rb_sdf_x6_points with TWO 16-row tiles per wave (csrc/sdf_x6t.hip + x6t_engine.h, round 4): a weight fragment read from the LDS feeds
  * two MFMAs per product, a pass of the weights serves 128 rows.  Same arguments, same blob, same arithmetic (the products of a class are
- * summed part by part: results agree with rb_sdf_x6_points to fp32 summation order).  The host mirror takes it for >= 32768 rows (below
- * that the one-tile kernel's rounds of 64 rows fill the chip better). */
+ * summed part by part: results agree with rb_sdf_x6_points to fp32 summation order).  The host mirror takes it where it
+ * needs fewer than two thirds of the one-tile form's passes over the persistent grid (16385-32768 rows, > 49152 rows on 256 compute
+ * units); elsewhere the one-tile kernel's rounds of 64 rows fill the chip better. */
 int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
                       rb_stream_t stream);
 /* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
 int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
 /* rb_color_x6_points with TWO 16-row tiles per wave (csrc/color_x6t.hip + x6t_engine.h, round 4): same arguments, same blob, results agree
- * with rb_color_x6_points to fp32 summation order.  The host mirror takes it for >= 32768 rows. */
+ * with rb_color_x6_points to fp32 summation order.  The host mirror takes it by the same rule. */
 int rb_color_x6t_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                         const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
 /* The visibility MLP on exact three-piece operands (csrc/vis_x6.hip; Wp = packing.pack_vis_x6): the arguments of rb_vis_mlp_points. */

@@ -357,14 +357,31 @@ def sdf_value_grad_f32(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     return out0, grad
 
 
-SDF_TWO_TILE_MIN_ROWS = int(os.environ.get("ROBIR_SDF_TWO_TILE_MIN_ROWS", "32768"))
+SDF_TWO_TILE_MIN_ROWS = int(os.environ.get("ROBIR_SDF_TWO_TILE_MIN_ROWS", "16385"))
+_CU_COUNT = []
+
+
+def _compute_units():
+    if not _CU_COUNT:
+        _CU_COUNT.append(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256)
+    return _CU_COUNT[0]
 
 
 def sdf_two_tile(M):
-    """The exact-operand SDF kernels come in two forms: two 16-row tiles per wave (rounds of 128 rows, half the LDS traffic per MFMA:
-    csrc/sdf_x6t.hip, sdf_back_x6t.hip) once a launch fills the chip with them (>= 128 rows x 256 CUs), one tile per wave (rounds of 64
-    rows, more and shorter rounds) below.  The two agree to fp32 summation order."""
-    return M >= SDF_TWO_TILE_MIN_ROWS
+    """The exact-operand SDF / colour kernels come in two forms: two 16-row tiles per wave (rounds of 128 rows, half the LDS traffic per
+    MFMA: csrc/sdf_x6t.hip, sdf_back_x6t.hip, color_x6t.hip) and one tile per wave (rounds of 64 rows).  Both run one persistent
+    workgroup per compute unit, so a launch costs (rounds per workgroup) x (time of a round), and a two-tile round takes 1.42-1.5 x a
+    one-tile round (tools/sweep_two_tile.py: 0.135 / 0.095 ms distance, 0.31 / 0.21 value + gradient, 0.083 / 0.055 colour): the
+    two-tile form wins where it needs fewer than two thirds of the passes -- 16385..32768 rows, and everything beyond 49152 on 256
+    compute units.  ROBIR_SDF_TWO_TILE_MIN_ROWS: rows below it always take the one-tile form (0: always two tiles).  The two forms
+    agree to fp32 summation order."""
+    if SDF_TWO_TILE_MIN_ROWS <= 0:
+        return True
+    if M < SDF_TWO_TILE_MIN_ROWS:
+        return False
+    cus = _compute_units()
+    r1, r2 = -(-M // (64 * cus)), -(-M // (128 * cus))
+    return 2 * r1 > 3 * r2
 
 
 def sdf_points_x6(x, M, blob, full, in_scale=1.0, out_scale=1.0):

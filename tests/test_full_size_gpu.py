@@ -134,7 +134,7 @@ def test_config3_illum_forward_800(model, view800, dev):
 def test_config3_trace_radiance_800(model, view800, dev):
     """BASELINE config 3 at full size: 'Illum' forward of the whole 800x800 view, then trace_radiance(nsamp=8) with every
     1024-pixel chunk as its own lock-step batch of secondary rays (the reference's per-chunk calls).  No oracle at this
-    size: properties -- the whole-view call equals per-chunk calls on sampled chunks bit for bit, run-to-run determinism, masks
+    size: properties -- the whole-view call equals per-chunk calls on sampled chunks (masks bit for bit, radiance to fp32 summation order), run-to-run determinism, masks
     and radiance consistent with each other."""
     uv, pose, K = view800
     N = uv.shape[0]
@@ -163,8 +163,13 @@ def test_config3_trace_radiance_800(model, view800, dev):
         sub = {k: o[k][sl] for k in ("points", "hdr_shift", "network_object_mask", "normals")}
         r0, r1 = int(first[c]) * 8, int(first[c + 1]) * 8
         one = model.trace_radiance(sub, nsamp=8, draws=(u1[r0:r1], u2[r0:r1]))
-        for k in ("trace_radiance", "gt_vis", "pred_vis", "indir_mask", "gt_integral"):
+        for k in ("gt_vis", "pred_vis", "indir_mask"):
             assert _same(one[k], a[k][sl]), (c, k)
+        # the borrowed radiance goes through the SDF / colour nets, whose kernel form follows the launch size (ops.sdf_two_tile: a chunk's
+        # points and a 65536-ray slab may take different forms, which agree to 2e-6 on the SDF outputs): through the surface search and the
+        # colour net the radiance agrees to 2e-5 (measured), held to the per-stage bar
+        for k in ("trace_radiance", "gt_integral"):
+            assert rel_err(one[k].cpu(), a[k][sl].cpu()) <= 1e-4, (c, k, rel_err(one[k].cpu(), a[k][sl].cpu()))
 
 
 def test_config2_render_neus_400x400(dev, synth_weights):
@@ -200,7 +205,7 @@ def test_config2_render_neus_400x400(dev, synth_weights):
 def test_config1_sdf_forward_64x64x64(dev, synth_weights):
     """64x64 crop, 64 samples per ray: the SDF network on 262 144 points against itself evaluated in 1024-row chunks (the
     reference's own chunk loop, neus_model.py:398-415).  Since round 4 the exact-operand net has two kernel forms -- two tiles per wave
-    from 32768 rows on, one tile below (ops.sdf_two_tile) -- which sum a weight class's products in different orders: the whole batch
+    where they need fewer than two thirds of the one-tile form's passes, one tile elsewhere (ops.sdf_two_tile) -- which sum a weight class's products in different orders: the whole batch
     and its 1024-row chunks agree to fp32 summation order (<= 2e-6 of the largest output), each form with itself bit for bit."""
     from robir_amd import nets, ops, synth
     m = nets.NeuSModel()

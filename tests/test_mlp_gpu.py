@@ -670,7 +670,7 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
     b32, back = packing.pack_sdf(sd, dev, full=True), packing.pack_sdf_back(sd, dev)
     x6f, x6d = packing.pack_sdf_x6(sd, dev, full=True), packing.pack_sdf_x6(sd, dev, full=False)
     back6 = packing.pack_sdf_back_x6(sd, dev) + (packing.pack_sdf_back_x6(sd, dev, two_tile=True)[0],)     # as nets.packed_back_x6
-    for n in (1, 15, 64, 65, 1000, 40000, 300001):      # from 32768 rows on: the two-tile kernels (ops.sdf_two_tile)
+    for n in (1, 15, 64, 65, 1000, 40000, 300001):      # 40000 rows: one tile per wave, 300001: two (ops.sdf_two_tile)
         x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
         ref = ops.sdf_mlp_points(x, n, b32, 1, 2.0, 0.5, 1.0)[0]
         out = ops.sdf_points_x6(x, n, x6f, True, 2.0, 0.5)
@@ -688,13 +688,13 @@ def test_sdf_exact_operand_kernel(dev, synth_weights, weights):
     for n in (100, 33000, 70001):
         x = ((torch.rand(n, 3, generator=g) - 0.5) * 1.2).to(dev)
         res = {}
-        for rows in (1, 1 << 60):
+        for rows in (0, 1 << 60):       # 0: two tiles per wave at every size | never
             old, ops.SDF_TWO_TILE_MIN_ROWS = ops.SDF_TWO_TILE_MIN_ROWS, rows
             try:
                 res[rows] = (ops.sdf_points_x6(x, n, x6d, False, 2.0, 0.5),) + ops.sdf_value_grad_x6(x, n, x6f, back6, 2.0, 0.5)
             finally:
                 ops.SDF_TWO_TILE_MIN_ROWS = old
-        two, one = res[1], res[1 << 60]
+        two, one = res[0], res[1 << 60]
         assert rel_err(two[0].cpu(), one[0].cpu()) <= 2e-6 and rel_err(two[1].cpu(), one[1].cpu()) <= 2e-6, n
         assert rel_err(two[2].cpu(), one[2].cpu()) <= 2e-5, (n, rel_err(two[2].cpu(), one[2].cpu()))
     x = ((torch.rand(300, 3, generator=g) - 0.5) * 1.2)
