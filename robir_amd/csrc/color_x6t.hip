@@ -5,7 +5,7 @@
 // two k-blocks; K = 256 after: two parts of four) through a 4-slot LDS ring of 30 KB slots, all biases resident in the LDS, rounds of
 // 128 rows, the copies of the chunk three ahead first and the previous chunk's relu + exact three-way split behind them, the rgb rows
 // through a per-round buffer descriptor.  The products of a class are summed part by part: results agree with k_color_x6 to fp32
-// summation order.  The host mirror takes this kernel from 32768 rows on (ops.sdf_two_tile).
+// summation order.  The host mirror takes this kernel where it needs fewer than two thirds of the one-tile form's passes (ops.sdf_two_tile).
 #include "../../include/robir_hip.h"
 #include "common.h"
 #include "mlp_engine.h"
