@@ -385,6 +385,13 @@ int rb_dvis_v2_debug(unsigned long long* out8);
 int rb_spec_vis_sample(const float* normal, const float* view, const float* rough, const int* chunk_id, long n,
                        int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
                        unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);
+/* The same sampling stage for a caller that passes its own lobes / lambdas -- the reference's exact signature
+ * get_specular_visibility(points, normals, viewdirs, VisModel, lgtSGLobes [n,3], lgtSGLambdas [n,1], nsamp, ...), model/sg_render.py:198-223:
+ * the cone is still built around the reflection of the view about the normal (:204-207), its opening from clip(lambdas, 0.1, 50) and the
+ * batch-global (per chunk_id) minimum (:219-223), the sample weights exp(sharp (d . lobes - 1)) from the passed lobes AS GIVEN (:281). */
+int rb_spec_vis_sample_lobes(const float* normal, const float* view, const float* lobes, const float* lambdas, const int* chunk_id,
+                             long n, int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
+                             unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);
 int rb_spec_vis_reduce(const float* logits, const unsigned char* front, const float* wts, long n, int nsamp, int inv,
                        int argmax_vis, int testing, float* bvis, rb_stream_t stream);
 
@@ -446,10 +453,15 @@ int rb_octree_cast_finish(const float* node, const float* nrm, long B, const flo
                           const int* res, const float* origins, const float* dirs, long R, int max_iter, float clamp_dt,
                           const float* t, const int* leaf, float* x_out, unsigned char* hit_out, float* t_out,
                           rb_stream_t stream);
-/* init + every iteration + finish of one lock-step batch of any size in ONE launch (persistent grid, grid-wide arrival counters
- * instead of one launch per iteration): counters[it_limit + 1] int32 (output: rays active at the start of each iteration) and
- * arrive[1024] 64-bit words zeroed by the caller (passed as int*, 8-byte aligned: one slot per workgroup of the grid barrier) (it_limit =
- * max_iter + 1, or max_total when max_iter <= 0: iterate until no ray is active); the same results bit for bit. */
+/* init + every iteration + finish of one lock-step batch of any size in ONE launch (persistent grid with a grid barrier instead of
+ * one launch per iteration): counters[it_limit + 1] int32 (output: rays active at the start of each iteration; it_limit = max_iter + 1,
+ * or max_total when max_iter <= 0: iterate until no ray is active) and arrive[1024] 64-bit words zeroed by the caller (passed as int*,
+ * 8-byte aligned): the barrier's slots, 2 x 512 selected by epoch parity -- workgroup g publishes {epoch, its active count} in slot
+ * [epoch & 1][g], so the grid is capped at 512 workgroups.  The same results as the per-iteration launches bit for bit.
+ * The barrier spins, so the grid must be co-resident: the launch is a COOPERATIVE one (hipLaunchCooperativeKernel; grid <= what the
+ * occupancy query of the current device allows, cached per device id).  Returns 0 = done, 2 = the runtime refused the launch (another
+ * stream or rank holds compute units; cooperative launches unsupported): NOTHING ran, take rb_octree_cast_init / _iter / _finish;
+ * any other value = error. */
 int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
                         const int* res, const float* origins, const float* dirs, long R, int max_iter, double step, int max_total,
                         float clamp_dt, float* t, int* leaf, unsigned char* active, int* counters, int* arrive, float* x_out,
@@ -514,6 +526,7 @@ int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char*
 /* ------------------------------------------------------------------------------------------------------------
  * NeuS ray-march with hierarchical sampling -- the non-MLP steps of render_neus (model/sdf_render.py:263-374):
  * rb_neus_coarse_z  z[R,n] = near + (far-near)*lin[n]                                   (:279-283)
+ * rb_neus_jitter_z  perturb > 0: z[r,:] += (u[r] - 0.5) * 2.0 / n, u[R] = the ray's one uniform draw (:293-295)
  * rb_ray_points     pts[R*n,3] = o + d*z (dirs[R*n,3] = d per sample, may be NULL)      (:313, :192-196)
  * rb_neus_upsample  up_sample + sample_pdf(det=True): z_new[R,n_new]; u[n_new] = the deterministic quantiles;
  *                   wtmp[R,n] scratch                                                   (:70-114, :37-67)
@@ -526,6 +539,7 @@ int rb_trace_integrate(const float* rad, const float* cosw, const unsigned char*
  * rb_surface_points / rb_surface_finish: NormalTrainRunner.get_neus_surface (training/train_normal.py:239-286).
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_neus_coarse_z(const float* near, const float* far, const float* lin, long R, int n, float* z, rb_stream_t stream);
+int rb_neus_jitter_z(const float* u, long R, int n, float* z, rb_stream_t stream);
 int rb_ray_points(const float* o, const float* d, const float* z, long R, int n, float* pts, float* dirs,
                   rb_stream_t stream);
 int rb_neus_upsample(const float* o, const float* d, const float* z, const float* sdf, long R, int n, int n_new,

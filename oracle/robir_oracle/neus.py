@@ -86,8 +86,9 @@ def importance_z(rays_o, rays_d, z, sdf, n_new, s, radius):
 
 
 def render_neus(sd, rays_o, rays_d, near, far, n_samples=64, n_importance=64, up_sample_steps=4,
-                white_bkgd=True, cos_anneal_ratio=None):
-    """render_neus with n_outside=0, is_eval=True (sdf_render.py:263-374) in NeuS space.
+                white_bkgd=True, cos_anneal_ratio=None, t_rand=None):
+    """render_neus with n_outside=0 (sdf_render.py:263-374) in NeuS space; is_eval=True / perturb=0 unless `t_rand` [R,1] is given:
+    the uniform draw of perturb > 0 (:293-295), every coarse sample of a ray shifted by (t_rand - 0.5) * 2.0 / n_samples.
     rays_o/d [R,3]; near/far [R,1].  -> dict(rgb, dist, acc, grad, weights, grad_error, z_vals).
     cos_anneal_ratio not None: the stage-1 render_core (neus/volume_render/sdf_render.py:172-190), whose alpha comes from
     the SDF extrapolated half a section along the ray with the annealed cosine instead of from the neighbouring samples."""
@@ -95,6 +96,8 @@ def render_neus(sd, rays_o, rays_d, near, far, n_samples=64, n_importance=64, up
     sample_dist = 2.0 / n_samples
     radius = 2.0                                                        # NeuSModel.radius() (neus_model.py:743)
     z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples)[None, :]
+    if t_rand is not None:
+        z = z + (t_rand - 0.5) * 2.0 / n_samples
     sdf_only = lambda p: nets.sdf_raw(sd, p)[:, :1]
     if n_importance > 0:
         sdf = sdf_only((rays_o[:, None, :] + rays_d[:, None, :] * z[..., None]).reshape(-1, 3)).reshape(R, -1)

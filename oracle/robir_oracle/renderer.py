@@ -155,10 +155,12 @@ def cesr_sg_render(sd, shadow_sd, normal_sd, points, view_dirs, indir_sgs, indir
 
 # ----------------------------------------------------------------------------- forward
 def forward(sd, tables, uv, pose, K, object_mask, hdr_shift, draws, trainstage="Material", testing=True,
-            trace_log=None, stats=None, cesr=None):
+            trace_log=None, stats=None, cesr=None, envmap=None):
     """IDRNetwork.forward, uv/pose/intrinsics input form (implicit_differentiable_renderer.py:290-479)
     for one lock-step batch of B x N pixels (the runners use B = 1; B views are ONE cast over B N rays, :299-305, outputs
-    flattened to [B N, ...]).  tables: primary octree.  draws: see robir_amd.synth.pbr_draws (row counts = number of hit rays)."""
+    flattened to [B N, ...]).  tables: primary octree.  draws: see robir_amd.synth.pbr_draws (row counts = number of hit rays).
+    envmap [H,W,3]: the background map a relight run has loaded (EnvmapMaterialNetwork.load_light, sg_envmap_material.py:257-268):
+    bg_rgb = its lat-long lookup along EVERY ray (:360-362) instead of ones."""
     dirs, cam = camera_rays(uv, pose, K)
     B, N = dirs.shape[0], dirs.shape[1]
     _, hit, dist = octree_mod.trace(tables, cam, dirs, -1, trace_log)
@@ -200,6 +202,8 @@ def forward(sd, tables, uv, pose, K, object_mask, hdr_shift, draws, trainstage="
             out[k][hit] = v.expand(-1, 3) if v.shape[-1] == 1 else v
         out["metallic"][hit] = r["metallic"]
         out["random_xi_metallic"][hit] = r["random_xi_metallic"]
+    if envmap is not None:
+        out["bg_rgb"] = sg.envmap_lookup(envmap, dirs)
     ret.update(out)
     ret["surface_mask"] = hit
     return ret

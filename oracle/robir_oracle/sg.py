@@ -309,3 +309,24 @@ def envmap_grid(lgt_sgs, H, W, upper_hemi=False):
     phi, theta = torch.meshgrid(phi, theta, indexing="ij")
     d = torch.stack([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], -1)
     return envmap_sg(lgt_sgs, d)
+
+
+def envmap_lookup(envmap, dirs):
+    """render_envmap (sg_render.py:45-59): bilinear lat-long lookup of envmap [H,W,3] along dirs [n,3] -> [n,3].  The reference goes through
+    F.grid_sample(align_corners=True, zero padding); restated here as the explicit four-texel blend: query_x = -atan2(y, x) / pi,
+    query_y = (arccos(z) - 1e-6) / pi * 2 - 1 map [-1, 1] onto the texel CENTRES 0 .. W-1 / 0 .. H-1, texels outside the map count as 0."""
+    H, W = envmap.shape[:2]
+    phi = torch.arccos(dirs[:, 2]) - TINY
+    theta = torch.atan2(dirs[:, 1], dirs[:, 0])
+    qx, qy = -theta / math.pi, (phi / math.pi) * 2 - 1
+    x, y = (qx + 1) / 2 * (W - 1), (qy + 1) / 2 * (H - 1)
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = x - x0, y - y0
+    out = torch.zeros(dirs.shape[0], envmap.shape[2], dtype=envmap.dtype)
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xi, yi = (x0 + dx).long(), (y0 + dy).long()
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            tex = envmap[yi.clamp(0, H - 1), xi.clamp(0, W - 1)]
+            out = out + torch.where(ok[:, None], tex, torch.zeros_like(tex)) * (wx * wy)[:, None]
+    return out

@@ -90,12 +90,13 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
-    else sat_in = sat_acc(sat_in, h);
+    // softplus outputs are >= 0 but NaN passes through them (NaN points of axis-parallel rays): sat_acc_pos, not the one-instruction
+    // raw-pattern form of the ReLU kernels, which a positive NaN would trip; signed inputs: sat_acc.  One domain (limit 0x7ffe).
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_pos(sat, h);
+    else sat = sat_acc(sat, h);
   };
   auto fold_sat_in = [&]() {
-    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
-    sat_in = 0u;
+    (void)sat_in;          // round 5: inputs and activations share sat_acc's domain, nothing to fold
   };
   // input value k of this lane's row (k = 16 blk + 4 g + r): the encoder's LDS row, then the one-hot block from column 63 on
   auto x0_block = [&](int blk, float scale, float (&v)[4]) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     };
     auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
     auto hidden_pair = [&](const SxAcc& a, int pj, int q) {
-      float v0 = softplus100_fast(combine(a, 2 * q), nullptr), v1 = softplus100_fast(combine(a, 2 * q + 1), nullptr);
+      float v0 = softplus100_stable(combine(a, 2 * q), nullptr), v1 = softplus100_stable(combine(a, 2 * q + 1), nullptr);
       if (SKIPOUT) {
         v0 *= inv_sqrt2;
         v1 *= inv_sqrt2;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       else run_layer(std::integral_constant<int, 1>{}, ub);
     }
   }
-  range_report<true>(sat, range_word);
+  range_report<false>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

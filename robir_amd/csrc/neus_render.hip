@@ -32,6 +32,15 @@ __global__ void k_coarse_z(const float* __restrict__ near, const float* __restri
   z[j] = near[r] + (far[r] - near[r]) * lin[j % n];
 }
 
+// perturb > 0 (sdf_render.py:293-295): ONE uniform draw per ray shifts all of its coarse samples,
+// z[r,i] += (u[r] - 0.5) * 2.0 / n  -- the reference's operation order ((t * 2.0) / n), -ffp-contract=off
+__global__ void k_jitter_z(const float* __restrict__ u, long R, int n, float* __restrict__ z) {
+  const long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= R * n) return;
+  const float t = u[j / n] - 0.5f;
+  z[j] = z[j] + (t * 2.0f) / (float)n;
+}
+
 // up_sample + sample_pdf(det=True) (sdf_render.py:70-114, 37-67): n_new importance samples per ray.
 // wtmp[R, n] is scratch for the interval weights.
 __global__ void k_upsample(const float* __restrict__ o, const float* __restrict__ d, const float* __restrict__ z,
@@ -317,6 +326,14 @@ int rb_neus_coarse_z(const float* near, const float* far, const float* lin, long
   RB_REQUIRE(near && far && lin && z, "null pointer");
   hipLaunchKernelGGL(k_coarse_z, grid1d(R * n, 256), dim3(256), 0, (hipStream_t)stream, near, far, lin, R, n, z);
   return check_launch("k_coarse_z");
+}
+
+int rb_neus_jitter_z(const float* u, long R, int n, float* z, rb_stream_t stream) {
+  if (R <= 0) return 0;
+  RB_REQUIRE(u && z, "null pointer");
+  RB_REQUIRE(n >= 1, "need n >= 1 samples");
+  hipLaunchKernelGGL(k_jitter_z, grid1d(R * n, 256), dim3(256), 0, (hipStream_t)stream, u, R, n, z);
+  return check_launch("k_jitter_z");
 }
 
 int rb_neus_upsample(const float* o, const float* d, const float* z, const float* sdf, long R, int n, int n_new,

@@ -548,31 +548,46 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
   if (R <= 0) return 0;
   RB_REQUIRE(node && nrm && origins && dirs && t && leaf && active && counters && arrive && x_out && hit_out && t_out, "null pointer");
   RB_REQUIRE(max_total >= 1, "max_total >= 1");
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return rb::fail(__func__, "device query failed");
-    cus = prop.multiProcessorCount;
-  }
-  Oct T = make_oct(node, nrm, B, root_min, root_size, res);
+  // Co-residency of the whole grid is a REQUIREMENT (the grid barrier spins): the launch is a cooperative one, which the runtime
+  // refuses (instead of deadlocking) when the grid cannot be resident -- another stream's kernel holding compute units, a second rank
+  // on the same device -- and the grid is sized from the occupancy query of THIS device (cached per device id: ranks of one process
+  // group may sit on different parts).  Status 2 = "not launched, take the per-iteration launches" (ops.octree_cast_general does).
   static int lpr = 0;
   if (!lpr) {
     const char* e = getenv("ROBIR_CAST_LPR");
     lpr = e ? atoi(e) : 4;       // measured (tools/ab_cast.py, 7500 secondary rays): 1.13 / 0.82 / 2.0 ms at 1 / 4 / 16 lanes per ray
     if (lpr != 1 && lpr != 4 && lpr != 16) lpr = 4;
   }
+  const void* kern = lpr == 1 ? (const void*)k_cast_coop<1> : lpr == 4 ? (const void*)k_cast_coop<4> : (const void*)k_cast_coop<16>;
+  constexpr int MAX_DEV = 64;
+  static int resident[MAX_DEV] = {};          // workgroups of this kernel the device holds at once; 0 = not queried yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return rb::fail(__func__, "device query failed");
+  if (!resident[dev]) {
+    hipDeviceProp_t prop;
+    int per_cu = 0;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 1024, 0) != hipSuccess || per_cu < 1 || !prop.cooperativeLaunch) {
+      (void)hipGetLastError();
+      rb::fail(__func__, "cooperative launch not available on this device");
+      return 2;
+    }
+    resident[dev] = prop.multiProcessorCount * per_cu;
+  }
+  Oct T = make_oct(node, nrm, B, root_min, root_size, res);
   const long want = (R * lpr + 1023) / 1024;
-  const long cap = cus < CC_MAX_GROUPS ? cus : CC_MAX_GROUPS;
-  const unsigned grid = (unsigned)(want < cap ? want : cap);                // every workgroup resident: the grid barrier spins
-  const int it_limit = max_iter > 0 ? max_iter + 1 : max_total;
-  auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, (hipStream_t)stream, T, origins, dirs, R, max_iter, step, it_limit, clamp_dt, t,
-                       leaf, active, counters, (unsigned long long*)arrive, x_out, hit_out, t_out);
-  };
-  if (lpr == 1) go(k_cast_coop<1>);
-  else if (lpr == 4) go(k_cast_coop<4>);
-  else go(k_cast_coop<16>);
+  const long cap = resident[dev] < CC_MAX_GROUPS ? resident[dev] : CC_MAX_GROUPS;
+  const unsigned grid = (unsigned)(want < cap ? want : cap);
+  int it_limit = max_iter > 0 ? max_iter + 1 : max_total;
+  unsigned long long* arrive64 = (unsigned long long*)arrive;
+  void* args[] = {&T, &origins, &dirs, &R, &max_iter, &step, &it_limit, &clamp_dt, &t, &leaf, &active, &counters, &arrive64, &x_out,
+                  &hit_out, &t_out};
+  const hipError_t e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(1024), args, 0, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    rb::fail(__func__, hipGetErrorString(e));
+    return 2;
+  }
   return check_launch("k_cast_coop");
 }
 

@@ -62,12 +62,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
-    else sat_in = sat_acc(sat_in, h);
+    // softplus outputs are >= 0 but NaN passes through them (NaN points of axis-parallel rays): sat_acc_pos, not the one-instruction
+    // raw-pattern form of the ReLU kernels, which a positive NaN would trip; signed inputs: sat_acc.  One domain (limit 0x7ffe).
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_pos(sat, h);
+    else sat = sat_acc(sat, h);
   };
   auto fold_sat_in = [&]() {
-    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
-    sat_in = 0u;
+    (void)sat_in;          // round 5: inputs and activations share sat_acc's domain, nothing to fold
   };
   auto load_layer0 = [&]() {
     float x0[16];
@@ -132,17 +133,17 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
       const f2 c2 = q ? f2{a.c2[2], a.c2[3]} : f2{a.c2[0], a.c2[1]};
       const f2 k11 = f2{C11, C11};
       const f2 z = __builtin_elementwise_fma(__builtin_elementwise_fma(c2, k11, c1), k11, c0);
-      const f2 t = z * SP_T_PER_Z;
+      // softplus100_stable (mlp_engine.h) on a value pair
+      const f2 t = f2{-__builtin_fabsf(z[0]), -__builtin_fabsf(z[1])} * SP_T_PER_Z;
       const f2 e = f2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
       const f2 u = e + 1.0f;
-      f2 sp = f2{__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])} * SP_LN2_OVER_100;
-      const bool lin0 = t[0] > SP_T_LINEAR, lin1 = t[1] > SP_T_LINEAR;
+      const f2 lg = f2{__builtin_amdgcn_logf(u[0]), __builtin_amdgcn_logf(u[1])};
       if constexpr (STORE) {
-        const f2 sgv = e * f2{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
-        sg[2 * q] = lin0 ? 1.0f : sgv[0];
-        sg[2 * q + 1] = lin1 ? 1.0f : sgv[1];
+        const f2 r = f2{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
+        sg[2 * q] = (z[0] > 0.0f ? 1.0f : e[0]) * r[0];
+        sg[2 * q + 1] = (z[1] > 0.0f ? 1.0f : e[1]) * r[1];
       }
-      f2 v = f2{lin0 ? z[0] : sp[0], lin1 ? z[1] : sp[1]};
+      f2 v = __builtin_elementwise_fma(lg, f2{SP_LN2_OVER_100, SP_LN2_OVER_100}, f2{__builtin_fmaxf(z[0], 0.0f), __builtin_fmaxf(z[1], 0.0f)});
       if (SKIPOUT) v = v * inv_sqrt2;
       ev0[q] = v[0];
       ev1[q] = v[1];
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
 #else
     auto stage_a = [&](const SxAcc& a, int q, f4& sg) {
       float s0, s1;
-      // log(1 + e) without the log1p correction (mlp_engine.h: an absolute error <= 4e-10 on the activation, below an fp32 sum's own rounding)
-      float v0 = softplus100_fast(combine(a, 2 * q), &s0), v1 = softplus100_fast(combine(a, 2 * q + 1), &s1);
+      // the overflow-free form (mlp_engine.h: max(z, 0) + a correction <= 0.0069 from the hardware exp2 / log2)
+      float v0 = softplus100_stable(combine(a, 2 * q), &s0), v1 = softplus100_stable(combine(a, 2 * q + 1), &s1);
       if (SKIPOUT) {
         v0 *= inv_sqrt2;
         v1 *= inv_sqrt2;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6(const float* __restrict__ xyz
       else run_layer(std::integral_constant<int, 1>{}, cb, l);
     }
   }
-  range_report<true>(sat, range_word);
+  range_report<false>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

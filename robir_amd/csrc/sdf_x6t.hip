@@ -79,12 +79,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     dh[q] = h;
     dm[q] = m;
     dl[q] = l;
-    if constexpr (decltype(nonneg)::value) sat = sat_acc_nonneg(sat, h);
-    else sat_in = sat_acc(sat_in, h);
+    // softplus outputs are >= 0 but NaN passes through them (NaN points of axis-parallel rays): sat_acc_pos, not the one-instruction
+    // raw-pattern form of the ReLU kernels, which a positive NaN would trip; signed inputs: sat_acc.  One domain (limit 0x7ffe).
+    if constexpr (decltype(nonneg)::value) sat = sat_acc_pos(sat, h);
+    else sat = sat_acc(sat, h);
   };
   auto fold_sat_in = [&]() {
-    if ((short)(sat_in & 0xffffu) >= 0x7ffe || (short)(sat_in >> 16) >= 0x7ffe) sat = 0x7c007c00u;
-    sat_in = 0u;
+    (void)sat_in;          // round 5: inputs and activations share sat_acc's domain, nothing to fold
   };
   auto load_layer0 = [&]() {
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     auto item_a = [&](int i, int e, int pj, bool sk, int lr) {
       const int t = i >> 1, q = i & 1;
       float s;
-      float v = softplus100_fast(z[t][2 * q + e], &s);      // no log1p correction: |error| <= 4e-10 (mlp_engine.h)
+      float v = softplus100_stable(z[t][2 * q + e], &s);    // max(z, 0) + log(1 + exp(-|100 z|)) / 100 (mlp_engine.h)
       if (sk) v *= inv_sqrt2;
       ev[i][e] = v;
       sg[i][e] = s;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
     run_layer(std::integral_constant<int, 7>{}, 109, 7);
     run_layer(std::integral_constant<int, 8>{}, 125, 8);
   }
-  range_report<true>(sat, range_word);
+  range_report<false>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
 }

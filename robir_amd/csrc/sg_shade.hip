@@ -163,6 +163,48 @@ __global__ void k_spec_dirs(const float* __restrict__ normal, const float* __res
   wts[j] = expf(s * (dot3(d, wl) - 1.f));
 }
 
+// get_specular_visibility with the CALLER'S lobes (the reference's own signature, model/sg_render.py:198-223: light_dirs = the passed
+// lgtSGLobes [n,3] used as they are, sharpness = clip(passed lgtSGLambdas [n], 0.1, 50), batch-global minimum): two kernels like the
+// roughness form above -- the first records the clipped sharpness and its per-chunk minimum, the second samples the cone.
+__global__ void k_spec_sharp_lobes(const float* __restrict__ lambdas, const int* __restrict__ cid, long n, float* __restrict__ sharp,
+                                   unsigned* __restrict__ chunk_min) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = fminf(fmaxf(lambdas[i], 0.1f), 50.f);      // NaN -> 0.1 under fmaxf/fminf; torch.clip keeps NaN (a NaN lambda is a caller error)
+  sharp[i] = s;
+  atomicMin(chunk_min + (cid ? cid[i] : 0), __float_as_uint(s));
+}
+
+__global__ void k_spec_dirs_lobes(const float* __restrict__ normal, const float* __restrict__ view, const float* __restrict__ lobes,
+                                  const float* __restrict__ sharp, const int* __restrict__ cid,
+                                  const unsigned* __restrict__ chunk_min, const float* __restrict__ u_theta,
+                                  const float* __restrict__ u_phi, long n, int nsamp, float* __restrict__ dirs,
+                                  float* __restrict__ wts, unsigned char* __restrict__ front) {
+  long j = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j >= n * nsamp) return;
+  const long i = j / nsamp;
+  V3 nn = v3(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+  V3 vv = v3(view[3 * i], view[3 * i + 1], view[3 * i + 2]);
+  V3 wl = v3(lobes[3 * i], lobes[3 * i + 1], lobes[3 * i + 2]);
+  const float ndv = fmaxf(dot3(nn, vv), 0.f);
+  V3 refl = v3(-vv.x + 2.f * ndv * nn.x, -vv.y + 2.f * ndv * nn.y, -vv.z + 2.f * ndv * nn.z);
+  V3 U = unit_eps3(cross3(v3(0.f, 0.f, 1.f), refl));
+  V3 V = unit_eps3(cross3(refl, U));
+  const float s = sharp[i];
+  const float rng = fminf(__uint_as_float(chunk_min[cid ? cid[i] : 0]), 1.f);
+  const float phi_range = acosf((-0.95f * rng) / s + 1.f);
+  const float th = u_theta[j] * 2.f * RB_PI_F;
+  const float ph = u_phi[j] * phi_range;
+  const float ct = cosf(th), st = sinf(th), cp = cosf(ph), sp = sinf(ph);
+  V3 d = v3(U.x * ct * sp + V.x * st * sp + refl.x * cp, U.y * ct * sp + V.y * st * sp + refl.y * cp,
+            U.z * ct * sp + V.z * st * sp + refl.z * cp);
+  dirs[3 * j] = d.x;
+  dirs[3 * j + 1] = d.y;
+  dirs[3 * j + 2] = d.z;
+  front[j] = dot3(nn, d) > RB_TINY ? 1 : 0;
+  wts[j] = expf(s * (dot3(d, wl) - 1.f));
+}
+
 // per point: weighted mean of the sampled visibilities (sg_render.py:269-294)
 __global__ void k_spec_reduce(const float* __restrict__ logits, const unsigned char* __restrict__ front,
                               const float* __restrict__ wts, long n, int nsamp, int inv, int argmax_vis, int testing,
@@ -372,6 +414,20 @@ int rb_spec_vis_sample(const float* normal, const float* view, const float* roug
   hipLaunchKernelGGL(k_spec_dirs, grid1d(n * nsamp, 256), dim3(256), 0, s, normal, view, sharp, chunk_id, chunk_min,
                      u_theta, u_phi, n, nsamp, dirs, wts, front);
   return check_launch("k_spec_dirs");
+}
+
+int rb_spec_vis_sample_lobes(const float* normal, const float* view, const float* lobes, const float* lambdas, const int* chunk_id,
+                             long n, int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
+                             unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream) {
+  if (n <= 0) return 0;
+  RB_REQUIRE(normal && view && lobes && lambdas && u_theta && u_phi && sharp && chunk_min && dirs && wts && front, "null pointer");
+  RB_REQUIRE(n_chunks >= 1 && nsamp >= 1, "bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_u32, grid1d(n_chunks, 256), dim3(256), 0, s, chunk_min, (long)n_chunks, 0x7f800000u);
+  hipLaunchKernelGGL(k_spec_sharp_lobes, grid1d(n, 256), dim3(256), 0, s, lambdas, chunk_id, n, sharp, chunk_min);
+  hipLaunchKernelGGL(k_spec_dirs_lobes, grid1d(n * nsamp, 256), dim3(256), 0, s, normal, view, lobes, sharp, chunk_id, chunk_min,
+                     u_theta, u_phi, n, nsamp, dirs, wts, front);
+  return check_launch("k_spec_dirs_lobes");
 }
 
 int rb_spec_vis_reduce(const float* logits, const unsigned char* front, const float* wts, long n, int nsamp, int inv,

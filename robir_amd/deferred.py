@@ -18,8 +18,12 @@ IDRNetwork.render_chunks run at the bench rate.  With `model.deferred_chunks = N
 What a recorded pass computes is exactly IDRNetwork._render on the concatenated chunks, i.e. what render_chunks returns for them
 (every chunk keeps its own lock-step trace, its own sample tables and its own specular minimum).  Differences from immediate
 execution, all stated in INTEGRATION.md: random numbers are drawn when the pass runs, starting from the generator state at the
-time of its first recorded chunk; weights must not change while chunks are pending (checked: RuntimeError); train(), eval(),
-load_light() and flush() run what is pending.
+time of its first recorded chunk -- a caller that re-seeds or draws BETWEEN two chunk forwards is detected at the next forward()
+(the generator no longer is in the state the pass was recorded under): the pending chunks then run from their own state, the new
+chunk runs at once, i.e. such a loop gets immediate-execution results chunk for chunk (tests/test_deferred_gpu.py); weights must not
+change in place while chunks are pending (checked: RuntimeError); train(), eval(), load_state_dict(), load_light() and flush() run
+what is pending.  A pass holds the outputs of up to `deferred_chunks` chunks (128 x 1024 rays x 240 B = 31 MB) plus the pass's scratch
+(the direction tables of its chunks, 4.2 MB each: 0.5 GB for 128) -- sized for a 288 GB part, set ROBIR_DEFER_CHUNKS lower elsewhere.
 """
 import os
 import weakref
@@ -220,6 +224,9 @@ class ChunkQueue:
         self.versions = _versions(model)
         gen = torch.cuda.default_generators[device.index or 0] if device.type == "cuda" else torch.default_generator
         self.gen, self.gen_state = gen, gen.get_state()
+        # recorded trace_radiance calls on this pass's chunks (slot -> nsamp; IDRNetwork.trace_radiance): they run behind the pass as ONE
+        # grouped call, every chunk its own lock-step batch, the CPU generator's draws taken chunk by chunk in slot order
+        self.trace, self.trace_nsamp, self.cpu_state, self.trace_result = {}, None, None, None
         _LIVE.add(self)
 
     def add(self, uv, mask, hdr):
@@ -259,10 +266,64 @@ class ChunkQueue:
                 self.gen.set_state(now)
         finally:
             self.running = False
+        hdr_rows = self.hdr[:self.rays] if self.hdr is not None else None
         self.uv = self.mask = self.hdr = None
         keys = set(self.result) - {"object_mask", "hdr_shift"}
         if keys != set(self.spec):
             raise RuntimeError(f"deferred pass returned {sorted(keys ^ set(self.spec))} unexpectedly")
+        if self.trace:
+            self._run_traces(model, hdr_rows)
+
+    # ------------------------------------------------------------------ recorded trace_radiance calls
+    def record_trace(self, slot, nsamp):
+        """IDRNetwork.trace_radiance on the (unmodified) outputs of recorded chunk `slot` with default arguments: recorded, to run behind
+        the pass with every chunk its own lock-step batch.  None = cannot be recorded (the pass has run; another nsamp; a second trace of
+        the same chunk; the caller drew from the CPU generator since the first recorded trace): the caller runs it at once."""
+        if self.result is not None or self.running or slot in self.trace or self.hdr is None:
+            return None
+        if self.trace and (nsamp != self.trace_nsamp or not torch.equal(torch.default_generator.get_state(), self.cpu_state)):
+            return None
+        if not self.trace:
+            self.trace_nsamp, self.cpu_state = int(nsamp), torch.default_generator.get_state()
+        self.trace[slot] = int(nsamp)
+        return TraceOutputs(self, slot, self.slots[slot][1], int(nsamp))
+
+    def _run_traces(self, model, hdr_rows):
+        """One grouped trace_radiance over the traced chunks of the pass that has just run.  Draws: the reference's trace_radiance takes
+        two torch.rand(n_hit * nsamp) from the CPU generator per call (implicit_differentiable_renderer.py:583-589) -- drawn here chunk by
+        chunk in slot order from the generator state of the first recorded trace, i.e. the numbers the immediate per-chunk calls draw."""
+        slots = sorted(self.trace)
+        res, ns = self.result, self.trace_nsamp
+        whole = slots == list(range(len(self.slots)))
+        rows = None if whole else torch.cat([torch.arange(a, a + n, device=res["points"].device) for a, n in (self.slots[k] for k in slots)])
+        pick = (lambda t: t) if whole else (lambda t: t.index_select(0, rows))
+        inp = {"points": pick(res["points"]), "hdr_shift": pick(hdr_rows), "network_object_mask": pick(res["network_object_mask"]),
+               "normals": pick(res["normals"])}
+        hits = inp["network_object_mask"]
+        sizes = [self.slots[k][1] for k in slots]
+        counts = [int(c) for c in torch.stack([h.sum() for h in hits.split(sizes)]).cpu()]       # one host read per pass
+        now = torch.default_generator.get_state()
+        untouched = torch.equal(now, self.cpu_state)
+        torch.default_generator.set_state(self.cpu_state)
+        u1, u2 = [], []
+        for c in counts:                             # torch.rand(n * nsamp) twice per chunk, in the reference's order
+            u1.append(torch.rand(c * ns))
+            u2.append(torch.rand(c * ns))
+        if not untouched:
+            torch.default_generator.set_state(now)
+        dev = res["points"].device
+        out = model.trace_radiance(inp, nsamp=ns, draws=(torch.cat(u1).to(dev), torch.cat(u2).to(dev)), chunk=self.chunk)
+        row0, hit0, acc_r, acc_h = {}, {}, 0, 0
+        for k, n, c in zip(slots, sizes, counts):
+            row0[k], hit0[k] = (acc_r, n), (acc_h, c)
+            acc_r, acc_h = acc_r + n, acc_h + c
+        self.trace_result = (out, row0, hit0)
+
+    def get_trace(self, slot, name):
+        self.flush()
+        out, row0, hit0 = self.trace_result
+        a, n = hit0[slot] if name == "sample_dirs" else row0[slot]
+        return out[name][a:a + n]
 
     def get(self, slot, name):
         self.flush()
@@ -283,6 +344,23 @@ class ChunkOutputs(dict):
     def __init__(self, queue, slot, n, device, given):
         super().__init__(given)
         self._q, self._slot, self._n, self._dev = queue, slot, n, device
+        self._dirty = False                # the caller replaced / removed an entry: no longer "the outputs of the recorded chunk"
+
+    def __setitem__(self, k, v):
+        self._dirty = True
+        dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._dirty = True
+        dict.__delitem__(self, k)
+
+    def update(self, *a, **k):
+        self._dirty = True
+        dict.update(self, *a, **k)
+
+    def pop(self, *a):
+        self._dirty = True
+        return dict.pop(self, *a)
 
     def __missing__(self, k):
         q = self._q
@@ -293,7 +371,7 @@ class ChunkOutputs(dict):
                 else torch.empty((self._n,) + s[0], dtype=s[1], device="meta"))
         slot = self._slot
         t = DeferredTensor(meta, self._dev, lambda: q.get(slot, k))
-        self[k] = t
+        dict.__setitem__(self, k, t)
         return t
 
     def _fill(self):
@@ -340,5 +418,62 @@ class ChunkOutputs(dict):
     def __eq__(self, other):
         self._fill()
         return dict.__eq__(self, other)
+
+    __hash__ = None
+
+
+class TraceOutputs(dict):
+    """What a RECORDED trace_radiance returns (IDRNetwork.trace_radiance on the outputs of a recorded chunk): placeholders for the five
+    per-ray results; `sample_dirs` has one row per HIT ray (a data-dependent shape), so reading it runs the pass."""
+
+    _SPEC = {"trace_radiance": (lambda n, s: (n, s, 3), torch.float32), "gt_vis": (lambda n, s: (n, s, 1), torch.bool),
+             "pred_vis": (lambda n, s: (n, s, 2), torch.float32), "indir_mask": (lambda n, s: (n, s), torch.bool),
+             "gt_integral": (lambda n, s: (n, 3), torch.float32)}
+    _KEYS = ("trace_radiance", "sample_dirs", "gt_vis", "pred_vis", "indir_mask", "gt_integral")
+
+    def __init__(self, queue, slot, n, nsamp):
+        super().__init__()
+        self._q, self._slot, self._n, self._ns = queue, slot, n, nsamp
+
+    def __missing__(self, k):
+        q, slot = self._q, self._slot
+        if k == "sample_dirs":
+            t = q.get_trace(slot, k)
+        elif k in self._SPEC:
+            shape, dt = self._SPEC[k]
+            t = DeferredTensor(torch.empty(shape(self._n, self._ns), dtype=dt, device="meta"), q.pose.device, lambda: q.get_trace(slot, k))
+        else:
+            raise KeyError(k)
+        dict.__setitem__(self, k, t)
+        return t
+
+    def _fill(self):
+        for k in self._KEYS:
+            if not dict.__contains__(self, k):
+                self.__missing__(k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self._KEYS else default
+
+    def __contains__(self, k):
+        return k in self._KEYS
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
 
     __hash__ = None

@@ -533,14 +533,21 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
     if precision == "f16x3-auto":
         # same arithmetic, bit-identical results: the streaming family balances small launches (a single 1024-pixel chunk) over
         # the CUs; at whole-view sizes the one-point-per-workgroup kernel is as fast and needs no scratch
-        precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x3-v2"
+        # (the tile-list forms cut a point's L*nsamp directions into whole 16-sample tiles: other shapes take the per-point kernel)
+        precision = "f16x3-v3" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS and (L * nsamp) % 16 == 0 else "f16x3-v2"
     h3 = precision.startswith("f16x3")
     X6 = ("f16x6", "f16x6-1t", "f16x6-pt", "f16x6-stream")
     assert h3 or precision in ("fp32", "f16x1") or precision in X6, precision
     if precision == "f16x6":
         # "auto": the persistent tile-list form for launches up to DVIS_STREAM_MAX_POINTS points (a single 1024-pixel chunk: balanced
         # over the CUs, 0.4 % tile padding), one workgroup per point beyond (no scratch); the two are bit-identical
-        precision = DVIS_X6_FORM if DVIS_X6_FORM != "auto" else ("f16x6-stream" if normals.shape[0] <= DVIS_STREAM_MAX_POINTS else "f16x6-pt")
+        # (same bits); a light whose L*nsamp is not a multiple of 16 (odd lobe counts with nsamp = 8) cannot be cut into whole tiles of
+        # the global list and takes the per-point form at every size
+        stream_ok = normals.shape[0] <= DVIS_STREAM_MAX_POINTS and (L * nsamp) % 16 == 0
+        precision = DVIS_X6_FORM if DVIS_X6_FORM != "auto" else ("f16x6-stream" if stream_ok else "f16x6-pt")
+    if precision == "f16x1" and (L * nsamp) % 16 != 0:
+        raise ValueError(f"the f16 throughput kernel (ROBIR_PRECISION=f16) exists in the tile-list form only: L*nsamp = {L}*{nsamp} must be a "
+                         "multiple of 16 -- use ROBIR_PRECISION=exact for this light")
     # "f16x3-v2" = second-generation split-precision kernel: two tiles per wave, one workgroup per CU, head on the matrix
     # pipe (csrc/vis_diffuse_v2.hip); "f16x3" = first generation: one 16-sample tile per wave, two workgroups per CU,
     # weights staged by LDS-DMA; "f16x6*" = exact three-piece operands: "-1t" round 3's one tile per wave, one workgroup per point
@@ -594,6 +601,23 @@ def spec_vis_sample(normal, view, rough, chunk_id, n_chunks, u_theta, u_phi):
     wts = torch.empty(n * ns, dtype=torch.float32, device=dev)
     front = torch.empty(n * ns, dtype=torch.uint8, device=dev)
     call("rb_spec_vis_sample", ptr(normal), ptr(view), ptr(rough), ptr(chunk_id), c_long(n), c_int(n_chunks), c_int(ns),
+         ptr(u_theta), ptr(u_phi), ptr(sharp), ptr(cmin), ptr(dirs), ptr(wts), ptr(front), stream_ptr())
+    return dirs, wts, front
+
+
+def spec_vis_sample_lobes(normal, view, lobes, lambdas, chunk_id, n_chunks, u_theta, u_phi):
+    """spec_vis_sample for a caller's own lobes [n,3] / lambdas [n] (the reference's get_specular_visibility signature)."""
+    normal, view, lobes, lambdas = _f32(normal), _f32(view), _f32(lobes), _f32(lambdas).reshape(-1)
+    u_theta, u_phi = _f32(u_theta), _f32(u_phi)
+    n, ns = u_theta.shape
+    assert lobes.shape == (n, 3) and lambdas.shape == (n,), (lobes.shape, lambdas.shape)
+    dev = normal.device
+    sharp = torch.empty(n, dtype=torch.float32, device=dev)
+    cmin = torch.empty(n_chunks, dtype=torch.int32, device=dev)
+    dirs = torch.empty(n * ns, 3, dtype=torch.float32, device=dev)
+    wts = torch.empty(n * ns, dtype=torch.float32, device=dev)
+    front = torch.empty(n * ns, dtype=torch.uint8, device=dev)
+    call("rb_spec_vis_sample_lobes", ptr(normal), ptr(view), ptr(lobes), ptr(lambdas), ptr(chunk_id), c_long(n), c_int(n_chunks), c_int(ns),
          ptr(u_theta), ptr(u_phi), ptr(sharp), ptr(cmin), ptr(dirs), ptr(wts), ptr(front), stream_ptr())
     return dirs, wts, front
 
@@ -667,6 +691,7 @@ def octree_cast_batched(T, origins, per_ray_origin, dirs, batch, max_iter, step,
 
 
 CAST_ONE_LAUNCH = _os.environ.get("ROBIR_CAST_ONE_LAUNCH", "1") == "1"    # the persistent-grid form of the general lock-step cast
+CAST_COOP_REFUSED = 0              # how often the cooperative launch was refused and the per-iteration launches took over
 CAST_ONE_LAUNCH_MAX_RAYS = 16384   # above this the per-iteration launches fill the chip and win (tools/ab_cast.py: 60 k rays 1.3 vs 2.1 ms)
 
 
@@ -686,11 +711,19 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
         x = torch.empty(R, 3, dtype=torch.float32, device=dev)
         hit = torch.empty(R, dtype=torch.uint8, device=dev)
         t_out = torch.empty(R, dtype=torch.float32, device=dev)
+        rc = 0
         if R > 0:
-            call("rb_octree_cast_coop", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step), c_int(max_total),
-                 c_float(T.clamp_dt), ptr(t), ptr(leaf), ptr(active), ptr(counters), ptr(arrive), ptr(x), ptr(hit), ptr(t_out),
-                 stream_ptr())
-        return x, hit.bool(), t_out, counters
+            # status 2: the cooperative launch was refused (the grid could not be co-resident: a side stream or another rank holds
+            # compute units) and nothing ran -- the per-iteration launches below give the same bits
+            rc = _lib.lib().rb_octree_cast_coop(*a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step),
+                                                c_int(max_total), c_float(T.clamp_dt), ptr(t), ptr(leaf), ptr(active), ptr(counters),
+                                                ptr(arrive), ptr(x), ptr(hit), ptr(t_out), stream_ptr())
+            if rc not in (0, 2):
+                raise _lib.RobirHipError(f"rb_octree_cast_coop failed ({rc}): {_lib.lib().rb_last_error().decode()}")
+        if rc == 0:
+            return x, hit.bool(), t_out, counters
+        global CAST_COOP_REFUSED
+        CAST_COOP_REFUSED += 1
     counters = torch.zeros(max_total + 2, dtype=torch.int32, device=dev)
     call("rb_octree_cast_init", *a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ptr(t), ptr(leaf), ptr(active),
          ptr(counters), stream_ptr())

@@ -114,7 +114,9 @@ class IDRNetwork(nn.Module):
         limit = self.__dict__.get("deferred_chunks", deferred.DEFAULT_CHUNKS)
         if (limit and not self.training and chunk == N and N <= 1024 and self.use_octree and draws is None and stats is None
                 and input.get("albedo_ratio") is None and self._tex_uv is None and not fun_spec):
-            return self._record_chunk(input, N, int(limit), trainstage, fun_spec, lin_diff)
+            rec = self._record_chunk(input, N, int(limit), trainstage, fun_spec, lin_diff)
+            if rec is not None:
+                return rec
         self.flush()
         return self._render(uv[0], pose[0], K[0], input["object_mask"].reshape(-1), input.get("hdr_shift"), chunk,
                             trainstage, fun_spec, lin_diff, draws, stats, input.get("albedo_ratio"))
@@ -125,6 +127,18 @@ class IDRNetwork(nn.Module):
         mask = input["object_mask"].reshape(-1)
         hook = self.get_sg_render
         q = self.__dict__.get("_pending")
+        if q is not None and not torch.equal(q.gen.get_state(), q.gen_state):
+            # The caller re-seeded or drew random numbers since the pending pass recorded its first chunk: it manages the generator per
+            # chunk, and a pass would draw this chunk's numbers from the wrong state.  Run what is pending -- from the state
+            # its chunks were recorded under, q.flush() then puts the caller's state back -- and run THIS chunk at once: both are exactly
+            # what immediate execution gives.  (None: forward() falls through to the immediate path.)
+            q.flush()
+            return None
+        if q is not None and q.closed:
+            # full, or ended by a short chunk: it runs when the NEXT chunk arrives (or at the first read) -- not at its own last forward(),
+            # so that a trace_radiance call on that last chunk can still join the pass
+            q.flush()
+            q = None
         if q is not None:
             psrc, ksrc = q.sig[-2:]
             same = (not q.closed and N <= q.chunk and q.sig[:6] == (trainstage, fun_spec, lin_diff, hdr is None, uv.device, hook)
@@ -147,10 +161,7 @@ class IDRNetwork(nn.Module):
         given = {"object_mask": mask}
         if hdr is not None:
             given["hdr_shift"] = hdr
-        out = deferred.ChunkOutputs(q, slot, N, uv.device, given)
-        if q.closed:                       # full (or ended by a short chunk): run it now, the next chunk starts a new pass
-            q.flush()
-        return out
+        return deferred.ChunkOutputs(q, slot, N, uv.device, given)
 
     def flush(self):
         """Run the recorded chunk forwards, if any (deferred_chunks > 0)."""
@@ -161,6 +172,10 @@ class IDRNetwork(nn.Module):
     def train(self, mode=True):
         deferred.flush_all()
         return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        deferred.flush_all()          # recorded chunk forwards were meant for the weights that are replaced now
+        return super().load_state_dict(*args, **kwargs)
 
     def render_chunks(self, uv, pose, K, hdr_shift, chunk=1024, trainstage="Material", draws=None, stats=None):
         """uv [N,2] for any number of consecutive `chunk`-pixel chunks (chunk <= 1024); pose [4,4], K [3,3];
@@ -350,6 +365,13 @@ class IDRNetwork(nn.Module):
         calling trace_radiance once per 1024-pixel chunk (training/train_visibility.py); without it the call is ONE batch, like
         one reference call."""
         forward_only_guard(self)
+        if (isinstance(input, deferred.ChunkOutputs) and not input._dirty and test_dir is None and draws is None and chunk is None):
+            # the outputs of a RECORDED chunk forward, default arguments (the runners' per-chunk `trace_radiance(out, nsamp=8)`,
+            # training/train_cesr.py:321-326, train_visibility.py): recorded as well -- it runs behind the pass as one grouped call, every
+            # chunk its own lock-step batch, with the draws the per-chunk calls would take (robir_amd/deferred.py)
+            rec = input._q.record_trace(input._slot, nsamp)
+            if rec is not None:
+                return rec
         points, shift, mask = input["points"], input["hdr_shift"], input["network_object_mask"]
         dev = points.device
         N = points.shape[0]

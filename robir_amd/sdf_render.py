@@ -2,7 +2,8 @@
 NormalTrainRunner.get_neus_surface (training/train_normal.py:239-286) on the HIP kernels.
 
 render_neus(rays, model, cos_anneal_ratio, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, ...)
-supports the configuration every shipped config uses: n_outside = 0, is_eval / perturb = 0, lindisp = False.
+supports n_outside = 0 (every stage-2 caller), lindisp = False, and both sampling modes: is_eval / perturb = 0 (deterministic) and
+perturb > 0 (the default of the only stage-2 caller, wrap_renderer, :397-399: one torch.rand([R,1]) shift per ray; `t_rand=` pins it).
 `model` is robir_amd.nets.NeuSModel (sdf / sdf+feat+gradient / colour run on the MFMA kernels)."""
 import collections
 import ctypes
@@ -22,7 +23,7 @@ def _f(t):
 
 
 def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4,
-                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, stage1_alpha=False, need_grad_error=True):
+                white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, stage1_alpha=False, need_grad_error=True, *, t_rand=None):
     """model/sdf_render.py:263-374 (stage 2; `cos_anneal_ratio` is ignored there).  stage1_alpha=True renders with the
     stage-1 render_core instead (neus/volume_render/sdf_render.py:172-190: alpha from the cos-annealed half-section
     extrapolation of the SDF), i.e. what NeuS stage-1 checkpoints were trained against; see render_neus_stage1.
@@ -32,8 +33,10 @@ def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64
     colour are evaluated only for samples whose weight is not exactly zero -- rgb / dist / acc / grad / weights are bit-identical
     (0 * colour adds nothing), `grad_error` is NaN.  Pays off for trained sharpness (inv_s in the hundreds: the transmittance
     underflows to 0 a few samples behind the surface); costs one sync to size the compacted batch."""
-    if n_outside != 0 or lindisp or not (is_eval or perturb == 0):
-        raise NotImplementedError("HIP render_neus: n_outside=0, lindisp=False, is_eval=True (deterministic sampling)")
+    if is_eval:
+        perturb = 0                                                      # sdf_render.py:273-274
+    if n_outside != 0 or lindisp:
+        raise NotImplementedError("HIP render_neus: n_outside=0 (no NeRF++ background), lindisp=False")
     o, d = _f(rays.origins), _f(rays.directions)
     near, far = _f(rays.near).reshape(-1), _f(rays.far).reshape(-1)
     R, dev = o.shape[0], o.device
@@ -45,6 +48,12 @@ def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64
     lin = torch.linspace(0.0, 1.0, n_samples).to(dev)
     z = torch.empty(R, n_samples, device=dev)
     call("rb_neus_coarse_z", ptr(near), ptr(far), ptr(lin), c_long(R), c_int(n_samples), ptr(z), S())
+    if perturb > 0:
+        # sdf_render.py:293-295: t_rand = torch.rand([R,1]) - 0.5; z_vals += t_rand * 2.0 / n_samples.  `t_rand=` (keyword-only, not in
+        # the reference) is that uniform draw [R,1] BEFORE the -0.5, for callers that replay recorded draws
+        u = _f(torch.rand([R, 1], device=dev) if t_rand is None else t_rand.to(dev)).reshape(-1)
+        assert u.shape[0] == R, (u.shape, R)
+        call("rb_neus_jitter_z", ptr(u), c_long(R), c_int(n_samples), ptr(z), S())
 
     def points(zz, want_dirs=False):
         n = zz.shape[1]
@@ -114,11 +123,11 @@ def render_neus(rays, model, cos_anneal_ratio=1.0, n_samples=64, n_importance=64
 
 
 def render_neus_stage1(rays, model, cos_anneal_ratio, n_samples=64, n_importance=64, n_outside=32, up_sample_steps=4,
-                       white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False):
+                       white_bkgd=True, lindisp=False, perturb=1.0, is_eval=False, *, t_rand=None):
     """neus/volume_render/sdf_render.py:238-365 (stage-1 `render_neus`; n_outside must be passed as 0 like every stage-2
     caller does -- the NeRF++ background is out of scope)."""
     return render_neus(rays, model, cos_anneal_ratio, n_samples, n_importance, n_outside, up_sample_steps, white_bkgd,
-                       lindisp, perturb, is_eval, stage1_alpha=True)
+                       lindisp, perturb, is_eval, stage1_alpha=True, t_rand=t_rand)
 
 
 def get_neus_surface(implicit_network, points, view_dirs, pred_normals, n_samp=32, dist=0.05):

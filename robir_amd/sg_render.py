@@ -186,10 +186,15 @@ def _diffuse_vis_generic(points, normals, VisModel, dirs, wdir, wsum, cid, C, L,
     return (vis.reshape(n, L, nsamp) * w).sum(-1) / wsum.reshape(C, L)[c]
 
 
-def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, cid, C):
-    """-> bvis [n] for the warped BRDF lobe of each point (lobe/lambda are recomputed from normal, view, roughness)."""
+def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, cid, C, lobes=None,
+                       lambdas=None):
+    """-> bvis [n] for the warped BRDF lobe of each point: recomputed on the device from (normal, view, roughness) -- render_with_sg's
+    own chain --, or the caller's lobes [n,3] / lambdas [n] when those are given (get_specular_visibility's reference signature)."""
     n, nsamp = u_t.shape
-    dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
+    if lobes is not None:
+        dirs, wts, front = ops.spec_vis_sample_lobes(normals, viewdirs, lobes, lambdas, cid, C, u_t, u_p)
+    else:
+        dirs, wts, front = ops.spec_vis_sample(normals, viewdirs, roughness, cid, C, u_t, u_p)
     if isinstance(VisModel, VisNetwork):
         logits = VisModel.logits_from_points(points.float().contiguous(), dirs, rep=nsamp)
     elif isinstance(VisModel, OctreeVisModel) and cid is not None and C > 1:
@@ -204,25 +209,38 @@ def _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p,
 
 def get_specular_visibility(points, normals, viewdirs, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=24, multi_view=False,
                             testing=False, inv=False, argmax_vis=False, *, roughness=None, draws=None):
-    """sg_render.py:198-301 (single view, or multi_view=True with viewdirs [V,n,3]).  The HIP path derives the warped lobe from (normal, view,
-    roughness), so callers outside render_with_sg must pass `roughness`."""
-    if roughness is None:
-        raise NotImplementedError("pass roughness= (the warped BRDF lobe is recomputed on the device)")
+    """sg_render.py:198-301 with the reference's own signature: the cone around the reflected view direction opens by the PASSED
+    lgtSGLambdas ([n,1] | [n]: clip 0.1..50, batch-global minimum, :219-223) and the samples are weighted by the PASSED lgtSGLobes
+    [n,3] as they are (:281) -- single view, or multi_view=True with viewdirs / lobes / lambdas [V,n,.] (:227-231, 247-258).
+    `roughness=` (keyword-only, not in the reference) is the path render_with_sg itself takes: lobe and lambda are then recomputed on
+    the device from (normal, view, roughness) and the passed ones are not read (they may be None).  `draws=(u_theta, u_phi)` [n,nsamp]
+    pins the two torch.rand draws (:224-225)."""
     n = points.shape[0]
+    dev = points.device
+    f = lambda t: t.to(dev).float().contiguous()
+    if roughness is None and (lgtSGLobes is None or lgtSGLambdas is None):
+        raise ValueError("get_specular_visibility needs lgtSGLobes / lgtSGLambdas (the reference's arguments) or roughness=")
+    if draws is None:
+        u_t, u_p = _rand((n, nsamp), dev), _rand((n, nsamp), dev)
+    else:
+        u_t, u_p = f(draws[0]), f(draws[1])
     if multi_view:
         # viewdirs [V,n,3] -> [V,n]: one batch of V n rows, the draws [n,nsamp] shared by the views, always the arg-max of the logits
         # (sg_render.py:227-231, 247-258: inv / argmax_vis are not read in this branch)
         V = viewdirs.shape[0]
-        if draws is None:
-            draws = _rand((n, nsamp), points.device), _rand((n, nsamp), points.device)
-        return _specular_vis_core(points.float().repeat(V, 1), normals.float().repeat(V, 1), viewdirs.float().reshape(V * n, 3).contiguous(),
-                                  VisModel, roughness.float().reshape(-1).repeat(V), draws[0].repeat(V, 1), draws[1].repeat(V, 1), testing,
-                                  False, True, None, 1).reshape(V, n)
-    if draws is None:
-        u_t, u_p = _rand((n, nsamp), points.device), _rand((n, nsamp), points.device)
-    else:
-        u_t, u_p = draws
-    return _specular_vis_core(points, normals, viewdirs, VisModel, roughness, u_t, u_p, testing, inv, argmax_vis, None, 1)
+        args = (f(points).repeat(V, 1), f(normals).repeat(V, 1), f(viewdirs).reshape(V * n, 3).contiguous(), VisModel)
+        if roughness is not None:
+            return _specular_vis_core(*args, f(roughness).reshape(-1).repeat(V), u_t.repeat(V, 1), u_p.repeat(V, 1), testing, False, True,
+                                      None, 1).reshape(V, n)
+        lob = f(lgtSGLobes).expand(V, n, 3).reshape(V * n, 3).contiguous()
+        lam = f(lgtSGLambdas).reshape(-1, n).expand(V, n).reshape(V * n).contiguous()
+        return _specular_vis_core(*args, None, u_t.repeat(V, 1), u_p.repeat(V, 1), testing, False, True, None, 1, lobes=lob,
+                                  lambdas=lam).reshape(V, n)
+    if roughness is not None:
+        return _specular_vis_core(f(points), f(normals), f(viewdirs), VisModel, f(roughness).reshape(-1), u_t, u_p, testing, inv, argmax_vis,
+                                  None, 1)
+    return _specular_vis_core(f(points), f(normals), f(viewdirs), VisModel, None, u_t, u_p, testing, inv, argmax_vis, None, 1,
+                              lobes=f(lgtSGLobes).reshape(n, 3), lambdas=f(lgtSGLambdas).reshape(n))
 
 
 def _kl_divergence(x, mu):

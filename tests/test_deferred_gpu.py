@@ -170,7 +170,7 @@ def test_short_last_chunk_stage_change_and_limit(dev, deferring):
     for s in split:
         s["hdr_shift"] = hdr(s)
         outs.append(model(s, trainstage="Material"))
-    assert model.__dict__.get("_pending") is None        # the short chunk closed the pass and ran it
+    assert model._pending.closed and model._pending.result is None   # the short chunk closed the pass; it runs at the first read (or the next chunk)
     albedo = torch.cat([o["diffuse_albedo"] for o in outs]).cpu()
     torch.manual_seed(9)
     ref = model.render_chunks(mi["uv"][0], mi["pose"][0], mi["intrinsics"][0], torch.full((total, 1), 0.5, device=dev))
@@ -220,3 +220,112 @@ def test_pending_chunks_and_changed_weights(dev, deferring):
     torch.manual_seed(77)
     assert torch.equal(torch.rand(4, device=dev), w1)
     assert bool(torch.isfinite(v1).all())
+
+
+def test_reseeding_per_chunk_under_default_settings_gives_immediate_results(dev, model):
+    """deferral is ON by default (ROBIR_DEFER_CHUNKS = 128) and draws a pass's random numbers from the generator state at its
+    first recorded chunk -- a caller that re-seeds before EVERY chunk forward (tests/test_runner_hooks_gpu.py does, to replay a run) must
+    still get, chunk for chunk, what immediate execution gives under those seeds.  forward() notices that the generator left the state the
+    pending pass was recorded under, runs the pending chunks from their own state and the new chunk at once.  Also: load_state_dict() while
+    chunks are pending runs them first (with the OLD weights) instead of raising at the next read."""
+    from robir_amd import deferred
+    model.__dict__.pop("deferred_chunks", None)            # the DEFAULT, whatever ROBIR_DEFER_CHUNKS says (0 in an A/B run: nothing to test)
+    if not deferred.DEFAULT_CHUNKS:
+        pytest.skip("ROBIR_DEFER_CHUNKS=0 in this environment")
+    mi, total = _view(dev, 64, 64)
+    split = split_input(mi, total)
+    for s in split:
+        s["hdr_shift"] = torch.full((1024, 1), 0.5, device=dev)
+    keys = ("sg_rgb", "indir_rgb", "vis_shadow", "diffuse_albedo", "network_object_mask")
+    lazy = []
+    for i, s in enumerate(split):
+        torch.manual_seed(100 + i)                         # the caller's per-chunk seed
+        lazy.append(model(s, trainstage="Material"))
+    got = [{k: o[k].cpu() for k in keys} for o in lazy]
+    model.flush()
+    model.deferred_chunks = 0
+    try:
+        for i, s in enumerate(split):
+            torch.manual_seed(100 + i)
+            now = model(s, trainstage="Material")
+            for k in keys:
+                assert _same(got[i][k], now[k]), (i, k)
+        # a loop that does NOT touch the generator is still recorded as one pass (the point of the default) ...
+        model.__dict__.pop("deferred_chunks", None)
+        torch.manual_seed(5)
+        outs = [model(s, trainstage="Material") for s in split]
+        assert all(o._q is outs[0]._q for o in outs) and outs[0]._q.result is None
+        # ... and replacing the weights runs it first, with the weights it was recorded for
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(sd)
+        assert outs[0]._q.result is not None and model.__dict__.get("_pending") is None
+        torch.manual_seed(5)
+        ref = model.render_chunks(mi["uv"][0], mi["pose"][0], mi["intrinsics"][0], torch.full((total, 1), 0.5, device=dev))
+        assert _same(torch.cat([o["sg_rgb"] for o in outs]), ref["sg_rgb"])
+    finally:
+        model.flush()
+        model.__dict__.pop("deferred_chunks", None)
+
+
+@pytest.mark.parametrize("stage", ["Material", "Illum"])
+def test_recorded_trace_radiance_per_chunk_equals_the_immediate_calls(dev, deferring, stage):
+    """The CESR / visibility runners call `trace_radiance(out, nsamp=8)` right after every chunk forward and only reduce its results
+    (training/train_cesr.py:321-326: max / mean of pred_vis).  On the outputs of a RECORDED chunk the call is recorded too and runs behind
+    the pass as ONE grouped call: every chunk its own lock-step batch (the > 100 000-ray step size must not kick in), the two
+    torch.rand(n_hit * nsamp) of every call taken from the CPU generator chunk by chunk.  Equal to render_chunks + one immediate
+    trace_radiance per chunk under the same seed -- directions, hit masks and predicted visibilities bit for bit, the borrowed radiance to
+    fp32 summation order; a short last chunk and the chunk that fills the pass included."""
+    model = deferring
+    model.deferred_chunks = 4
+    mi, total = _view(dev, 72, 100)              # 7 full chunks + 32 rays: passes of 4 + 4 (the second ended by the short chunk)
+    split = split_input(mi, total)
+    hdr_all = torch.full((total, 1), 0.5, device=dev)
+    for i, s in enumerate(split):
+        s["hdr_shift"] = hdr_all[i * 1024:(i + 1) * 1024]
+    torch.manual_seed(21)
+    red, outs, trs = [], [], []
+    for s in split:
+        out = model(s, trainstage=stage)
+        tr = model.trace_radiance(out, nsamp=8)
+        assert isinstance(tr, dict) and "pred_vis" in tr and len(tr) == 6
+        _, pv = torch.max(tr["pred_vis"].detach(), dim=-1)
+        red.append(torch.mean(pv.float(), axis=1))       # the runner's reduction: still a placeholder
+        outs.append(out)
+        trs.append(tr)
+    q_first, q_last = outs[0]._q, outs[-1]._q
+    assert q_first is not q_last and q_first.result is not None and q_last.result is None and len(q_last.trace) == 4
+    got_red = torch.cat(red).cpu()                       # first read: runs the second pass and its four traces
+    got = {k: torch.cat([t[k] for t in trs]).cpu() for k in ("trace_radiance", "gt_vis", "pred_vis", "indir_mask", "gt_integral", "sample_dirs")}
+    model.flush()
+    model.deferred_chunks = 0
+    uv, pose, K = mi["uv"][0], mi["pose"][0], mi["intrinsics"][0]
+    ref = {k: [] for k in got}
+    torch.manual_seed(21)
+    for a, b in ((0, 4), (4, 8)):                        # the two passes: render_chunks draws like a recorded pass
+        lo, hi = a * 1024, min(b * 1024, total)
+        o = model.render_chunks(uv[lo:hi], pose, K, hdr_all[lo:hi], chunk=1024, trainstage=stage)
+        for c in range(a, b):
+            r0, r1 = c * 1024 - lo, min((c + 1) * 1024, total) - lo
+            one = {k: o[k][r0:r1] for k in ("points", "network_object_mask", "normals")}
+            one["hdr_shift"] = hdr_all[lo + r0:lo + r1]
+            t = model.trace_radiance(one, nsamp=8)       # immediate, ONE lock-step batch, its own two CPU draws
+            for k in ref:
+                ref[k].append(t[k])
+    for k in got:
+        r = torch.cat(ref[k]).cpu()
+        if k in ("trace_radiance", "gt_integral"):
+            # the borrowed colours go through the SDF / colour kernels, whose form (one or two tiles per wave, ops.sdf_two_tile) follows the
+            # batch size: a pass's grouped call and a chunk's own call agree to fp32 summation order, not always bit for bit (DESIGN 5.0)
+            assert got[k].shape == r.shape and float((got[k] - r).abs().max()) <= 5e-6 * max(1.0, float(r.abs().max())), k
+        else:
+            assert _same(got[k], r), k
+    _, pv = torch.max(torch.cat(ref["pred_vis"]), dim=-1)
+    assert _same(got_red, torch.mean(pv.float(), axis=1))
+    assert int(torch.cat(ref["gt_vis"]).sum()) > 0 or stage == "Material"
+    # a modified output dict, explicit draws or a test direction are not recorded
+    model.deferred_chunks = 4
+    out = model(split[0], trainstage=stage)
+    out["hdr_shift"] = hdr_all[:1024] * 1.0
+    tr = model.trace_radiance(out, nsamp=4)
+    assert not hasattr(tr, "_q") and tr["trace_radiance"].shape == (1024, 4, 3)
+    model.flush()

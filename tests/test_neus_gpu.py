@@ -39,6 +39,45 @@ def test_render_neus_golden(dev, synth_weights, tag):
     bounded("render_neus_%s/weights" % tag, out["weights"].cpu(), g["out_weights"], 5e-3, 0.01)
 
 
+def test_render_neus_perturb_golden(dev, synth_weights, oracle_sd):
+    """render_neus with perturb > 0 (model/sdf_render.py:293-295: one torch.rand([R,1]) shift of a ray's coarse samples) -- what the only
+    stage-2 caller wrap_renderer gets by default (:397-399: n_samples = n_importance = 32, two up-sampling steps, is_eval unset) --
+    against the reference's own output with the draw replayed (oracle/gen_golden_r5.py), and against the oracle on more rays."""
+    from robir_amd import sdf_render
+    from robir_oracle import neus as oneus
+    g = load_golden("render_neus_perturb")
+    model = _neus(dev, synth_weights, 0.3)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in g.items() if v.dtype.kind == "f" and v.ndim > 0}
+    rays = sdf_render.Rays(t["rays_o"], t["rays_d"], t["rays_d"], None, None, t["near"], t["far"])
+    kw = dict(n_samples=int(g["n_samples"]), n_importance=int(g["n_importance"]), n_outside=0, up_sample_steps=int(g["up_sample_steps"]))
+    out = sdf_render.render_neus(rays, model, 1.0, t_rand=t["t_rand"], **kw)                  # perturb = 1.0, is_eval = False: the defaults
+    for k, tol in (("rgb", 1e-4), ("dist", 1e-4), ("acc", 2e-4), ("grad", 2e-4), ("grad_error", 1e-4)):
+        e = rel_err(out[k].cpu(), g["out_" + k])
+        assert e <= tol, (k, e)
+    bounded("render_neus_perturb/weights", out["weights"].cpu(), g["out_weights"], 5e-3, 0.01)
+    # the shift is real: the deterministic render of the same rays has other sample positions
+    det = sdf_render.render_neus(rays, model, 1.0, is_eval=True, **kw)
+    assert rel_err(det["weights"].cpu(), g["out_weights"]) > 1e-2
+    # is_eval overrides perturb (:273-274), and without t_rand the draw comes from torch's generator: seeded twice -> the same image
+    assert torch.equal(sdf_render.render_neus(rays, model, 1.0, perturb=1.0, is_eval=True, **kw)["rgb"], det["rgb"])
+    torch.manual_seed(5)
+    a = sdf_render.render_neus(rays, model, 1.0, **kw)["rgb"]
+    torch.manual_seed(5)
+    assert torch.equal(a, sdf_render.render_neus(rays, model, 1.0, **kw)["rgb"]) and not torch.equal(a, det["rgb"])
+    # more rays against the oracle with its own draw
+    gen = torch.Generator().manual_seed(8)
+    R = 200
+    o = t["rays_o"][:1].cpu().expand(R, 3).contiguous()
+    d = torch.nn.functional.normalize(t["rays_d"].cpu().mean(0, keepdim=True) + 0.12 * torch.randn(R, 3, generator=gen), dim=-1)
+    near, far, tr = torch.full((R, 1), 0.8), torch.full((R, 1), 2.8), torch.rand(R, 1, generator=gen)
+    ref = oneus.render_neus(oracle_sd, o, d, near, far, n_samples=32, n_importance=32, up_sample_steps=2, t_rand=tr)
+    rays2 = sdf_render.Rays(o.to(dev), d.to(dev), d.to(dev), None, None, near.to(dev), far.to(dev))
+    out2 = sdf_render.render_neus(rays2, model, 1.0, t_rand=tr.to(dev), **kw)
+    for k, tol in (("rgb", 1e-4), ("dist", 1e-4), ("acc", 2e-4)):
+        assert bad_frac(out2[k].cpu(), ref[k], tol) <= 0.01, (k, bad_frac(out2[k].cpu(), ref[k], tol))
+        assert rel_err(out2[k].cpu(), ref[k]) <= 2e-3, (k, rel_err(out2[k].cpu(), ref[k]))
+
+
 @pytest.mark.parametrize("tag", ["c03", "c10"])
 def test_render_neus_stage1_golden(dev, synth_weights, tag):
     """Stage-1 renderer (cos-annealed alpha) against the reference's neus/volume_render/sdf_render.py output."""

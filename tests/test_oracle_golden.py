@@ -304,3 +304,59 @@ def test_oracle_camera_quaternion_pose():
     d, c = orend.camera_rays(torch.from_numpy(g["uv"]), torch.from_numpy(g["pose7"]), torch.from_numpy(g["K"]))
     assert float((d - torch.from_numpy(g["ray_dirs"])).abs().max()) <= 1e-6
     assert float((c - torch.from_numpy(g["cam_loc"])).abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------- round 5 (oracle/gen_golden_r5.py)
+@pytest.mark.parametrize("tag,testing,inv,argmax_vis", [("plain", False, False, False), ("testing_inv", True, True, False), ("argmax", False, False, True)])
+def test_specular_visibility_reference_signature(oracle_sd, tag, testing, inv, argmax_vis):
+    """get_specular_visibility with arbitrary caller lobes / lambdas (model/sg_render.py:196-301) against the reference's own outputs."""
+    from robir_oracle import nets, sg
+    g = load_golden("spec_vis_refsig")
+    T = lambda k: torch.from_numpy(g[k])
+    out = sg.specular_visibility(T("points"), T("normals"), T("view"), lambda p, d: nets.vis_logits(oracle_sd, p, d), T("lobes"), T("lambdas"),
+                                 T("u_theta"), T("u_phi"), testing=testing, inv=inv, argmax_vis=argmax_vis)
+    assert rel_err(out, g["out_" + tag]) <= 1e-6, rel_err(out, g["out_" + tag])
+
+
+def test_render_neus_perturb(synth_weights):
+    """render_neus with perturb > 0 (model/sdf_render.py:293-295), wrap_renderer's sample counts, the draw replayed."""
+    from robir_oracle import nets, neus
+    g = load_golden("render_neus_perturb")
+    sd = nets.as_torch(synth_weights)
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.dtype.kind == "f" and v.ndim > 0}
+    out = neus.render_neus(sd, t["rays_o"], t["rays_d"], t["near"], t["far"], n_samples=int(g["n_samples"]), n_importance=int(g["n_importance"]),
+                           up_sample_steps=int(g["up_sample_steps"]), t_rand=t["t_rand"])
+    for k, tol in (("rgb", 1e-4), ("dist", 1e-4), ("acc", 2e-4), ("grad", 2e-4), ("grad_error", 1e-4)):
+        assert rel_err(out[k], g["out_" + k]) <= tol, k
+    assert bad_frac(out["weights"], g["out_weights"], 5e-3) <= 0.01
+
+
+@pytest.mark.parametrize("env_id", [6, 12])
+def test_forward_relit_chunk(oracle_sd, oracle_octree, env_id):
+    """forward('Material') under a LOADED light (the shipped SG fit + a background map; scripts/relight.py:33-60,
+    model/sg_envmap_material.py:257-268) against the reference's output -- own octree build: the end-to-end bound of
+    test_forward_material_chunk; the sharp shipped lights make the specular terms ill-conditioned in fp32, so they get the looser fraction."""
+    import os
+    from conftest import GOLD
+    from robir_amd import synth, exr
+    from robir_oracle import renderer
+    g = load_golden("forward_relit_%d" % env_id)
+    H, W, c = int(g["H"]), int(g["W"]), int(g["chunk"])
+    uv, pose, K = synth.synth_camera(H, W)
+    sl = slice(c * 1024, (c + 1) * 1024)
+    draws = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("draw_")}
+    sd = dict(oracle_sd)
+    sd["envmap_material_network.lgtSGs"] = torch.from_numpy(g["lgtSGs"])
+    env = torch.from_numpy(np.ascontiguousarray(exr.read_exr(os.path.join(GOLD, str(g["env_fixture"])))[:, :, :3]))
+    out = renderer.forward(sd, oracle_octree, torch.from_numpy(uv)[None, sl], torch.from_numpy(pose)[None], torch.from_numpy(K)[None],
+                           torch.ones(1, 1024, dtype=torch.bool), torch.from_numpy(g["hdr_shift"]).expand(1024, 1), draws, "Material",
+                           testing=True, envmap=env)
+    assert bool((out["network_object_mask"].numpy() == g["out_network_object_mask"]).all())
+    assert rel_err(out["bg_rgb"], g["out_bg_rgb"]) <= 1e-5, rel_err(out["bg_rgb"], g["out_bg_rgb"])
+    assert float(np.abs(g["out_bg_rgb"] - 1.0).max()) > 0.1
+    for k in ("points", "sdf_output", "ray_dirs"):
+        assert rel_err(out[k], g["out_" + k]) <= TOL, k
+    for k in ("indir_rgb", "sg_diffuse_rgb", "vis_shadow", "diffuse_albedo", "roughness", "normals", "normal_map", "metallic"):
+        assert bad_frac(out[k], g["out_" + k], 2e-3) <= 0.002, (k, bad_frac(out[k], g["out_" + k], 2e-3))
+    for k in ("sg_rgb", "sg_specular_rgb", "indir_specular_rgb"):
+        assert bad_frac(out[k], g["out_" + k], 2e-3) <= 0.1, (k, bad_frac(out[k], g["out_" + k], 2e-3))

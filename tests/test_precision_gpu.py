@@ -1,13 +1,20 @@
-"""Where does the split-precision (f16 hi/lo pairs on the f16 MFMA, fp32 accumulate) arithmetic sit relative to fp32?
+"""Where do the kernels' arithmetics sit relative to fp32?  Everything here is anchored on a FLOAT64 evaluation of the reference's formulas.
 
 One Material chunk: the whole per-hit chain (indirect-illumination net -> NeuS normal -> material auto-encoders -> 128-lobe
 light visibility through the visibility MLP -> BRDF-lobe visibility -> SG shading) evaluated on IDENTICAL surface points,
 view directions and random draws by
   (r64)  the oracle in float64            -- the anchor: what the reference's formulas give without rounding noise,
   (o32)  the oracle in float32            -- the reference's own arithmetic (PyTorch CPU fp32),
-  (k32)  the HIP kernels, exact mode      -- every MLP on v_mfma_f32_16x16x4_f32 (ROBIR_MLP_PRECISION=fp32),
-  (kh3)  the HIP kernels, default mode    -- split precision.
-Asserted per field: err(kh3 vs r64) <= 1.25 * err(k32 vs r64) + F and <= 2 * err(o32 vs r64) + F, on the median and on the
+  (k32)  the HIP kernels, f32-input MFMA  -- every MLP on v_mfma_f32_16x16x4_f32 (ROBIR_MLP_PRECISION=fp32),
+  (kx6)  the HIP kernels, DEFAULT policy  -- ROBIR_PRECISION=exact: every fp32 operand carried exactly as three f16 pieces, six f16
+                                             MFMA products per multiply-add, fp32 accumulation ("f16x6": the arithmetic bench.py's
+                                             headline runs in and whose `dtype` claim -- not narrower than fp32 -- this file asserts),
+  (kh3)  the HIP kernels, split precision -- ROBIR_PRECISION=split: (hi, lo) f16 pairs, 22-bit operands (the throughput policy).
+Asserted per field for the DEFAULT: err(kx6 vs r64) <= X6_VS_K32 * err(k32 vs r64) + 2^-23 and <= X6_VS_O32 * err(o32 vs r64) + 2^-23
+on the median and the 99th percentile (both factors are sampling allowances for quantiles of a few hundred entries of two fp32
+evaluations that differ in summation order only -- NOT a representation floor: the three pieces ARE the fp32 operand);
+test_per_net_error_budget asserts the same per network on 8192 rows with factor 1.0.
+Asserted per field for split precision: err(kh3 vs r64) <= 1.25 * err(k32 vs r64) + F and <= 2 * err(o32 vs r64) + F, on the median and on the
 99th percentile of the per-entry errors.  F = 16 * 2^-22 = 3.8e-6 is the representation floor of the split: an (hi, lo) half
 pair carries 22 bits where fp32 carries 24, so a DIRECT network output (the NeuS normal: measured 2e-6 at p99 against 5e-7 for
 the exact kernels) sits a few 2^-22 above fp32 while being 50x below the 1e-4 bar; every SHADING field (errors 1e-5..1e-3,
@@ -25,6 +32,11 @@ import torch
 from conftest import err_entries, record_metric
 
 pytestmark = pytest.mark.gpu
+
+# sampling allowances of the chained test (quantiles over ~600 entries of fields whose error is set by a handful of ill-conditioned
+# entries): two fp32 evaluations in different summation orders scatter around each other by this much -- the o32 / k32 columns do
+X6_VS_K32 = 1.25
+X6_VS_O32 = 2.0
 
 FIELDS = ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_diffuse_rgb", "indir_specular_rgb",
           "vis_shadow", "diffuse_albedo", "roughness", "metallic", "normals", "normal_map")
@@ -66,29 +78,40 @@ def test_chained_error_budget(monkeypatch, seed, variance, sharp):
     draws = {k: torch.from_numpy(v) for k, v in synth.pbr_draws(seed + 40, n_hit, chunk_id=9).items()}
     dd = {k: v.to(dev) for k, v in draws.items()}
     outs = {}
-    for mode, vis in (("fp32", "fp32"), ("f16x3", "f16x3-auto")):
+    for mode, vis in (("fp32", "fp32"), ("f16x6", "f16x6"), ("f16x3", "f16x3-auto")):
         monkeypatch.setenv("ROBIR_MLP_PRECISION", mode)
         monkeypatch.setattr(sg_render, "VIS_PRECISION", vis)
         outs[mode] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in
                       model(inp, trainstage="Material", train_spec=True, draws=dd).items()}
-    k32, kh3 = outs["fp32"], outs["f16x3"]
-    assert torch.equal(k32["network_object_mask"], hit) and torch.equal(kh3["network_object_mask"], hit)
-    assert torch.equal(k32["points"][hit], kh3["points"][hit])          # the cast is geometry code: identical in both modes
+    k32, kx6, kh3 = outs["fp32"], outs["f16x6"], outs["f16x3"]
+    for o in (k32, kx6, kh3):
+        assert torch.equal(o["network_object_mask"], hit)
+        assert torch.equal(o["points"][hit], k32["points"][hit])       # the cast is geometry code: identical in every mode
     pts, view, hdr = k32["points"][hit], -k32["ray_dirs"][hit], inp["hdr_shift"].cpu()[hit]
     r64 = _oracle_chain(sd, pts, view, hdr, draws, torch.float64)
     o32 = _oracle_chain(sd, pts, view, hdr, draws, torch.float32)
-    worst_ratio = 0.0
+    worst_ratio, worst_x6 = 0.0, 0.0
+    ulp = 2.0 ** -23
     for f in FIELDS:
         ref = r64[f].expand(-1, 3) if (f == "roughness") else r64[f]
         o = o32[f].expand(-1, 3) if (f == "roughness") else o32[f]
-        e = {"o32": err_entries(o, ref), "k32": err_entries(k32[f][hit], ref), "kh3": err_entries(kh3[f][hit], ref)}
+        e = {"o32": err_entries(o, ref), "k32": err_entries(k32[f][hit], ref), "kx6": err_entries(kx6[f][hit], ref),
+             "kh3": err_entries(kh3[f][hit], ref)}
         st = {}
         for name, v in e.items():
             st[name + "_p50"], st[name + "_p99"] = float(v.quantile(0.5)), float(v.quantile(0.99))
             st[name + "_max"], st[name + "_n_gt_1e-3"] = float(v.max()), int((v > 1e-3).sum())
         record_metric(f"chained_error_budget/seed{seed}/{f}", entries=int(e["kh3"].numel()), **st)
         print(f"{f:22s} " + "  ".join(f"{n}: p50 {st[n + '_p50']:.2e} p99 {st[n + '_p99']:.2e} max {st[n + '_max']:.2e} "
-                                      f"n>1e-3 {st[n + '_n_gt_1e-3']}" for n in ("o32", "k32", "kh3")))
+                                      f"n>1e-3 {st[n + '_n_gt_1e-3']}" for n in ("o32", "k32", "kx6", "kh3")))
+        # ---- the DEFAULT policy (exact three-piece operands): an fp32 evaluation like the other two
+        for q in ("_p50", "_p99"):
+            assert st["kx6" + q] <= X6_VS_K32 * st["k32" + q] + ulp, ("f16x6 vs f32-input MFMA", f, q, st)
+            assert st["kx6" + q] <= X6_VS_O32 * st["o32" + q] + ulp, ("f16x6 vs the reference's fp32", f, q, st)
+            worst_x6 = max(worst_x6, st["kx6" + q] / (st["k32" + q] + ulp))
+        assert st["kx6_n_gt_1e-3"] <= max(2 * st["o32_n_gt_1e-3"], st["k32_n_gt_1e-3"] + 3, 3), (f, st)       # cull flips, counted
+        assert st["kx6_p99"] <= max(1e-4, 2.0 * st["o32_p99"]), (f, st)
+        # ---- split precision
         slack = 16 * 2.0 ** -22
         for q in ("_p50", "_p99"):
             assert st["kh3" + q] <= 1.25 * st["k32" + q] + slack, (f, q, st)
@@ -100,6 +123,7 @@ def test_chained_error_budget(monkeypatch, seed, variance, sharp):
         # are ill-conditioned in fp32 (lambda_trick / hemisphere_int cancel large exponentials: o32 itself is at 2e-4..1e-3)
         assert st["kh3_p99"] <= max(1e-4, 2.0 * st["o32_p99"]), (f, st)
     record_metric(f"chained_error_budget/seed{seed}/worst_ratio_h3_over_fp32mfma", ratio=worst_ratio)
+    record_metric(f"chained_error_budget/seed{seed}/worst_ratio_x6_over_fp32mfma", ratio=worst_x6)
     # ROBIR_PRECISION=f16 (light-visibility MLP in plain f16, one product; every other net exact): NARROWER than fp32 -- measured against
     # the same float64 anchor, printed and recorded (DESIGN.md quotes the table), held only to a sanity band: no parity claim
     monkeypatch.setenv("ROBIR_MLP_PRECISION", "f16x6")
@@ -209,3 +233,139 @@ def test_activation_range_sentinel(monkeypatch):
     e1, e2 = rel_err(logits, ref_logits), rel_err(vis, ref_vis)
     record_metric("range_sentinel/act_2e5_exact_kernels", logits=e1, light_vis=e2)
     assert e1 <= 1e-4 and e2 <= 1e-4, (e1, e2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# per network: the default (exact three-piece operand) kernels against float64, next to the f32-input-MFMA kernels and the reference's
+# own fp32 arithmetic on the same inputs.  This is the evidence behind bench.py's dtype "f16x6 ... not narrower than fp32".
+PER_NET_ROWS = 8192
+# err(x6 vs r64) <= PER_NET_VS_K32 * err(k32 vs r64) + 2^-23   (median and 99th percentile of the per-entry errors, 8192 rows)
+# err(x6 vs r64) <= PER_NET_VS_O32 * err(o32 vs r64) + 2^-23   (o32: PyTorch CPU fp32 = the reference's arithmetic)
+PER_NET_VS_K32 = 1.0
+PER_NET_VS_O32 = 1.0
+
+
+def _f64(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def _per_net_cases(dev, sd_np):
+    """[(name, oracle(sd, dtype) -> tensor, {form: thunk -> device tensor})]: inputs are drawn once (fp32) and shared by every column."""
+    from robir_amd import ops, packing, synth
+    from robir_oracle import nets as on
+    from robir_oracle.encoding import pe
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(20260929)
+    n = PER_NET_ROWS
+    x = (torch.rand(n, 3, generator=g) - 0.5) * 1.2                                      # stage-2 points around the object
+    view = F.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    nrm = F.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    hdr = torch.rand(n, 1, generator=g)
+    xd, vd, nd, hd = x.to(dev), view.to(dev), nrm.to(dev), hdr.to(dev)
+    b32, back = packing.pack_sdf(sd_np, dev, full=True), packing.pack_sdf_back(sd_np, dev)
+    x6f = packing.pack_sdf_x6(sd_np, dev, full=True)
+    back6 = packing.pack_sdf_back_x6(sd_np, dev) + (packing.pack_sdf_back_x6(sd_np, dev, two_tile=True)[0],)
+    feat_d = ops.sdf_mlp_points(xd, n, b32, 1, 2.0, 0.5, 1.0)[0][:, 1:].contiguous()    # one fp32 feature tensor for the colour columns
+    feat = feat_d.cpu()
+    c32, c6 = packing.pack_color(sd_np, dev), packing.pack_color_x6(sd_np, dev)
+    v32, v6 = packing.pack_vis(sd_np, dev), packing.pack_vis_x6(sd_np, dev)
+    ill32, ill6 = packing.pack_illum(sd_np, dev), packing.pack_illum_x6(sd_np, dev)
+    pre = "envmap_material_network.spec_brdf_encoder_layer"
+    enc32, _ = packing.pack_sparse_ae(sd_np, pre, dev)
+    enc6 = packing.pack_sparse_ae_encoder_x6(sd_np, pre, dev)
+    cesr = synth.synth_cesr_nets(0)
+    no = {"net." + k: v for k, v in cesr["normal_net"].items()}
+    sh = {"net." + k: v for k, v in cesr["shadow_net"].items()}
+    no32, no6 = packing.pack_softplus512(no, "net.", 63, dev), packing.pack_softplus512_x6(no, "net.", 63, dev)
+    sh32, sh6 = packing.pack_softplus512(sh, "net.", 191, dev), packing.pack_softplus512_x6(sh, "net.", 191, dev)
+    no_t = {k: torch.from_numpy(v) for k, v in cesr["normal_net"].items()}
+    sh_t = {k: torch.from_numpy(v) for k, v in cesr["shadow_net"].items()}
+    nl, nsh = 8, n // 8                                                                  # shadow_net: n/8 points x 8 one-hot labels
+    lrelu = lambda t: F.leaky_relu(t, 0.2)
+
+    def two_forms(fn):
+        """{one tile per wave, two tiles per wave} of the SDF kernels, whatever ops.sdf_two_tile would pick at this size."""
+        def run(rows):
+            old, ops.SDF_TWO_TILE_MIN_ROWS = ops.SDF_TWO_TILE_MIN_ROWS, rows
+            try:
+                return fn()
+            finally:
+                ops.SDF_TWO_TILE_MIN_ROWS = old
+        return {"x6_one_tile": lambda: run(1 << 60), "x6_two_tile": lambda: run(0)}
+
+    def shadow_oracle(sd, dt):
+        p = x[:nsh].to(dt)
+        rows = torch.cat([pe(p, 10)[:, None, :].expand(-1, nl, -1), torch.eye(128, dtype=dt)[None, :nl].expand(nsh, -1, -1)], -1)
+        return on.softplus_net512({k: v.to(dt) for k, v in sh_t.items()}, rows.reshape(-1, 191))
+
+    cases = [
+        ("sdf_values_257", lambda sd, dt: on.implicit_forward(sd, x.to(dt)),
+         dict(k32=lambda: ops.sdf_mlp_points(xd, n, b32, 1, 2.0, 0.5, 1.0)[0],
+              **two_forms(lambda: ops.sdf_points_x6(xd, n, x6f, True, 2.0, 0.5)))),
+        ("sdf_gradient", lambda sd, dt: on.implicit_gradient(sd, x.to(dt)),
+         dict(k32=lambda: ops.sdf_value_grad_f32(xd, n, b32, back, 2.0, 0.5)[1],
+              **two_forms(lambda: ops.sdf_value_grad_x6(xd, n, x6f, back6, 2.0, 0.5)[1]))),
+        ("colour_rgb", lambda sd, dt: on.color_raw(sd, x.to(dt), nrm.to(dt), view.to(dt), feat.to(dt)),
+         dict(k32=lambda: ops.color_mlp_points(xd, vd, nd, feat_d, c32),
+              x6_one_tile=lambda: ops.color_x6_points(xd, vd, nd, feat_d, c6, two_tile=False),
+              x6_two_tile=lambda: ops.color_x6_points(xd, vd, nd, feat_d, c6, two_tile=True))),
+        ("visibility_logits", lambda sd, dt: on.vis_logits(sd, x.to(dt) * 0.5, view.to(dt)),
+         dict(k32=lambda: ops.vis_mlp_points(xd * 0.5, vd, v32, 1), x6=lambda: ops.vis_x6_points(xd * 0.5, vd, v6, 1))),
+        ("illum_lobe_net_512", lambda sd, dt: on._seq(sd, on.ILL + "lobe_layer.", 5, torch.cat([pe(x.to(dt) * 0.5, 10), hdr.to(dt)], -1), torch.relu),
+         dict(k32=lambda: ops.wide_mlp_points(xd * 0.5, hd, ill32, False), x6=lambda: ops.wide_x6_points(xd * 0.5, hd, ill6, False))),
+        ("spec_encoder_512", lambda sd, dt: on._seq(sd, pre + ".brdf_encoder_layer.", 5, pe(x.to(dt) * 0.5, 10), lrelu),
+         dict(k32=lambda: ops.wide_mlp_points(xd * 0.5, None, enc32, True), x6=lambda: ops.wide_x6_points(xd * 0.5, None, enc6, True))),
+        ("cesr_normal_net", lambda sd, dt: on.softplus_net512({k: v.to(dt) for k, v in no_t.items()}, pe(x.to(dt) * 0.5, 10)),
+         dict(k32=lambda: ops.cesr_net_points(xd * 0.5, n, 0, no32), x6=lambda: ops.cesr_net_x6_points(xd * 0.5, n, 0, no6))),
+        ("cesr_shadow_net", shadow_oracle,
+         dict(k32=lambda: ops.cesr_net_points(xd[:nsh].contiguous(), nsh * nl, 2, sh32, nl),
+              x6=lambda: ops.cesr_net_x6_points(xd[:nsh].contiguous(), nsh * nl, 2, sh6, nl))),
+    ]
+    return cases
+
+
+@pytest.mark.parametrize("weights", ["init", "trained_like"])
+def test_per_net_error_budget(weights):
+    """Every network of the path, DEFAULT arithmetic (exact three-piece operands, "f16x6") against a float64 evaluation of the
+    reference's formulas (model/neus_model.py:385-417 SDF net, :425-438 its input gradient, :535-560 colour net;
+    model/implicit_differentiable_renderer.py:250-258 visibility MLP, :199-222 lobe net; model/sg_envmap_material.py:74-99 encoder;
+    training/train_cesr.py:106-110 CESR nets) on identical fp32 inputs and weights:
+        err(x6 vs r64)  <=  PER_NET_VS_K32 * err(f32-input-MFMA kernel vs r64) + 2^-23
+        err(x6 vs r64)  <=  PER_NET_VS_O32 * err(PyTorch CPU fp32 vs r64)      + 2^-23
+    on the median and on the 99th percentile of the per-entry errors |a-b| / (|b| + mean|b|); maxima are recorded.  Both forms of a
+    kernel that has two (one / two tiles per wave) are held to it."""
+    from robir_amd import ops, synth
+    from robir_oracle import nets as on
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd_np = synth.synth_state_dict(0, variance=0.3)
+    if weights == "trained_like":
+        import importlib
+        sd_np = importlib.import_module("test_mlp_gpu")._trained_like(sd_np, 5)
+    sd32 = on.as_torch(sd_np)
+    sd64 = _f64(sd32)
+    ulp = 2.0 ** -23
+    ops.range_check(sync=True)
+    table = []
+    for name, oracle, forms in _per_net_cases(dev, sd_np):
+        r64 = oracle(sd64, torch.float64)
+        o32 = oracle(sd32, torch.float32)
+        assert o32.dtype == torch.float32 and r64.dtype == torch.float64, name
+        st = {}
+        cols = {"o32": o32}
+        for form, thunk in forms.items():
+            cols[form] = thunk().cpu().reshape(r64.shape)
+        for col, v in cols.items():
+            e = err_entries(v, r64)
+            st[col + "_p50"], st[col + "_p99"], st[col + "_max"] = float(e.quantile(0.5)), float(e.quantile(0.99)), float(e.max())
+        record_metric(f"per_net_error_budget/{weights}/{name}", entries=int(r64.numel()), **st)
+        line = f"{name:20s} " + "  ".join(f"{c}: p50 {st[c + '_p50']:.2e} p99 {st[c + '_p99']:.2e} max {st[c + '_max']:.2e}" for c in cols)
+        print(line)
+        table.append((name, st, [c for c in cols if c.startswith("x6")]))
+    ops.range_check(sync=True)
+    for name, st, x6cols in table:
+        for c in x6cols:
+            for q in ("_p50", "_p99"):
+                assert st[c + q] <= PER_NET_VS_K32 * st["k32" + q] + ulp, (name, c, q, "vs f32-input MFMA", st)
+                assert st[c + q] <= PER_NET_VS_O32 * st["o32" + q] + ulp, (name, c, q, "vs the reference's fp32", st)
+            assert st[c + "_p99"] <= 1e-4 and st[c + "_max"] <= 1e-4 * 4, (name, c, st)      # and north_star's bar itself

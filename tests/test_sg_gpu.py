@@ -99,6 +99,33 @@ def test_diffuse_visibility_vs_oracle(dev, vis_net, oracle_sd, precision):
         print(f"[{precision}] chunk {c}: max rel err vs oracle {rel_err(out[sl], ref):.3e}")
 
 
+@pytest.mark.parametrize("vis_mode", ["f16x6", "f16x3-auto", "fp32"])
+def test_diffuse_visibility_light_that_does_not_fill_whole_tiles(dev, vis_net, oracle_sd, vis_mode, monkeypatch):
+    """A light with L * nsamp NOT a multiple of 16 (7 lobes x 8 samples = 56; the CESR diffuse_vis path and any direct
+    get_diffuse_visibility(nsamp=8) with an odd lobe count) on a chunk-sized batch: the policies' auto rules must take the per-point
+    kernels -- the tile-list forms cut a point's directions into whole 16-sample tiles and refuse this shape -- and agree with
+    the oracle; the f16 throughput kernel, which exists in the tile-list form only, says so in Python instead of failing in the launcher."""
+    from robir_amd import sg_render, synth
+    from robir_oracle import nets as on, sg as osg
+    monkeypatch.setattr(sg_render, "VIS_PRECISION", vis_mode)
+    g = np.random.Generator(np.random.PCG64(35))
+    n, L, nsamp = 41, 7, 8
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128, sharp=True))[:L]
+    lobe, lam = lgt[:, :3], lgt[:, 3:4].abs()
+    u = torch.from_numpy(g.random((2, L, nsamp), dtype=np.float32))
+    draws = {"dvis_theta": u[0][None].to(dev), "dvis_phi": u[1][None].to(dev)}
+    out = sg_render.get_diffuse_visibility(pts.to(dev), nrm.to(dev), vis_net, lobe.to(dev), lam.to(dev), nsamp=nsamp, draws=draws).cpu()
+    ref = osg.diffuse_visibility(pts, nrm, lambda p, d: on.vis_logits(oracle_sd, p, d), torch.nn.functional.normalize(lobe, dim=-1), lam, u[0], u[1])
+    assert out.shape == ref.shape == (L, n)
+    assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+    if vis_mode == "f16x6":
+        monkeypatch.setattr(sg_render, "VIS_PRECISION", "f16x1")
+        with pytest.raises(ValueError, match="multiple of 16"):
+            sg_render.get_diffuse_visibility(pts.to(dev), nrm.to(dev), vis_net, lobe.to(dev), lam.to(dev), nsamp=nsamp, draws=draws)
+
+
 @pytest.mark.parametrize("argmax_vis", [False, True])
 def test_diffuse_visibility_bounding_vs_oracle(dev, vis_net, oracle_sd, argmax_vis):
     """bounding=True (sg_render.py:185-186): the per-sample visibilities [L, nsamp, n] before the lobe-weighted mean, culled pairs 0;
@@ -220,6 +247,51 @@ def test_specular_visibility_vs_oracle(dev, vis_net, oracle_sd, testing, inv, ar
         assert float(((out - ref).abs() > 1e-4).float().mean()) <= 0.05
     else:
         assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("tag,testing,inv,argmax_vis", [("plain", False, False, False), ("testing_inv", True, True, False), ("argmax", False, False, True)])
+def test_specular_visibility_reference_signature_golden(dev, vis_net, oracle_sd, tag, testing, inv, argmax_vis):
+    """get_specular_visibility called EXACTLY as the reference declares it (model/sg_render.py:196-197), all eleven arguments positional,
+    on lobes / lambdas that are not the warped BRDF lobe of the points (un-normalised vectors, lambdas on both sides of the 0.1 .. 50
+    clip): the cone opens by the PASSED lambdas (batch-global minimum, :219-223), the samples are weighted by the PASSED lobes (:281).
+    Against the reference's own outputs (tests/golden/spec_vis_refsig.npz, oracle/gen_golden_r5.py) and the oracle; the two uniform draws
+    are replayed by seeding torch's device generator -- the reference draws them with torch.rand at this point (:224-225)."""
+    from robir_amd import sg_render
+    from robir_oracle import nets as on, sg as osg
+    g = load_golden("spec_vis_refsig")
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    nsamp = int(g["nsamp"])
+    out = sg_render.get_specular_visibility(T("points"), T("normals"), T("view"), vis_net, T("lobes"), T("lambdas"), nsamp, False, testing,
+                                            inv, argmax_vis, draws=(T("u_theta"), T("u_phi"))).cpu()
+    ref = torch.from_numpy(g["out_" + tag])
+    assert out.shape == ref.shape
+    mine = osg.specular_visibility(*(torch.from_numpy(g[k]) for k in ("points", "normals", "view")), lambda p, d: on.vis_logits(oracle_sd, p, d),
+                                   torch.from_numpy(g["lobes"]), torch.from_numpy(g["lambdas"]), torch.from_numpy(g["u_theta"]),
+                                   torch.from_numpy(g["u_phi"]), testing=testing, inv=inv, argmax_vis=argmax_vis)
+    assert float(ref.std()) > 0.02
+    if argmax_vis:
+        assert float(((out - ref).abs() > 1e-4).float().mean()) <= 0.05 and float(((mine - ref).abs() > 1e-4).float().mean()) <= 0.05
+    else:
+        assert rel_err(mine, ref) <= 1e-5, rel_err(mine, ref)
+        assert rel_err(out, ref) <= TOL, rel_err(out, ref)
+    # the call with no keyword at all draws from torch's generator like the reference: same seed, same result, and a value per point
+    torch.manual_seed(11)
+    a = sg_render.get_specular_visibility(T("points"), T("normals"), T("view"), vis_net, T("lobes"), T("lambdas"), nsamp, False, testing, inv, argmax_vis)
+    torch.manual_seed(11)
+    b = sg_render.get_specular_visibility(T("points"), T("normals"), T("view"), vis_net, T("lobes"), T("lambdas"), nsamp, False, testing, inv, argmax_vis)
+    assert torch.equal(a, b) and a.shape == ref.shape and bool(torch.isfinite(a).all())
+    # and the warped-lobe fast path (roughness=) equals the reference-signature path fed with the warped lobe it recomputes
+    rough = torch.from_numpy(np.exp(np.random.default_rng(2).uniform(np.log(0.08), np.log(0.9), (ref.shape[0], 1))).astype(np.float32))
+    nrm, view = torch.from_numpy(g["normals"]), torch.from_numpy(g["view"])
+    vdl = (nrm * view).sum(-1, keepdim=True).clamp(min=0.0)
+    w_lobe = 2 * vdl * nrm - view
+    w_lobe = w_lobe / (w_lobe.norm(dim=-1, keepdim=True) + 1e-6)
+    w_lam = (2.0 / rough ** 4) / (4 * vdl + 1e-6)
+    fast = sg_render.get_specular_visibility(T("points"), T("normals"), T("view"), vis_net, None, None, nsamp, testing=testing, inv=inv,
+                                             argmax_vis=argmax_vis, roughness=rough.to(dev), draws=(T("u_theta"), T("u_phi")))
+    slow = sg_render.get_specular_visibility(T("points"), T("normals"), T("view"), vis_net, w_lobe.to(dev), w_lam.to(dev), nsamp, False,
+                                             testing, inv, argmax_vis, draws=(T("u_theta"), T("u_phi")))
+    assert float((fast - slow).abs().max()) <= (0.5 if argmax_vis else 2e-5), float((fast - slow).abs().max())
 
 
 def test_generic_vismodel_callable(dev, vis_net):

@@ -193,8 +193,13 @@ def config5(model, reps=1, first=875, nch=125, trace=True):
         t = timed(cesr, reps, (SHADOW_TIMER,))
     finally:
         model.__dict__.pop("get_sg_render", None)
+    from robir_amd import deferred
+    dc = int(model.__dict__.get("deferred_chunks", deferred.DEFAULT_CHUNKS))
     return {"config": 5, "workload": f"CESR forward + trace_radiance(nsamp=8) per chunk, {nch} chunks of 1600x1200 chunk by chunk"
-                                     + ("" if trace else " (no trace_radiance)"),
+                                     + ("" if trace else " (no trace_radiance)")
+                                     + (f"; default settings: the chunk forwards and their trace_radiance calls are recorded and run as passes of {dc} chunks "
+                                        "(robir_amd/deferred.py), every chunk its own lock-step batch" if dc else "; every call runs at once (ROBIR_DEFER_CHUNKS=0)"),
+            "deferred_chunks": dc,
             "value": nch * 1024 / t, "unit": "rays/s", "ms": t * 1e3, "chunks": nch, "hit_rays": state["hits"],
             "hit_rays_per_s": state["hits"] / t,
             "roofline": SHADOW_TIMER.roofline("shadow_net (512 x 8 softplus net over 128 one-hot labels)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
