@@ -19,22 +19,23 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 5
+#define RB_ABI_VERSION 6
 
 typedef void* rb_stream_t; /* hipStream_t */
 
 int rb_abi_version(void);
 
-/* Activation-range sentinel of the split-precision ("f16x3") kernels.  Those kernels carry each fp32 operand as an (hi, lo)
- * pair of halves after lifting it by a power of two; an operand whose lifted magnitude reaches 65504 no longer fits (the hi
- * half saturates -- round-toward-zero conversion -- and the pair silently loses precision).  Every split-precision kernel
- * therefore tracks the largest |hi| half it consumed and, when one saturates (or is inf / NaN), stores 1 into a per-family
+/* Activation-range sentinel of the kernels that carry fp32 operands as f16 PIECES (the exact three-piece "f16x6" kernels of the default
+ * policy; the (hi, lo) pairs of the legacy split-precision kernels).  The leading piece is a half: an operand whose magnitude reaches
+ * 65504 no longer fits (it saturates -- round-toward-zero conversion -- and the pieces silently lose precision).  Every such kernel
+ * therefore tracks the largest leading piece it consumed and, when one saturates (or is inf; NaN inputs are not an overflow), stores 1 into a per-family
  * word of a process-wide block of pinned, mapped host memory.  rb_range_check reads and clears the words:
- *   mask bit 0 light-visibility (rb_dvis_fused*), 1 rb_vis_mlp_h3, 2 rb_sdf_mlp_h3, 3 rb_color_mlp_h3, 4 rb_wide_mlp_h3,
- *   5 rb_cesr_net_h3.
+ *   mask bit 0 light-visibility (rb_dvis_fused* / rb_dvis_stream*), 1 visibility MLP (rb_vis_x6_points), 2 SDF net (rb_sdf_x6*_points,
+ *   rb_sdf_value_grad_x6*_points), 3 colour net (rb_color_x6*_points), 4 512-wide nets (rb_wide_x6*), 5 CESR nets (rb_cesr_net_x6_points);
+ *   the legacy library's split-precision kernels (robir_hip_legacy.h) report into the same families of ITS block.
  * synchronize != 0: wait for `stream` first, so every kernel enqueued on it so far has reported; 0: no wait -- reports what
  * completed kernels have flagged (free of charge; call it at the next natural sync point for a complete answer).
- * A set bit means: re-run that family with the exact f32-input MFMA kernels (the non-_h3 entry points).  Nothing like this
+ * A set bit means: re-run that family with the f32-input MFMA kernels (rb_*_mlp_points; ROBIR_MLP_PRECISION=fp32 / ROBIR_VIS_PRECISION=fp32).  Nothing like this
  * exists in the reference (PyTorch fp32 throughout); it guards the precision mode this library adds. */
 int rb_range_check(int synchronize, rb_stream_t stream, unsigned* mask_out);
 const char* rb_last_error(void);
@@ -49,10 +50,6 @@ const char* rb_last_error(void);
  * k_perm (device int32[k_pad], may be NULL): packed input column k reads source column k_perm[k] (-1: zero).
  * ------------------------------------------------------------------------------------------------------------ */
 long rb_packed_layer_floats(int n_pad, int k_pad);
-/* split-precision packing: weights (and bias) scaled by 2^scale_log2, stored as hi/lo half pairs; k_pad % 32 == 0;
- * same size as the fp32 packing. */
-int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* perm,
-                     int scale_log2, float* out, rb_stream_t stream);
 int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* k_perm,
                   float w_scale, float* out, rb_stream_t stream);
 /* exact-operand packing ("f16x6"): every weight * 2^scale_log2 as three halves h, m, l with w = h + m 2^-11 + l 2^-22 exactly;
@@ -65,27 +62,15 @@ int rb_pack_layer_x6(const float* W, const float* b, int n_out, int k_in, int n_
  * Feature construction (positional encodings), accurate sinf/cosf.
  * Replaces: model/embedder.py:7-55 (get_embedder), model/neus_model.py:14-57,71-91 (IPE).
  * ------------------------------------------------------------------------------------------------------------ */
-/* X[M,128] = [PE10(p[i/rep]) | PE10(d[i]) | 0 0]   VisNetwork input; p holds M/rep points, d holds M directions */
-int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_stream_t stream);
 /* X[M,64] = [PE10(x*scale) | extra[M] or 0];  jvp!=0: X[4M,64] with rows (PE, dPE/dx, dPE/dy, dPE/dz) per point */
 int rb_feat_pe10(const float* x, long M, float scale, const float* extra, int jvp, float* X, rb_stream_t stream);
 /* X[M,64] = full-covariance IPE(x, var*I) (60) [+ noise[M,60]*noise_scale] | 0 x4 */
 int rb_feat_ipe(const float* x, long M, float var, const float* noise, float noise_scale, float* X,
                 rb_stream_t stream);
-/* X[M,304] = [feat[M,256 @feat_stride]*feat_scale | x*x_scale | PE4(view) | normal | 0 x15]   colour-net input */
-int rb_feat_color(const float* x, float x_scale, const float* view, const float* normal, const float* feat,
-                  long feat_stride, float feat_scale, long M, float* X, rb_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused MLPs (fp32 MFMA, activations resident in registers across all layers).
  * ------------------------------------------------------------------------------------------------------------ */
-/* VisNetwork.forward (implicit_differentiable_renderer.py:250-258): X[M,128] -> logits[M,2].
- * Wp: packed [128->256, 256->256 x3, 256->16]. */
-int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream_t stream);
-/* Same with split-precision (f16x3) layers: Wp = the five layers packed by rb_pack_layer_h3 with scale 2^scale_log2. */
-int rb_vis_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* logits, rb_stream_t stream);
-/* One linear layer X[M,64] -> Y[M,256] (packed 64->256); used to factor the visibility net's first layer. */
-int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream);
 /* SDFNetwork.forward / .gradient (model/neus_model.py:385-438), ImplicitNetworkMy.forward/.gradient (:788-818).
  * X from rb_feat_pe10 (jvp rows for modes 2,3).  Wp packed [64->256, 256->256 x2, 256->208, 272->256, 256->256 x3,
  * 256->272] (modes 1,3) or [... , 256->16] (modes 0,2).
@@ -94,44 +79,6 @@ int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_strea
  * Softplus(beta=100) is evaluated with the hardware exp/log/rcp (a few ulp); modes 4 and 6 are modes 0 and 2 with the
  * library expf/log1pf instead -- the octree build uses them because its split / hit thresholds must fall exactly where
  * the reference's do. */
-/* Split-precision (f16x3) form of modes 0..3: Wp = the nine layers packed by rb_pack_layer_h3 with k_pad 64, 256, 256, 256,
- * 288 (skip layer: [208 | 64 | 16 zero slots]), 256 x4 and one scale 2^scale_log2. */
-int rb_sdf_mlp_h3(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
-                  float* out0, float* grad, rb_stream_t stream);
-/* Second generation of rb_sdf_mlp_h3 (csrc/sdf_ring.hip): same arguments, packed weights and results (to fp32 rounding); the net
- * is one cyclic chunk stream through an LDS-DMA ring, activations and hi/lo splits run between the MFMAs, workgroups are
- * persistent (n_workgroups <= 0: one per compute unit). */
-int rb_sdf_mlp_ring(const float* X, long M, const float* Wp, int mode, int scale_log2, float out_scale, float grad_scale,
-                    float* out0, float* grad, int n_workgroups, rb_stream_t stream);
-/* Value rows (modes 0, 1 and the value pass of rb_sdf_value_grad) run as eight waves of one 16-row tile per workgroup -- two
- * waves per SIMD, csrc/sdf_ring8.hip -- or as four waves of two tiles (csrc/sdf_ring.hip): same results.  Selects 8 (default)
- * or 4 for the calling process; returns the previous setting. */
-int rb_sdf_ring_waves(int waves);
-/* All 257 outputs and the input gradient of the signed distance in REVERSE mode (csrc/sdf_back.hip; model/neus_model.py:440-452
- * is autograd too): one value pass (rb_sdf_mlp_ring's kernel, which also stores sigmoid(100 z) of every hidden pre-activation)
- * and one row vector per point back through the transposed layers -- twice the matrix work of the values instead of the four
- * times of the forward-mode rows of mode 3; same results to fp32 rounding.
- *   X [M,64] rb_feat_pe10 rows (value rows only);  Wp as rb_sdf_mlp_ring;  out0 [M,257], grad [M,3] as mode 3;
- *   Wb   the transposed layers packed by rb_pack_layer_h3 in the order W7^T, W6^T, W5^T, W4^T (320 x 256: rows 0..192 the
- *        columns of layer 3's outputs, 208..270 those of the skip features, the rest zero), W3^T (256 x 224), W2^T, W1^T,
- *        W0^T (64 x 256), followed by >= 2 KB of padding;  w8row [256] = row 0 of layer 8 (the distance output);
- *   scratch  rb_sdf_value_grad_scratch_floats(M) floats (8.5 KB per point: the sigmoid blob and the feature gradients).
- * Callers bound the scratch by evaluating large M in slabs. */
-long rb_sdf_value_grad_scratch_floats(long M);
-int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
-                      float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
-                      rb_stream_t stream);
-/* The same two ops with the positional encoding FUSED into the network kernel (SDFNetwork.forward = embed_fn + layers,
- * model/neus_model.py:385-417; model/embedder.py:17-38): x [M,3] points, evaluated at x * in_scale -- no feature rows, no encoding
- * kernel.  The four lanes that share a point evaluate its 30 sine / cosine pairs between them once per round (the sincosf calls of
- * rb_feat_pe10), so outputs are bit-identical to the row forms above.
- *   rb_sdf_points_ring        mode 0 = signed distance [M], 1 = all 257 outputs [M,257]          (= rb_feat_pe10 + rb_sdf_mlp_ring)
- *   rb_sdf_points_ring_jvp    mode 2 / 3 = the same + the forward-mode gradient (small batches)   (= rb_feat_pe10(jvp) + rb_sdf_mlp_ring)
- *   rb_sdf_value_grad_points  all outputs + d sdf / dx; grad_scale multiplies the gradient           (= rb_feat_pe10 + rb_sdf_value_grad) */
-int rb_sdf_points_ring(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
-                       float* out0, int n_workgroups, rb_stream_t stream);
-int rb_sdf_points_ring_jvp(const float* x, long M, float in_scale, const float* Wp, int mode, int scale_log2, float out_scale,
-                           float grad_scale, float* out0, float* grad, int n_workgroups, rb_stream_t stream);
 /* The same op at the reference's precision (the default policy): value rows on the f32-input MFMA with the sigmoid of every hidden
  * pre-activation kept (k_sdf_mlp<5>), one pass over the transposed layers (k_sdf_back_f32; Wt / w8row from the host mirror's
  * packing.pack_sdf_back), the encoding's Jacobian (k_pe_grad_points) -- 2 x the value pass's MACs instead of the 4 x of the three
@@ -175,11 +122,6 @@ int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_scale, const f
 long rb_sdf_value_grad_f32_scratch_floats(long M);
 int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
-int rb_sdf_value_grad_points(const float* x, long M, float in_scale, const float* Wp, const float* Wb, const float* w8row,
-                             int scale_log2, float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
-                             int n_workgroups, rb_stream_t stream);
-int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
-               float* grad, rb_stream_t stream);
 /* rb_sdf_mlp with the positional encoding fused (every mode, tangent rows of the forward-mode gradient included): x [M,3],
  * evaluated at x * in_scale; bit-identical to rb_feat_pe10 (jvp for modes 2, 3, 6) + rb_sdf_mlp. */
 int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float grad_scale,
@@ -191,56 +133,14 @@ int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, i
  *   rb_wide_mlp_points / _h3_points  64 -> 512 x4 nets on [PE10(x) | extra]: indirect-illumination lobes (extra = hdr_shift [M]) and
  *                                    SparseAE encoders (extra NULL)                                       (= rb_feat_pe10 + rb_illum_mlp / rb_ae_encode / rb_wide_mlp_h3) */
 int rb_vis_mlp_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, rb_stream_t stream);
-int rb_vis_mlp_h3_points(const float* p, const float* d, long M, int rep, const float* Wp, int scale_log2, float* logits,
-                         rb_stream_t stream);
 int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_stream_t stream);
 int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, rb_stream_t stream);
-int rb_wide_mlp_h3_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
-                          rb_stream_t stream);
 /* CESR nets straight from the points (training/train_cesr.py:106-110,331-352): kind 0 = normal_net on PE10(x) [M rows], kind 2 =
  * shadow_net on (point, one-hot label) rows [M = points * n_label rows]; = rb_feat_pe10 + rb_cesr_net[_h3]. */
 int rb_cesr_net_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
-int rb_cesr_net_h3_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y, rb_stream_t stream);
-/* The split-precision 512-wide nets on the chunk-stream machine (csrc/wide_ring.h: persistent workgroups of four waves, the net as one
- * cyclic stream of 16-neuron chunks through an LDS-DMA ring, activation + hi/lo split between the next chunk's MFMAs): the same
- * arguments and bit-identical outputs as rb_cesr_net_h3_points / rb_wide_mlp_h3_points, the default for batches that fill the chip.
- * n_workgroups <= 0: one workgroup per compute unit. */
-int rb_cesr_net_ring_points(const float* x, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y, int n_workgroups,
-                            rb_stream_t stream);
-int rb_wide_mlp_ring_points(const float* x, const float* extra, long M, const float* Wp, int encoder, int scale_log2, float* Y,
-                            int n_workgroups, rb_stream_t stream);
-/* ... on feature rows X[M,64] (rb_feat_pe10 / rb_feat_ipe): the arguments and bits of rb_wide_mlp_h3 */
-int rb_wide_mlp_ring(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, int n_workgroups, rb_stream_t stream);
-/* NeuS RenderingNetwork.forward (model/neus_model.py:535-560): X[M,304] -> rgb[M,3] (sigmoid applied).
- * Wp packed [304->256 (columns permuted to the rb_feat_color order), 256->256 x3, 256->16]. */
-int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream);
-/* Split-precision (f16x3) form: Wp = the five layers packed by rb_pack_layer_h3 (first layer k_pad 320, same permutation). */
-int rb_color_mlp_h3(const float* X, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
-/* The same net reading its 304 input columns from two places: 0..255 = feat[i*feat_stride + 0..255] * feat_scale (the SDF net's
- * output rows; 4-byte alignment suffices), 256..303 = tail[i*48 + 0..47] written by rb_feat_color_tail ([x*x_scale | PE4(view) |
- * normal | 0 x15]) -- no assembled [M,304] rows.  Results equal rb_feat_color + rb_color_mlp_h3 bit for bit. */
-int rb_feat_color_tail(const float* x, float x_scale, const float* view, const float* normal, long M, float* tail, rb_stream_t stream);
-int rb_color_mlp_h3_two(const float* feat, long feat_stride, float feat_scale, const float* tail, long M, const float* Wp,
-                        int scale_log2, float* rgb, rb_stream_t stream);
-/* The same with the 48 encoded columns computed IN the kernel from x / view / normal [M,3] (embedview_fn fused into the network,
- * model/neus_model.py:535-545): no tail rows, no rb_feat_color_tail launch; bit-identical rgb. */
-int rb_color_mlp_h3_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                           const float* normal, long M, const float* Wp, int scale_log2, float* rgb, rb_stream_t stream);
-/* The same network on the eight-wave chunk-stream machine of rb_sdf_points_ring (csrc/color_ring8.hip: persistent workgroups, the
- * five layers as one cyclic stream of 65 chunks through an LDS-DMA ring, two waves per SIMD): bit-identical rgb, the default for
- * batches that fill the chip (n_workgroups <= 0: one workgroup per compute unit). */
-int rb_color_ring_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                         const float* normal, long M, const float* Wp, int scale_log2, float* rgb, int n_workgroups,
-                         rb_stream_t stream);
 /* f32-input-MFMA form of the same (rb_feat_color + rb_color_mlp without the assembled [M,304] rows). */
 int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                         const float* normal, long M, const float* Wp, float* rgb, rb_stream_t stream);
-/* IndirctIllumNetwork.lobe_layer (implicit_differentiable_renderer.py:186-193,206): X[M,64] -> raw[M,144].
- * Wp packed [64->512, 512->512 x3, 512->144]. */
-/* Split-precision (f16x3) form of rb_illum_mlp (encoder = 0, raw[M,144]) and rb_ae_encode (encoder = 1, raw_latent[M,32]):
- * Wp = the five layers packed by rb_pack_layer_h3 with one scale. */
-int rb_wide_mlp_h3(const float* X, long M, const float* Wp, int encoder, int scale_log2, float* Y, rb_stream_t stream);
-int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream);
 /* raw[M,24,6] -> lgt_sgs[M,24,7] (implicit_differentiable_renderer.py:208-218). */
 int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
 /* CESR-stage nets (training/train_cesr.py:106-110; SDFNetwork with multires 0, model/neus_model.py:312-417):
@@ -249,9 +149,6 @@ int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
  *         the one-hot block is synthesised in registers -> Y[M,2].
  * Wp packed [K0P->512, 512->512 x2, 512->N3P, 528->512 (cols [lin3 | input]), 512->512 x3, 512->16]. */
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
-/* Split-precision (f16x3) form: Wp = the nine layers packed by rb_pack_layer_h3 (skip layer k_pad 544). */
-int rb_cesr_net_h3(const float* X, long M, int kind, int n_label, const float* Wp, int scale_log2, float* Y,
-                   rb_stream_t stream);
 /* SparseAE (model/sg_envmap_material.py:40-99): encoder X[M,64] -> raw latent[M,32]
  * (packed [64->512, 512->512 x3, 512->32]); latent = act(raw*(1-var)) [+ lat2 = latent + noise*noise_scale];
  * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus. */
@@ -273,10 +170,8 @@ int rb_axpy(const float* a, const float* b, float s, long n, float* y, rb_stream
  *   (rb_linear_64_256), Whid = packed [256->256 x3], wlast[2,256], blast[2] row-major; chunk_id[n] int32 or NULL.
  *   vis_out[n,L] (the reference returns the transpose [L,n]); eval_count (may be NULL) += surviving (p,d) pairs.
  *   precision 0: hidden layers on the f32-input MFMA (exact fp32 fma chain), Whid from rb_pack_layer;
- *   precision 5: split-precision f16x3 (x*w = xh*wh + xh*wl + xl*wh on v_mfma_f32_16x16x32_f16, fp32 accumulate,
- *                |error| ~ 2^-22 relative), Whid from rb_pack_layer_h3 with the same scale_log2: the first-generation kernel
- *                (1 tile per wave, 2 workgroups per CU, LDS-DMA weight ring), kept as the independent implementation the
- *                later generations are tested against.  The production paths are rb_dvis_fused_x6 / rb_dvis_fused_v2 below.
+ *   precision 5: the first-generation split-precision kernel -- legacy library only (include/robir_hip_legacy.h).
+ * The production path is rb_dvis_fused_x6t / rb_dvis_stream_x6 below.
  * ------------------------------------------------------------------------------------------------------------ */
 int rb_dvis_dirs(const float* lgt, int L, int nsamp, int C, int direct, const float* u_theta, const float* u_phi, float thr,
                  float* dirs, float* wdir, float* wsum, rb_stream_t stream);
@@ -291,30 +186,25 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
  *   minimum: the reference's batch-global sharpness.min()), dirs[n*nsamp,3], wts[n*nsamp], front[n*nsamp] (uint8).
  * rb_spec_vis_reduce: logits[n*nsamp,2] of the visibility MLP -> bvis[n]; inv: use softmax[...,0] (indirect pass).
  * ------------------------------------------------------------------------------------------------------------ */
-/* Second-generation kernel of the same stage (csrc/vis_diffuse_v2.hip): W49 = the three hidden layers and the 256->2 output
- * layer (rows padded to 16) packed by rb_pack_layer_h3 back to back = 49 chunks; two sample tiles per wave, one workgroup
- * per CU, output layer on the matrix pipe.  Same arguments and results (to fp32 rounding of the output layer). */
-int rb_dvis_fused_v2(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
-                     const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
-                     float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* The same stage with EXACT fp32 operands on the f16 matrix pipe ("f16x6", csrc/vis_diffuse_x6.hip): every operand as three
- * halves (h + m 2^-11 + l 2^-22 = the fp32 value exactly), the six partial products of weight >= 2^-22 in three fp32
- * accumulators by weight class -- not narrower than the reference's fp32 (VisNetwork, model/implicit_differentiable_renderer.py:
- * 241-258 evaluated by nn.Linear in fp32).  W49 = the same 49 chunks packed by rb_pack_layer_x6.  Same arguments as
- * rb_dvis_fused_v2; vis_out agrees with precision 0 of rb_dvis_fused to fp32 summation order. */
-int rb_dvis_fused_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
-                     const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
-                     float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* rb_dvis_fused_x6 with TWO 16-sample tiles per wave (csrc/vis_diffuse_x6t.hip, round 4): a weight fragment read from the LDS feeds
- * both tiles and a pass of the weights serves 128 samples.  Same arguments, same arithmetic (three-piece operands, six products, one
- * fp32 accumulator per weight class); the products of a class are summed half-chunk by half-chunk, so vis_out agrees with
- * rb_dvis_fused_x6 to fp32 summation order, not bit for bit. */
+/* The light-visibility stage with EXACT fp32 operands on the f16 matrix pipe ("f16x6", csrc/vis_diffuse_x6t.hip + x6t_engine.h; the
+ * DEFAULT and bench.py's headline kernel): every operand as three halves (h + m 2^-11 + l 2^-22 = the fp32 value exactly), the six
+ * partial products of weight >= 2^-22 in three fp32 accumulators by weight class -- not narrower than the reference's fp32
+ * (VisNetwork, model/implicit_differentiable_renderer.py:241-258, evaluated by nn.Linear in fp32).  W49 = the three hidden layers and
+ * the 256->2 output layer (rows padded to 16) packed by rb_pack_layer_x6 back to back = 49 chunks; scale_log2 = 0.  One workgroup of
+ * four waves per point, TWO 16-sample tiles per wave (a weight fragment read from the LDS feeds both tiles, a pass of the weights
+ * serves 128 samples), output layer on the matrix pipe.  Other arguments as rb_dvis_fused; vis_out agrees with its precision 0 to
+ * fp32 summation order. */
 int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                       const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                       float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* rb_dvis_stream (below) on the arithmetic and the two-tile machine of rb_dvis_fused_x6t: cull, a persistent grid over the global
- * tile list (eight 16-sample tiles per round, whatever point they belong to), per-lobe reduce.  Same arguments and scratch as
- * rb_dvis_stream; every pair goes through rb_dvis_fused_x6t's instruction sequence: vis_out is bit-identical to it. */
+/* The same arithmetic as THREE launches on `stream` (the form for launches up to ~8192 points, e.g. one 1024-pixel chunk):
+ *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
+ *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point
+ *             they belong to (balanced over the CUs for any n; the tile count is read from device memory: no host sync);
+ *   reduce    one workgroup per point: SG-weighted mean per lobe in the fixed sample order.
+ * Every pair goes through rb_dvis_fused_x6t's instruction sequence: vis_out is bit-identical to it.  Caller-provided scratch (device):
+ *   pair_j[n*L*nsamp] u16, pair_vis[n*L*nsamp] f32, tile_info[n*L*nsamp/16][2] i32, point_info[n][2] i32, counters[2] u64.
+ * L*nsamp must be a multiple of 16 (other shapes: rb_dvis_fused_x6t). */
 int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                       const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                       unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
@@ -327,22 +217,10 @@ int rb_dvis_stream_f16(const float* normals, const int* chunk_id, long n, const 
                        const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                        unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
                        int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* Third generation of the same stage (csrc/vis_diffuse_v3.hip): three launches on `stream` --
- *   cull      one workgroup per point: n.d > 1e-6 survivors compacted into a global list of 16-sample tiles;
- *   stream    a PERSISTENT grid (n_workgroups; <= 0: one per CU) walks the tile list eight tiles per round, whatever point
- *             they belong to (balanced over the CUs for any n; the tile count is read from device memory: no host sync);
- *   reduce    one workgroup per point: SG-weighted mean per lobe in the fixed sample order.
- * Per pair the instruction sequence is that of rb_dvis_fused_v2: vis_out is bit-identical.  Caller-provided scratch (device):
- *   pair_j[n*L*nsamp] u16, pair_vis[n*L*nsamp] f32, tile_info[n*L*nsamp/16][2] i32, point_info[n][2] i32, counters[2] u64.
- * L*nsamp must be a multiple of 16. */
-int rb_dvis_stream(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
-                   const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
-                   unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
-                   int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* ------------------------------------------------------------------------------------------------------------
  * Traced light visibility -- OctreeVisModel (model/octree_tracing.py:63-85) as the VisModel of get_diffuse_visibility
  * (model/sg_render.py:111-195), the mode `trace_vis` switches on (training/train_pbr.py:409-410): csrc/octree_vis.hip.
- * rb_dvis_octree: same inputs / vis_out[n,L] as rb_dvis_fused_v2 with points[n,3] instead of the MLP rows and the octree
+ * rb_dvis_octree: same inputs / vis_out[n,L] as rb_dvis_fused_x6t with points[n,3] instead of the MLP rows and the octree
  *   tables of rb_octree_cast_*; the surviving (point, direction) pairs of each chunk, in the reference's order, are traced in
  *   lock-step batches of `batch_pairs` (reference: 2 000 000, sg_render.py:158) with max_iter (32) -- per batch the step size
  *   (0.01 beyond 100 000 rays, else 0.005) and the per-iteration fine-march count follow utils/octree.py:542-549.
@@ -378,10 +256,6 @@ int rb_octree_cast_grouped(const float* node, const float* nrm, long B, const fl
                            int max_iter, float clamp_dt, long* gsize, int* grp, float* t_st, int* leaf_st,
                            unsigned char* act_st, int* counters, float* x_out, unsigned char* hit_out, float* t_out,
                            rb_stream_t stream);
-/* Profiling aid: with RB_V2_TIMED=1 in the environment rb_dvis_fused_v2 runs an instrumented build that accumulates
- * shader-clock totals of wave 0 per phase (prologue, ring start, row gather, hidden layers, head, final reduction);
- * this call copies the six totals to out8[0..5] and clears them.  Returns non-zero on a HIP error. */
-int rb_dvis_v2_debug(unsigned long long* out8);
 int rb_spec_vis_sample(const float* normal, const float* view, const float* rough, const int* chunk_id, long n,
                        int n_chunks, int nsamp, const float* u_theta, const float* u_phi, float* sharp,
                        unsigned* chunk_min, float* dirs, float* wts, unsigned char* front, rb_stream_t stream);
@@ -592,5 +466,8 @@ int rb_exr_piz_decode(const unsigned char* src, long n_src, const int* chan, int
 
 #ifdef __cplusplus
 }
+#endif
+#ifdef RB_LEGACY        /* the legacy library is a superset: its translation units see both sets of prototypes */
+#include "robir_hip_legacy.h"
 #endif
 #endif /* ROBIR_HIP_H */

@@ -24,32 +24,71 @@ class RobirHipError(RuntimeError):
     pass
 
 
-def build(verbose=False):
-    """Compile every HIP translation unit for gfx950 and link librobir_hip.so in-tree."""
+LEGACY_PATH = os.path.join(_HERE, "librobir_hip_legacy.so")
+_legacy = None
+ABI_VERSION = 6
+
+
+def build(verbose=False, legacy=True):
+    """Compile every HIP translation unit for gfx950 and link, in-tree, librobir_hip.so (the default library) and -- legacy=True --
+    librobir_hip_legacy.so (the superset with the retired kernel generations, csrc/Makefile)."""
     jobs = str(min(8, os.cpu_count() or 1))
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j", jobs], capture_output=not verbose, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j", jobs, "all" if legacy else "default"],
+                       capture_output=not verbose, text=True)
     if r.returncode != 0:
         raise RobirHipError("building librobir_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
     return LIB_PATH
 
 
+def _load(path, what):
+    if not os.path.exists(path):
+        raise RobirHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` " + what)
+    L = ctypes.CDLL(path)
+    L.rb_last_error.restype = ctypes.c_char_p
+    for name in ("rb_packed_layer_floats", "rb_packed_layer_x6_floats", "rb_sdf_value_grad_scratch_floats",
+                 "rb_sdf_value_grad_f32_scratch_floats"):
+        if hasattr(L, name):
+            getattr(L, name).restype = ctypes.c_long
+    if L.rb_abi_version() != ABI_VERSION:
+        raise RobirHipError(f"{os.path.basename(path)} ABI version mismatch")
+    return L
+
+
 def lib():
+    """The default library (include/robir_hip.h): everything the `exact` / `f16` policies and the fp32 override run."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RobirHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                                "(robir_amd has no CPU fallback)")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.rb_last_error.restype = ctypes.c_char_p
-        _lib.rb_packed_layer_floats.restype = ctypes.c_long
-        _lib.rb_packed_layer_x6_floats.restype = ctypes.c_long
-        _lib.rb_sdf_value_grad_scratch_floats.restype = ctypes.c_long
-        _lib.rb_sdf_value_grad_f32_scratch_floats.restype = ctypes.c_long
-        if _lib.rb_abi_version() != 5:
-            raise RobirHipError("librobir_hip.so ABI version mismatch")
-        if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
-            _lib.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))
+        _lib = _load(LIB_PATH, "(robir_amd has no CPU fallback)")
     return _lib
+
+
+def legacy():
+    """The legacy library (include/robir_hip_legacy.h; `make -C robir_amd/csrc legacy`): loaded the first time a retired entry point is
+    called -- ROBIR_PRECISION=split, ROBIR_SDF_FUSED_PE=0, the tests that compare kernel generations.  Its own copy of the process-wide
+    state (range sentinel block, device caches)."""
+    global _legacy
+    if _legacy is None:
+        _legacy = _load(LEGACY_PATH, "(the split-precision family and the other retired kernel generations live in the LEGACY library; the "
+                                     "default policy ROBIR_PRECISION=exact does not need it)")
+        if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the split SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
+            _legacy.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))
+    return _legacy
+
+
+def legacy_loaded():
+    return _legacy is not None
+
+
+def resolve(name):
+    """(library, function) of an entry point: the default library if it exports `name`, else the legacy one."""
+    L = lib()
+    fn = getattr(L, name, None)
+    if fn is None:
+        L = legacy()
+        fn = getattr(L, name, None)
+        if fn is None:
+            raise RobirHipError(f"{name} is exported by neither librobir_hip.so nor librobir_hip_legacy.so")
+    return L, fn
 
 
 def stream_ptr():
@@ -63,8 +102,16 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def call_legacy(name, *args):
+    """An entry point of the LEGACY library even where the default one exports the same name (rb_dvis_fused with precision 5)."""
+    L = legacy()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RobirHipError(f"{name} failed ({rc}): {L.rb_last_error().decode()}")
+
+
 def call(name, *args):
-    fn = getattr(lib(), name)
+    L, fn = resolve(name)
     rc = fn(*args)
     if rc != 0:
-        raise RobirHipError(f"{name} failed ({rc}): {lib().rb_last_error().decode()}")
+        raise RobirHipError(f"{name} failed ({rc}): {L.rb_last_error().decode()}")

@@ -1012,6 +1012,7 @@ int rb_pack_layer(const float* W, const float* b, int n_out, int k_in, int n_pad
   return check_launch("k_pack_layer");
 }
 
+#ifdef RB_LEGACY
 int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_pad, int k_pad, const int* perm,
                      int scale_log2, float* out, rb_stream_t stream) {
   RB_REQUIRE(W && out, "null pointer");
@@ -1024,6 +1025,7 @@ int rb_pack_layer_h3(const float* W, const float* b, int n_out, int k_in, int n_
                      perm, ldexpf(1.0f, scale_log2), out);
   return check_launch("k_pack_layer_h3");
 }
+#endif  // RB_LEGACY
 
 long rb_packed_layer_x6_floats(int n_pad, int k_pad) { return (long)(n_pad / 16) * (16 + (long)k_pad * 24); }
 
@@ -1040,6 +1042,7 @@ int rb_pack_layer_x6(const float* W, const float* b, int n_out, int k_in, int n_
   return check_launch("k_pack_layer_x6");
 }
 
+#ifdef RB_LEGACY
 int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(p && d && X, "null pointer");
@@ -1049,6 +1052,7 @@ int rb_feat_vis(const float* p, const float* d, long M, int rep, float* X, rb_st
                      rep, X);
   return check_launch("k_feat_vis");
 }
+#endif  // RB_LEGACY
 
 int rb_feat_pe10(const float* x, long M, float scale, const float* extra, int jvp, float* X, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -1068,6 +1072,7 @@ int rb_feat_ipe(const float* x, long M, float var, const float* noise, float noi
   return check_launch("k_feat_ipe");
 }
 
+#ifdef RB_LEGACY
 int rb_feat_color(const float* x, float x_scale, const float* view, const float* normal, const float* feat,
                   long feat_stride, float feat_scale, long M, float* X, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -1090,6 +1095,7 @@ int rb_vis_mlp(const float* X, long M, const float* Wp, float* logits, rb_stream
   hipLaunchKernelGGL(k_vis_mlp<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, logits, nullptr, 1);
   return check_launch("k_vis_mlp");
 }
+#endif  // RB_LEGACY
 
 int rb_vis_mlp_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -1099,12 +1105,14 @@ int rb_vis_mlp_points(const float* p, const float* d, long M, int rep, const flo
   return check_launch("k_vis_mlp<points>");
 }
 
+#ifdef RB_LEGACY
 int rb_linear_64_256(const float* X, long M, const float* Wp, float* Y, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && Y, "null pointer");
   hipLaunchKernelGGL(k_linear_64_256<false>, grid1d(M, 128), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, Y);
   return check_launch("k_linear_64_256");
 }
+#endif  // RB_LEGACY
 
 int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -1113,6 +1121,7 @@ int rb_linear_pe10_256(const float* x, long M, const float* Wp, float* Y, rb_str
   return check_launch("k_linear_64_256<points>");
 }
 
+#ifdef RB_LEGACY
 int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scale, float grad_scale, float* out0,
                float* grad, rb_stream_t stream) {
   if (M <= 0) return 0;
@@ -1133,6 +1142,7 @@ int rb_sdf_mlp(const float* X, long M, const float* Wp, int mode, float out_scal
   }
   return check_launch("k_sdf_mlp");
 }
+#endif  // RB_LEGACY
 
 int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float grad_scale,
                       float* out0, float* grad, rb_stream_t stream) {
@@ -1155,6 +1165,7 @@ int rb_sdf_mlp_points(const float* x, long M, float in_scale, const float* Wp, i
   return check_launch("k_sdf_mlp<points>");
 }
 
+#ifdef RB_LEGACY
 int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && rgb, "null pointer");
@@ -1162,6 +1173,7 @@ int rb_color_mlp(const float* X, long M, const float* Wp, float* rgb, rb_stream_
                      nullptr, 1.0f, nullptr, nullptr);
   return check_launch("k_color_mlp");
 }
+#endif  // RB_LEGACY
 
 int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
                         const float* normal, long M, const float* Wp, float* rgb, rb_stream_t stream) {
@@ -1172,12 +1184,14 @@ int rb_color_mlp_points(const float* feat, long feat_stride, float feat_scale, c
   return check_launch("k_color_mlp<points>");
 }
 
+#ifdef RB_LEGACY
 int rb_illum_mlp(const float* X, long M, const float* Wp, float* raw, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(X && Wp && raw, "null pointer");
   hipLaunchKernelGGL(k_wide_mlp<false>, grid1d(M, 64), dim3(256), 0, (hipStream_t)stream, X, M, (const f4*)Wp, raw);
   return check_launch("k_wide_mlp<illum>");
 }
+#endif  // RB_LEGACY
 
 int rb_wide_mlp_points(const float* x, const float* extra, long M, const float* Wp, int encoder, float* Y, rb_stream_t stream) {
   if (M <= 0) return 0;

@@ -527,10 +527,12 @@ __global__ void k_pe_grad_points(const float* __restrict__ gfeat, const float* _
 
 using namespace rb;
 
+#ifdef RB_LEGACY
 extern "C" long rb_sdf_value_grad_scratch_floats(long M) {
   const long rounds = (M + 127) / 128;
   return rounds * (SB_SIG_ROUND_F4 * 4 + 128L * 128);
 }
+#endif  // RB_LEGACY
 
 // X != nullptr: feature rows; X == nullptr: points xyz[M,3] x in_scale with the encoding fused into the value pass
 static int sdf_value_grad_impl(const float* X, const float* xyz, float in_scale, long M, const float* Wp, const float* Wb,
@@ -653,6 +655,7 @@ extern "C" int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_sca
   return check_launch("k_pe_grad_points");
 }
 
+#ifdef RB_LEGACY
 extern "C" int rb_sdf_value_grad(const float* X, long M, const float* Wp, const float* Wb, const float* w8row, int scale_log2,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int n_workgroups,
                                  rb_stream_t stream) {
@@ -668,3 +671,4 @@ extern "C" int rb_sdf_value_grad_points(const float* x, long M, float in_scale, 
   return sdf_value_grad_impl(nullptr, x, in_scale, M, Wp, Wb, w8row, scale_log2, out_scale, grad_scale, out0, grad, scratch,
                              n_workgroups, stream);
 }
+#endif  // RB_LEGACY

@@ -278,6 +278,9 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                        Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis, 1.0f, vis_out, eval_count,
                        (unsigned*)nullptr);
   } else {
+#ifndef RB_LEGACY
+    return rb::fail(__func__, "precision 5 (first-generation split-precision kernel) is built into librobir_hip_legacy.so only (make legacy)");
+#else
 #define RB_LAUNCH_H3(CH, NT, ...)                                                                                     \
   hipLaunchKernelGGL((k_dvis_fused<true, CH, NT, ##__VA_ARGS__>), dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, normals, chunk_id, \
                      n, A, Bd, dirs, wdir, wsum, (const f4*)Whid, wlast, blast, L, nsamp, argmax_vis,                  \
@@ -285,6 +288,7 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
                      range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr)
     RB_LAUNCH_H3(2, 1, true);   // one tile per wave, two workgroups per CU, weights staged by LDS-DMA (global_load_lds)
 #undef RB_LAUNCH_H3
+#endif
   }
   return check_launch("k_dvis_fused");
 }

@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
   }
 }
 
-// the cull / per-lobe reduce passes around the stream form: precision-agnostic, shared with the split-precision family (vis_diffuse_v3.hip)
+// the cull / per-lobe reduce passes around the stream form: precision-agnostic (dvis_tiles.hip), shared with the legacy split-precision family
 struct V3Tile;
 __global__ void k_dvis3_cull(const float* __restrict__ normals, const int* __restrict__ cid, long n, const float* __restrict__ dirs, int LS,
                              unsigned short* __restrict__ pair_j, V3Tile* __restrict__ tile_info, int2* __restrict__ point_info,

@@ -24,11 +24,17 @@ RANGE_FAMILIES = ("light-visibility kernel (rb_dvis_fused*)", "visibility MLP (r
 def range_check(sync=False):
     """Raise RobirHipError if a split-precision or exact-operand kernel saw an activation beyond the f16 range of its leading operand piece
     (include/robir_hip.h: rb_range_check).  sync=False costs nothing and reports kernels that have completed; sync=True waits
-    for the current stream first."""
+    for the current stream first.  The legacy library keeps its own sentinel block: read too once it has been loaded."""
     mask = ctypes.c_uint(0)
     call("rb_range_check", c_int(1 if sync else 0), stream_ptr(), ctypes.byref(mask))
-    if mask.value:
-        fams = [RANGE_FAMILIES[i] for i in range(len(RANGE_FAMILIES)) if mask.value >> i & 1]
+    bits = mask.value
+    if _lib.legacy_loaded():
+        rc = _lib.legacy().rb_range_check(c_int(0), stream_ptr(), ctypes.byref(mask))      # the stream has been waited for above
+        if rc != 0:
+            raise _lib.RobirHipError(f"rb_range_check (legacy library) failed ({rc})")
+        bits |= mask.value
+    if bits:
+        fams = [RANGE_FAMILIES[i] for i in range(len(RANGE_FAMILIES)) if bits >> i & 1]
         raise _lib.RobirHipError(
             "f16-piece arithmetic (split precision f16x3 / exact operands f16x6) overflowed its activation range in: " + "; ".join(fams) + " -- the outputs of "
             "the call(s) since the last check are not fp32-accurate.  Select the exact f32-input MFMA kernels for this "
@@ -304,7 +310,7 @@ def release_scratch():
 
 def sdf_ring_waves():
     """Current setting of rb_sdf_ring_waves (8 = csrc/sdf_ring8.hip, 4 = csrc/sdf_ring.hip) without changing it."""
-    return int(_lib.lib().rb_sdf_ring_waves(0))
+    return int(_lib.legacy().rb_sdf_ring_waves(0))
 
 
 def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
@@ -315,7 +321,7 @@ def sdf_value_grad(x, M, blob, back, scale_log2, in_scale=1.0, out_scale=1.0):
     if M == 0:
         return out0, grad
     slab = min(M, SDF_GRAD_SLAB)
-    need = int(_lib.lib().rb_sdf_value_grad_scratch_floats(c_long(slab)))
+    need = int(_lib.legacy().rb_sdf_value_grad_scratch_floats(c_long(slab)))
     key = (x.device, torch.cuda.current_stream().cuda_stream)
     scratch = _sdf_grad_scratch.get(key)
     if scratch is None or scratch.numel() < need:
@@ -583,7 +589,8 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
              ptr(split["hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
              c_int(split["h3_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
-    call("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+    # precision 5 = the first-generation split-precision kernel: compiled into the legacy library only
+    (_lib.call_legacy if h3 else call)("rb_dvis_fused", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
          ptr(split["hidden_h3"] if h3 else split["hidden"]), ptr(split["w_last"]), ptr(split["b_last"]), c_int(L),
          c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(5 if h3 else 0), c_int(split["h3_scale_log2"] if h3 else 0),
          ptr(out), ptr(eval_count), stream_ptr())

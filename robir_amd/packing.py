@@ -150,17 +150,33 @@ def pack_vis_split(sd, device):
     hl = [dict(W=_t(sd, VIS + "%d.weight" % (2 * i)), b=_t(sd, VIS + "%d.bias" % (2 * i)), n_pad=256, k_pad=256)
           for i in (1, 2, 3)]
     hid = pack_layers(hl, device)
-    hid_h3 = pack_layers_h3(hl, device)
     w_last = _t(sd, VIS + "8.weight").to(device=device, dtype=torch.float32).contiguous()      # [2,256]
     b_last = _t(sd, VIS + "8.bias").to(device=device, dtype=torch.float32).contiguous()        # [2]
-    # 49 chunks: hidden stack + the output layer as one more 16-row chunk (rb_dvis_fused_v2)
-    hid_h3_head = pack_layers_h3(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device)
-    # the same 49 chunks with every weight as three halves (rb_dvis_fused_x6: exact fp32 operands on the f16 MFMA)
-    x6_scale = 0         # the m / l pieces carry their own 2^11 / 2^22: no lift needed (csrc/vis_diffuse_x6.hip)
+    # 49 chunks: hidden stack + the output layer as one more 16-row chunk, every weight as three halves (rb_dvis_fused_x6t: exact fp32
+    # operands on the f16 MFMA); the m / l pieces carry their own 2^11 / 2^22: no lift needed
+    x6_scale = 0
     hid_x6_head = pack_layers_x6(hl + [dict(W=w_last, b=b_last, n_pad=16, k_pad=256)], device, scale_log2=x6_scale)
-    return dict(point=wp, dir=wd, hidden=hid, hidden_h3=hid_h3, hidden_h3_head=hid_h3_head, h3_scale_log2=H3_SCALE_LOG2,
-                hidden_x6_head=hid_x6_head, x6_head_scale_log2=x6_scale,
-                h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last)
+    return _VisSplit(dict(point=wp, dir=wd, hidden=hid, h3_scale_log2=H3_SCALE_LOG2, hidden_x6_head=hid_x6_head, x6_head_scale_log2=x6_scale,
+                          h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last), hl, device)
+
+
+class _VisSplit(dict):
+    """pack_vis_split's blobs; the split-precision ones (`hidden_h3`: the hidden stack, `hidden_h3_head`: the 49 chunks of
+    rb_dvis_fused_v2 / rb_dvis_stream) are packed by the LEGACY library on first use -- the default policy never asks for them."""
+
+    def __init__(self, d, hl, device):
+        super().__init__(d)
+        self._hl, self._device = hl, device
+
+    def __missing__(self, k):
+        if k == "hidden_h3":
+            v = pack_layers_h3(self._hl, self._device)
+        elif k == "hidden_h3_head":
+            v = pack_layers_h3(self._hl + [dict(W=self["w_last"], b=self["b_last"], n_pad=16, k_pad=256)], self._device)
+        else:
+            raise KeyError(k)
+        self[k] = v
+        return v
 
 
 def pack_sdf(sd, device, full=True):

@@ -9,18 +9,33 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _header_symbols(name):
+    hdr = open(os.path.join(ROOT, "include", name)).read()
+    return sorted(set(re.findall(r"^(?:int|long|const char\*) (rb_[a-z0-9_]+)\s*\(", hdr, re.M)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if " T rb_" in l)
+
+
 def test_library_exports_header_symbols():
+    """The default library exports exactly what include/robir_hip.h declares (ABI version 6: 85 entry points -- the retired kernel
+    generations left it in round 5), the legacy library exactly that plus include/robir_hip_legacy.h."""
     from robir_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LEGACY_PATH)):
         _lib.build()
     L = _lib.lib()
-    assert L.rb_abi_version() == 5
-    hdr = open(os.path.join(ROOT, "include", "robir_hip.h")).read()
-    syms = sorted(set(re.findall(r"\b(rb_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(syms) >= 40
-    missing = [s for s in syms if not hasattr(L, s)]
-    assert not missing, missing
+    assert L.rb_abi_version() == 6
+    syms, leg = _header_symbols("robir_hip.h"), _header_symbols("robir_hip_legacy.h")
+    assert 40 <= len(syms) <= 90 and len(leg) >= 30 and not set(syms) & set(leg)
+    assert _exported(_lib.LIB_PATH) == syms                                      # nothing missing, nothing undeclared, nothing legacy
+    assert _exported(_lib.LEGACY_PATH) == sorted(syms + leg)                     # the superset
+    assert _lib.legacy().rb_abi_version() == 6
     assert L.rb_packed_layer_floats(256, 256) == 16 * (16 + 256 * 16)
+    # a retired entry point resolves to the legacy library, a current one to the default library
+    assert _lib.resolve("rb_dvis_fused_v2")[0] is _lib.legacy() and _lib.resolve("rb_dvis_fused_x6t")[0] is L
 
 
 def test_error_reporting_without_gpu():
@@ -28,9 +43,11 @@ def test_error_reporting_without_gpu():
     import ctypes
     from robir_amd import _lib
     L = _lib.lib()
-    rc = L.rb_vis_mlp(ctypes.c_void_p(0), ctypes.c_long(8), ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_void_p(0))
+    rc = L.rb_vis_mlp_points(ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_long(8), ctypes.c_int(1), ctypes.c_void_p(0), ctypes.c_void_p(0),
+                             ctypes.c_void_p(0))
     assert rc != 0 and b"null pointer" in L.rb_last_error()
-    assert L.rb_vis_mlp(ctypes.c_void_p(0), ctypes.c_long(0), ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_void_p(0)) == 0
+    assert L.rb_vis_mlp_points(ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_long(0), ctypes.c_int(1), ctypes.c_void_p(0), ctypes.c_void_p(0),
+                               ctypes.c_void_p(0)) == 0
 
 
 def test_no_oracle_import_in_product():
@@ -66,6 +83,10 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.RobirHipError):
         _lib.lib()
+    monkeypatch.setattr(_lib, "_legacy", None)
+    monkeypatch.setattr(_lib, "LEGACY_PATH", str(tmp_path / "nope_legacy.so"))
+    with pytest.raises(_lib.RobirHipError, match="LEGACY library"):
+        _lib.legacy()
 
 
 def test_mlp_precision_switch(monkeypatch):

@@ -284,7 +284,8 @@ def test_round3_second_half_entry_points_on_empty_tiny_and_bad_inputs(dev, synth
             ("rb_sdf_x6_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_float(1.0), ops.ptr(x6f), ctypes.c_int(3), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_int(0), nul)),
             ("rb_color_x6_points", (nul, ctypes.c_long(257), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_float(1.0), ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ops.ptr(col6), ops.ptr(y), ctypes.c_int(0), nul)),
             ("rb_octree_cast_coop", (nul,) * 6 + (ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ctypes.c_int(32), ctypes.c_double(0.005), ctypes.c_int(64), ctypes.c_float(0.1)) + (nul,) * 9)):
-        assert getattr(L, name)(*args) != 0, name
+        L, fn = _lib.resolve(name)                # the default library, or the legacy one for a retired entry point
+        assert fn(*args) != 0, name
         assert b"null pointer" in L.rb_last_error() or b"kind" in L.rb_last_error() or b"n_label" in L.rb_last_error() or b"mode" in L.rb_last_error(), (name, L.rb_last_error())
     # rb_scatter_rows
     idx = torch.tensor([5, 0, 3], device=dev)

@@ -272,7 +272,7 @@ def test_sdf_value_kernels_eight_and_four_waves_agree(dev, synth_weights):
     full = packing.pack_sdf_h3(synth_weights, dev, full=True)
     dist = packing.pack_sdf_h3(synth_weights, dev, full=False)
     back = packing.pack_sdf_back_h3(synth_weights, dev)
-    L = _lib.lib()
+    L = _lib.legacy()                 # the split-precision SDF kernels live in the legacy library
     res = {}
     try:
         for waves in (8, 4):
