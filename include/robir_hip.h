@@ -88,22 +88,17 @@ int rb_feat_ipe(const float* x, long M, float var, const float* noise, float noi
  * x in_scale), Wp = the host mirror's packing.pack_sdf_x6(full = mode); mode 0: out0 [M] signed distances, 1: out0 [M,257].
  * rb_sdf_value_grad_x6_points: rb_sdf_value_grad_f32_points with that value pass and the pass over the transposed layers on exact
  * operands too (csrc/sdf_back_x6.hip; Wt / w8row = packing.pack_sdf_back_x6; same scratch). */
-int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
-                     rb_stream_t stream);
-/* rb_sdf_x6_points with TWO 16-row tiles per wave (csrc/sdf_x6t.hip + x6t_engine.h, round 4): a weight fragment read from the LDS feeds
- * two MFMAs per product, a pass of the weights serves 128 rows.  Same arguments, same blob, same arithmetic (the products of a class are
- * summed part by part: results agree with rb_sdf_x6_points to fp32 summation order).  The host mirror takes it where it
- * needs fewer than two thirds of the one-tile form's passes over the persistent grid (16385-32768 rows, > 49152 rows on 256 compute
- * units); elsewhere the one-tile kernel's rounds of 64 rows fill the chip better. */
-int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
-                      rb_stream_t stream);
-/* The colour net on exact three-piece operands (csrc/color_x6.hip; Wp = packing.pack_color_x6): the arguments of rb_color_mlp_points. */
+/* two_tile = 0: one 16-row tile per wave, rounds of 64 rows (csrc/sdf_x6.hip); 1: TWO tiles per wave (csrc/sdf_x6t.hip + x6t_engine.h,
+ * round 4): a weight fragment read from the LDS feeds two MFMAs per product, a pass of the weights serves 128 rows -- same blob, same
+ * arithmetic, the products of a class summed part by part: the two forms agree to fp32 summation order, each with itself bit for bit.
+ * The host mirror takes the two-tile form where it needs fewer than two thirds of the one-tile form's passes over the persistent grid
+ * (16385-32768 rows, > 49152 rows on 256 compute units: ops.sdf_two_tile); elsewhere rounds of 64 rows fill the chip better. */
+int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int two_tile,
+                     int n_workgroups, rb_stream_t stream);
+/* The colour net on exact three-piece operands (csrc/color_x6.hip; two_tile = 1: csrc/color_x6t.hip, as above; Wp = packing.pack_color_x6):
+ * the arguments of rb_color_mlp_points. */
 int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                       const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
-/* rb_color_x6_points with TWO 16-row tiles per wave (csrc/color_x6t.hip + x6t_engine.h, round 4): same arguments, same blob, results agree
- * with rb_color_x6_points to fp32 summation order.  The host mirror takes it by the same rule. */
-int rb_color_x6t_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                        const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream);
+                       const float* normal, long M, const float* Wp, float* rgb, int two_tile, int n_workgroups, rb_stream_t stream);
 /* The visibility MLP on exact three-piece operands (csrc/vis_x6.hip; Wp = packing.pack_vis_x6): the arguments of rb_vis_mlp_points. */
 int rb_vis_x6_points(const float* p, const float* d, long M, int rep, const float* Wp, float* logits, int n_workgroups, rb_stream_t stream);
 /* The 512-wide ReLU nets (SparseAE encoder: raw latent [M,32]; indirect-illumination decoder: raw SG outputs [M,144]) on exact
@@ -113,12 +108,11 @@ int rb_wide_x6(const float* X /* feature rows [M,64] */, long M, const float* Wp
 /* The CESR nets on exact three-piece operands (csrc/cesr_x6.hip; Wp = packing.pack_softplus512_x6): the arguments of rb_cesr_net_points
  * (kind 0: normal_net on PE10(x), 2: shadow_net on (point, one-hot label) rows). */
 int rb_cesr_net_x6_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, int n_workgroups, rb_stream_t stream);
+/* two_tile = 1: two tiles per wave in the value and the reverse pass (csrc/sdf_x6t.hip, sdf_back_x6t.hip); Wt then = the transposed layers
+ * packed with W3^T's K padded to 256 (packing.pack_sdf_back_x6(two_tile=True)).  Same scratch. */
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
-                                float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
-/* ... with two tiles per wave in the value and the reverse pass (csrc/sdf_x6t.hip, sdf_back_x6t.hip); Wt = the transposed layers packed
- * with W3^T's K padded to 256 (packing.pack_sdf_back_x6(two_tile=True)).  Same scratch. */
-int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
-                                 float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
+                                float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int two_tile,
+                                rb_stream_t stream);
 long rb_sdf_value_grad_f32_scratch_floats(long M);
 int rb_sdf_value_grad_f32_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
                                  float out_scale, float grad_scale, float* out0, float* grad, float* scratch, rb_stream_t stream);
@@ -234,23 +228,17 @@ int rb_dvis_stream_f16(const float* normals, const int* chunk_id, long n, const 
  *   separate rb_octree_cast_* call with max_iter.  Outputs as OctreeTracing.forward.  Scratch: gsize[G] i64, grp[R] i32,
  *   t_st[R] f32, leaf_st[R] i32, act_st[R] u8, counters[34*G] i32.
  * ------------------------------------------------------------------------------------------------------------ */
+/* alive_a .. n_alive (all six non-NULL): the rays still active are compacted -- stably, by a prefix sum: list order = (point, direction)
+ * order -- between the lock-step iterations, so that an iteration reads and steps only live rays in full waves (all six NULL: the plain
+ * form, which walks every pair 33 times).  Bit-identical vis_out.  alive_a, alive_b int32[cap], flags uint8[cap + 8] (cap = size of pair_p,
+ * < 2^31), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[40] (list sizes + per-iteration cursors). */
 int rb_dvis_octree(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
                    const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
                    const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
                    int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
                    unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
-                   long* layout, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
-/* rb_dvis_octree with the rays still active compacted -- stably, by a prefix sum: list order = (point, direction) order -- between
- * the lock-step iterations, so that an iteration reads and steps only live rays in full waves (the plain form walks every pair 33
- * times).  Bit-identical vis_out.  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap + 8] (cap = size of pair_p,
- * < 2^31), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[2] (the two list sizes, ping-pong). */
-int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
-                           const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
-                           const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
-                           int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
-                           unsigned short* pair_j, float* t_st, int* leaf_st, unsigned char* act_st, int* grp, long* point_span,
-                           long* layout, int* alive_a, int* alive_b, unsigned char* flags, int* blk_cnt, long* blk_off, long* n_alive,
-                           float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+                   long* layout, int* alive_a, int* alive_b, unsigned char* flags, int* blk_cnt, long* blk_off, long* n_alive,
+                   float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 int rb_octree_cast_grouped(const float* node, const float* nrm, long B, const float* root_min, const float* root_size,
                            const int* res, const float* origins, const float* dirs, long R, const long* group_start, int G,
                            int max_iter, float clamp_dt, long* gsize, int* grp, float* t_st, int* leaf_st,
@@ -343,15 +331,13 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
 
 /* ------------------------------------------------------------------------------------------------------------
  * Ray generation / points / tone mapping.
- * rb_camera_rays: get_camera_params + lift, 4x4 pose (utils/rend_util.py:51-97).  pose_host: 16 floats row-major
- *   camera-to-world (HOST), K_host: 9 floats row-major intrinsics (HOST); uv[N,2] (x = column, y = row) -> dirs[N,3].
+ * rb_camera_rays_dev: get_camera_params + lift, 4x4 pose (utils/rend_util.py:51-97).  pose_dev: 16 floats row-major
+ *   camera-to-world, K_dev: 9 floats row-major intrinsics, both in DEVICE memory (no host copy on the per-chunk path);
+ *   uv[N,2] (x = column, y = row) -> dirs[N,3].
  * rb_points_along: pts = o + t*d (implicit_differentiable_renderer.py:324); origins [N/batch,3] or per ray.
  * rb_tonemap: ACESToneMapping hdr_mode 0 (model/color_correction.py:52-60,116-134): mode 0 hdr2ldr, 1 ldr2hdr,
  *   2 ldr2hdr(x^2.2); rows of 3 channels, shift[n] (stride 1) or one value (stride 0), clamped to [1e-4,1].
  * ------------------------------------------------------------------------------------------------------------ */
-int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv, long N, float* dirs,
-                   rb_stream_t stream);
-/* the same arithmetic with pose[16] / K[9] in DEVICE memory (no host copy on the per-chunk path) */
 int rb_camera_rays_dev(const float* pose_dev, const float* K_dev, const float* uv, long N, float* dirs, rb_stream_t stream);
 int rb_points_along(const float* origins, int per_ray_origin, long batch, const float* dirs, const float* t, long N,
                     float* pts, rb_stream_t stream);

@@ -289,9 +289,12 @@ __global__ __launch_bounds__(256, 1) void k_color_x6(const float* __restrict__ f
 using namespace rb;
 
 extern "C" int rb_color_x6_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                                  const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream) {
+                                  const float* normal, long M, const float* Wp, float* rgb, int two_tile, int n_workgroups,
+                                  rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
+  if (two_tile)      // two 16-row tiles per wave, rounds of 128 rows (color_x6t.hip): the form for launches that fill the grid
+    return rb::launch_color_x6t(feat, feat_stride, feat_scale, x, x_scale, view, normal, M, Wp, rgb, n_workgroups, (hipStream_t)stream);
   const int pg = persistent_grid((M + 63) / 64, n_workgroups);
   if (pg <= 0) return rb::fail(__func__, "device query failed");
   const unsigned grid = (unsigned)pg;

@@ -311,15 +311,14 @@ __global__ __launch_bounds__(256, 1) void k_color_x6t(const float* __restrict__ 
 
 }  // namespace rb
 
-using namespace rb;
-
-extern "C" int rb_color_x6t_points(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
-                                   const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, rb_stream_t stream) {
-  if (M <= 0) return 0;
-  RB_REQUIRE(feat && x && view && normal && Wp && rgb, "null pointer");
+namespace rb {
+// the two-tile form of rb_color_x6_points (color_x6.hip holds the entry point; arguments checked there)
+int launch_color_x6t(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                     const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, hipStream_t stream) {
   const int pg = persistent_grid((M + 127) / 128, n_workgroups);
-  if (pg <= 0) return rb::fail(__func__, "device query failed");
-  hipLaunchKernelGGL(k_color_x6t, dim3((unsigned)pg), dim3(256), 0, (hipStream_t)stream, feat, feat_stride, feat_scale, x, x_scale, view,
+  if (pg <= 0) return rb::fail("rb_color_x6_points", "device query failed");
+  hipLaunchKernelGGL(k_color_x6t, dim3((unsigned)pg), dim3(256), 0, stream, feat, feat_stride, feat_scale, x, x_scale, view,
                      normal, M, (const f4*)Wp, rgb, range_flags() ? range_flags() + RB_RANGE_COLOR : nullptr);
   return check_launch("k_color_x6t");
 }
+}  // namespace rb

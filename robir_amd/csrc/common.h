@@ -40,6 +40,8 @@ int launch_sdf_back_f32(const float* sig, long M, const float* Wt, const float* 
 int launch_sdf_back_x6(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s);                       // sdf_back_x6.hip
 int launch_sdf_x6_store(const float* x, long M, float in_scale, const float* Wp, float out_scale, float* out0, float* sig, hipStream_t s);   // sdf_x6.hip
 
+int launch_color_x6t(const float* feat, long feat_stride, float feat_scale, const float* x, float x_scale, const float* view,
+                     const float* normal, long M, const float* Wp, float* rgb, int n_workgroups, hipStream_t stream);                      // color_x6t.hip
 int launch_sdf_back_x6t(const float* sig, long M, const float* Wt, const float* w8row, float* gfeat, hipStream_t s);                      // sdf_back_x6t.hip
 int launch_sdf_x6t(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, float* sig,
                    int n_workgroups, hipStream_t s);                                                                                      // sdf_x6t.hip

@@ -5,34 +5,7 @@
 
 namespace rb {
 
-struct Cam {
-  float p[12];            // rows 0..2 of the camera-to-world matrix
-  float fx, fy, cx, cy, sk;
-};
-
-__global__ void k_camera_rays(Cam c, const float* __restrict__ uv, long N, float* __restrict__ dirs) {
-  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const float x = uv[2 * i], y = uv[2 * i + 1], z = 1.0f;
-  const float xl = (x - c.cx + c.cy * c.sk / c.fy - c.sk * y / c.fy) / c.fx * z;
-  const float yl = (y - c.cy) / c.fy * z;
-  const float pc[4] = {xl, -yl, -z, 1.0f};
-  float w[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    float acc = c.p[4 * r] * pc[0];
-    acc = acc + c.p[4 * r + 1] * pc[1];
-    acc = acc + c.p[4 * r + 2] * pc[2];
-    acc = acc + c.p[4 * r + 3] * pc[3];
-    w[r] = acc - c.p[4 * r + 3];        // world - cam_loc
-  }
-  const float n = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);   // F.normalize
-  dirs[3 * i] = w[0] / n;
-  dirs[3 * i + 1] = w[1] / n;
-  dirs[3 * i + 2] = w[2] / n;
-}
-
-// the same with pose / intrinsics read from device memory (a per-chunk forward() must not wait for a device-to-host copy)
+// camera rays (get_camera_params + lift, utils/rend_util.py:51-97), pose / intrinsics read from device memory (a per-chunk forward() must not wait for a device-to-host copy)
 __global__ void k_camera_rays_dev(const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ uv, long N,
                                   float* __restrict__ dirs) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -295,21 +268,6 @@ int rb_scatter_rows(const float* const* src, const int* src_width, const int* ds
   a.total_cols = cols;
   hipLaunchKernelGGL(k_scatter_rows, grid1d(n * cols, 256), dim3(256), 0, (hipStream_t)stream, a, idx, n, flat);
   return check_launch("k_scatter_rows");
-}
-
-int rb_camera_rays(const float* pose_host, const float* K_host, const float* uv, long N, float* dirs,
-                   rb_stream_t stream) {
-  if (N <= 0) return 0;
-  RB_REQUIRE(pose_host && K_host && uv && dirs, "null pointer");
-  Cam c;
-  for (int i = 0; i < 12; ++i) c.p[i] = pose_host[i];
-  c.fx = K_host[0];
-  c.sk = K_host[1];
-  c.cx = K_host[2];
-  c.fy = K_host[4];
-  c.cy = K_host[5];
-  hipLaunchKernelGGL(k_camera_rays, grid1d(N, 256), dim3(256), 0, (hipStream_t)stream, c, uv, N, dirs);
-  return check_launch("k_camera_rays");
 }
 
 int rb_camera_rays_dev(const float* pose_dev, const float* K_dev, const float* uv, long N, float* dirs, rb_stream_t stream) {

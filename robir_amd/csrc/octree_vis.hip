@@ -551,9 +551,8 @@ static int ovis_grid() {
   return cus * 8;
 }
 
-extern "C" {
-
-int rb_dvis_octree(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
+// the plain walk (every iteration visits every pair slot): rb_dvis_octree without the compaction scratch
+static int dvis_octree_plain(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
                    const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
                    const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
                    int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
@@ -603,10 +602,13 @@ int rb_dvis_octree(const float* node, const float* nrm, long B, const float* roo
   return 0;
 }
 
-/* rb_dvis_octree with the active rays compacted between the lock-step iterations (same results bit for bit: a ray's state never
- * depends on where it sits in a launch).  Extra caller scratch: alive_a, alive_b int32[cap], flags uint8[cap] (cap = the size of
- * pair_p), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[40] (list sizes + per-iteration cursors). */
-int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
+extern "C" {
+
+/* With the compaction scratch (alive_a .. n_alive all non-NULL) the active rays are compacted between the lock-step iterations (same
+ * results bit for bit: a ray's state never depends on where it sits in a launch): alive_a, alive_b int32[cap], flags uint8[cap] (cap = the
+ * size of pair_p), blk_cnt int32[cap / 2048 + 2], blk_off int64[cap / 2048 + 2], n_alive int64[40] (list sizes + per-iteration cursors).
+ * All six NULL: the plain walk. */
+int rb_dvis_octree(const float* node, const float* nrm, long B, const float* root_min, const float* root_size, const int* res,
                            const float* points, const float* normals, const int* chunk_id, long n, int n_chunks, const float* dirs,
                            const float* wdir, const float* wsum, int L, int nsamp, int argmax_vis, long batch_pairs, int max_iter,
                            int* pcount, int* prank, long* chunk_tab, long* group_tab, int max_groups, int* counters, int* pair_p,
@@ -614,6 +616,10 @@ int rb_dvis_octree_compact(const float* node, const float* nrm, long B, const fl
                            long* layout, int* alive_a, int* alive_b, unsigned char* flags, int* blk_cnt, long* blk_off, long* n_alive,
                            float* vis_out, unsigned long long* eval_count, rb_stream_t stream) {
   if (n <= 0) return 0;
+  if (!alive_a && !alive_b && !flags && !blk_cnt && !blk_off && !n_alive)
+    return dvis_octree_plain(node, nrm, B, root_min, root_size, res, points, normals, chunk_id, n, n_chunks, dirs, wdir, wsum, L, nsamp,
+                             argmax_vis, batch_pairs, max_iter, pcount, prank, chunk_tab, group_tab, max_groups, counters, pair_p, pair_j,
+                             t_st, leaf_st, act_st, grp, point_span, layout, vis_out, eval_count, stream);
   RB_REQUIRE(node && nrm && points && normals && dirs && wdir && wsum && vis_out, "null pointer");
   RB_REQUIRE(pcount && prank && chunk_tab && group_tab && counters && pair_p && pair_j && t_st && leaf_st && act_st && grp &&
                  point_span && layout && alive_a && alive_b && flags && blk_cnt && blk_off && n_alive,

@@ -615,10 +615,11 @@ extern "C" int rb_sdf_value_grad_f32_points(const float* x, long M, float in_sca
   return check_launch("k_pe_grad_points");
 }
 
-// ... with both passes on exact three-piece operands (k_sdf_x6<5>, csrc/sdf_x6.hip, Wp = packing.pack_sdf_x6; k_sdf_back_x6,
-// csrc/sdf_back_x6.hip, Wt = packing.pack_sdf_back_x6): same scratch.
+// ... with both passes on exact three-piece operands: same scratch.  two_tile = 0: k_sdf_x6<5> (csrc/sdf_x6.hip, Wp = packing.pack_sdf_x6)
+// + k_sdf_back_x6 (csrc/sdf_back_x6.hip, Wt = packing.pack_sdf_back_x6), one 16-row tile per wave; two_tile = 1: k_sdf_x6t<5> +
+// k_sdf_back_x6t (csrc/sdf_x6t.hip, sdf_back_x6t.hip; Wt = packing.pack_sdf_back_x6(two_tile=True): W3^T's K padded to 256).
 extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
-                                           float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
+                                           float out_scale, float grad_scale, float* out0, float* grad, float* scratch, int two_tile,
                                            rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && Wp && Wt && w8row && out0 && grad && scratch, "null pointer");
@@ -626,29 +627,9 @@ extern "C" int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scal
   const long tiles = (M + 127) / 128 * 8;
   float* sig = scratch;
   float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
-  int rc = launch_sdf_x6_store(x, M, in_scale, Wp, out_scale, out0, sig, s);
+  int rc = two_tile ? launch_sdf_x6t(x, M, in_scale, Wp, 5, out_scale, out0, sig, 0, s) : launch_sdf_x6_store(x, M, in_scale, Wp, out_scale, out0, sig, s);
   if (rc) return rc;
-  rc = launch_sdf_back_x6(sig, M, Wt, w8row, gfeat, s);
-  if (rc) return rc;
-  const long n = 3 * M;
-  hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);
-  return check_launch("k_pe_grad_points");
-}
-
-// ... with two 16-row tiles per wave in both passes (k_sdf_x6t<5>, csrc/sdf_x6t.hip; k_sdf_back_x6t, csrc/sdf_back_x6t.hip, Wt =
-// packing.pack_sdf_back_x6(two_tile=True): W3^T's K padded to 256): same arguments, same scratch.
-extern "C" int rb_sdf_value_grad_x6t_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,
-                                            float out_scale, float grad_scale, float* out0, float* grad, float* scratch,
-                                            rb_stream_t stream) {
-  if (M <= 0) return 0;
-  RB_REQUIRE(x && Wp && Wt && w8row && out0 && grad && scratch, "null pointer");
-  hipStream_t s = (hipStream_t)stream;
-  const long tiles = (M + 127) / 128 * 8;
-  float* sig = scratch;
-  float* gfeat = scratch + tiles * (8L * 16 * 64 * 4);
-  int rc = launch_sdf_x6t(x, M, in_scale, Wp, 5, out_scale, out0, sig, 0, s);
-  if (rc) return rc;
-  rc = launch_sdf_back_x6t(sig, M, Wt, w8row, gfeat, s);
+  rc = two_tile ? launch_sdf_back_x6t(sig, M, Wt, w8row, gfeat, s) : launch_sdf_back_x6(sig, M, Wt, w8row, gfeat, s);
   if (rc) return rc;
   const long n = 3 * M;
   hipLaunchKernelGGL(k_pe_grad_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gfeat, x, in_scale, M, grad_scale, grad);

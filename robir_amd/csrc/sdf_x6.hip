@@ -424,11 +424,13 @@ int sx_launch(const float* x, long M, float in_scale, const float* Wp, int mode,
 
 extern "C" {
 
-int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int n_workgroups,
-                     rb_stream_t stream) {
+int rb_sdf_x6_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0, int two_tile,
+                     int n_workgroups, rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && Wp && out0, "null pointer");
   RB_REQUIRE(mode == 0 || mode == 1, "mode: 0 signed distance only (blob packed with full = 0), 1 all 257 outputs");
+  if (two_tile)      // two 16-row tiles per wave, rounds of 128 rows (sdf_x6t.hip)
+    return rb::launch_sdf_x6t(x, M, in_scale, Wp, mode, out_scale, out0, nullptr, n_workgroups, (hipStream_t)stream);
   return sx_launch(x, M, in_scale, Wp, mode, out_scale, out0, nullptr, n_workgroups, (hipStream_t)stream);
 }
 

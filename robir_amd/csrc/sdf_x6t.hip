@@ -450,11 +450,3 @@ int launch_sdf_x6t(const float* x, long M, float in_scale, const float* Wp, int 
   return check_launch("k_sdf_x6t");
 }
 }  // namespace rb
-
-extern "C" int rb_sdf_x6t_points(const float* x, long M, float in_scale, const float* Wp, int mode, float out_scale, float* out0,
-                                 int n_workgroups, rb_stream_t stream) {
-  if (M <= 0) return 0;
-  RB_REQUIRE(x && Wp && out0, "null pointer");
-  RB_REQUIRE(mode == 0 || mode == 1, "mode: 0 signed distance only (blob packed with full = 0), 1 all 257 outputs");
-  return rb::launch_sdf_x6t(x, M, in_scale, Wp, mode, out_scale, out0, nullptr, n_workgroups, (hipStream_t)stream);
-}

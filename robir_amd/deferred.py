@@ -31,6 +31,24 @@ import weakref
 import torch
 
 DEFAULT_CHUNKS = int(os.environ.get("ROBIR_DEFER_CHUNKS", "128") or 0)      # round 4: on by default (0 = every forward() runs at once)
+# The first pass of a loop is SHORT and the following ones double up to the limit (16, 32, 64, 128, 128, ...): the GPU has work after 16
+# recorded chunks (7 ms of host time) instead of idling while 128 are recorded (58 ms of a 1.5 s view); 0 = every pass `limit` chunks.
+RAMP_START = int(os.environ.get("ROBIR_DEFER_RAMP", "16") or 0)
+
+
+def pass_sizes(n_chunks, limit, start=None):
+    """Chunks per pass of an uninterrupted loop over n_chunks full chunks (what IDRNetwork._record_chunk does; tests build their reference
+    partition from it)."""
+    start = RAMP_START if start is None else start
+    out, cur = [], (min(limit, start) if start else limit)
+    while n_chunks > 0:
+        k = min(cur, n_chunks)
+        out.append(k)
+        n_chunks -= k
+        cur = min(limit, 2 * cur)
+    return out
+
+
 _NO_TF = torch._C.DisableTorchFunctionSubclass
 _LIVE = weakref.WeakSet()            # queues with recorded chunks that have not run
 
@@ -251,6 +269,8 @@ class ChunkQueue:
             raise RuntimeError("deferred chunks outlived their model")
         if model.__dict__.get("_pending") is self:
             model._pending = None
+        if not self.closed or len(self.slots) < self.limit:       # the loop was interrupted (a read, a short last chunk): the next one starts short again
+            model.__dict__.pop("_defer_ramp", None)
         if _versions(model) != self.versions:
             raise RuntimeError("model parameters changed while chunk forwards were pending (deferred_chunks > 0): call "
                                "model.flush() before modifying weights")

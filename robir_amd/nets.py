@@ -511,7 +511,9 @@ class SDFNetwork(nn.Module):
 
     def eval_points(self, x, in_scale=1.0, out_scale=1.0, full=True, grad=False, precise=False):
         """NeuS shape only.  x [M,3] -> (out [M,257] | [M], grad [M,3] | None); grad = d(out_scale*sdf(in_scale*x))/dx.
-        precise: library-grade softplus (sdf-only modes) for values that feed exact threshold decisions."""
+        precise: library-grade softplus (expf / log1pf on the f32-input MFMA, sdf-only modes) for VALUES that feed exact threshold
+        decisions (the octree build).  With grad=True under the default policy the flag covers the value only: the gradient comes from
+        the exact-operand reverse pass (ROBIR_PRECISE_GRAD=split, the default), whose softplus is the hardware-transcendental form."""
         assert self.kind == "neus"
         forward_only_guard(self)
         x = x.float().contiguous()
@@ -815,14 +817,15 @@ class ImplicitNetworkMy(nn.Module):
         rgb, _ = ops.neus_composite(out[:, 0].reshape(m, 16).contiguous(), col.reshape(m, 16, 3), self.neus_model.inv_s())
         return rgb
 
-    def batch_borrow_color(self, points, view_dirs, batch_size=8192):
-        """neus_model.py:873-884.  The reference walks the rays in batches of 8192 to bound ITS memory; the rows are independent
-        (nothing batch-global), so here a batch is a slab of BORROW_SLAB_ROWS rays (x 16 samples: 1 M network evaluations, 1 GB of
-        outputs + 9 GB of gradient scratch) -- the same values bit for bit from an eighth of the launches (a view's 3.4 M
-        secondary hits: 53 slabs instead of 420 batches x 3 kernels of 0.4-0.8 ms)."""
+    def batch_borrow_color(self, points, view_dirs, batch_size=None):
+        """neus_model.py:873-884.  The reference walks the rays in batches of 8192 (its default) to bound ITS memory; the rows are
+        independent (nothing batch-global), so with `batch_size` left at its default a batch here is a slab of BORROW_SLAB_ROWS rays (x 16
+        samples: 1 M network evaluations, 1 GB of outputs + 9 GB of gradient scratch): a view's 3.4 M secondary hits in 53 slabs instead of
+        420 batches x 3 kernels of 0.4-0.8 ms.  An explicit `batch_size` is honoured (a caller bounding memory).  Results are equal to fp32
+        summation order whatever the batch size (the SDF / colour kernels pick their one- or two-tile form by launch size)."""
         if points.shape[0] == 0:
             return torch.zeros_like(points)
-        step = max(int(batch_size), BORROW_SLAB_ROWS)
+        step = BORROW_SLAB_ROWS if batch_size is None else max(1, int(batch_size))
         with torch.no_grad():
             outs = [self.borrow_color(points[i:i + step].contiguous(), view_dirs[i:i + step].contiguous())
                     for i in range(0, points.shape[0], step)]

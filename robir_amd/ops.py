@@ -251,8 +251,8 @@ def color_x6_points(x, view, normal, feat, blob, x_scale=1.0, feat_scale=1.0, tw
     rgb = torch.empty(M, 3, dtype=torch.float32, device=x.device)
     if two_tile is None:
         two_tile = sdf_two_tile(M)
-    call("rb_color_x6t_points" if two_tile else "rb_color_x6_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
-         ptr(view), ptr(normal), c_long(M), ptr(blob), ptr(rgb), c_int(0), stream_ptr())
+    call("rb_color_x6_points", ctypes.c_void_p(feat.data_ptr()), c_long(feat.stride(0)), c_float(feat_scale), ptr(x), c_float(x_scale),
+         ptr(view), ptr(normal), c_long(M), ptr(blob), ptr(rgb), c_int(1 if two_tile else 0), c_int(0), stream_ptr())
     return rgb
 
 
@@ -395,8 +395,8 @@ def sdf_points_x6(x, M, blob, full, in_scale=1.0, out_scale=1.0):
     x = _f32(x)
     out0 = torch.empty((M, 257) if full else (M,), dtype=torch.float32, device=x.device)
     if M > 0:
-        call("rb_sdf_x6t_points" if sdf_two_tile(M) else "rb_sdf_x6_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_float(out_scale), ptr(out0),
-             c_int(0), stream_ptr())
+        call("rb_sdf_x6_points", ptr(x), c_long(M), c_float(in_scale), ptr(blob), c_int(1 if full else 0), c_float(out_scale), ptr(out0),
+             c_int(1 if sdf_two_tile(M) else 0), c_int(0), stream_ptr())
     return out0
 
 
@@ -420,9 +420,9 @@ def sdf_value_grad_x6(x, M, blob, back, in_scale=1.0, out_scale=1.0):
     for a in range(0, M, slab):
         n = min(slab, M - a)
         two = wt2 is not None and sdf_two_tile(n)
-        call("rb_sdf_value_grad_x6t_points" if two else "rb_sdf_value_grad_x6_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob),
-             ptr(wt2 if two else wt), ptr(w8),
-             c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), stream_ptr())
+        call("rb_sdf_value_grad_x6_points", ptr(x[a:a + n]), c_long(n), c_float(in_scale), ptr(blob), ptr(wt2 if two else wt), ptr(w8),
+             c_float(out_scale), c_float(out_scale * in_scale), ptr(out0[a:a + n]), ptr(grad[a:a + n]), ptr(scratch), c_int(1 if two else 0),
+             stream_ptr())
     return out0, grad
 
 
@@ -812,10 +812,10 @@ def dvis_octree(T, points, normals, chunk_id, n_chunks, dirs, wdir, wsum, L, nsa
         alive_a, alive_b, blk_cnt = i32(cap), i32(cap), i32(nblk)
         flags = torch.empty(cap + 8, dtype=torch.uint8, device=dev)
         blk_off, n_alive = i64(nblk), i64(2)
-        call("rb_dvis_octree_compact", *common, ptr(alive_a), ptr(alive_b), ptr(flags), ptr(blk_cnt), ptr(blk_off), ptr(n_alive),
+        call("rb_dvis_octree", *common, ptr(alive_a), ptr(alive_b), ptr(flags), ptr(blk_cnt), ptr(blk_off), ptr(n_alive),
              ptr(out), ptr(eval_count), stream_ptr())
-    else:
-        call("rb_dvis_octree", *common, ptr(out), ptr(eval_count), stream_ptr())
+    else:           # the plain walk: no compaction scratch
+        call("rb_dvis_octree", *common, *([ptr(None)] * 6), ptr(out), ptr(eval_count), stream_ptr())
     lay4 = layout[:4].clone()            # device tensor [pairs, groups, node records read, ray-iterations] of the last call
     lay4[2:4] = layout[4:].view(4096, 2).sum(0)
     LAST_OCTREE_VIS_LAYOUT = lay4
@@ -880,13 +880,14 @@ def camera_rays(pose, K, uv):
         call("rb_camera_rays_dev", ptr(_f32(pose.detach()).reshape(16)), ptr(_f32(K.detach()).reshape(9)), ptr(uv), c_long(N),
              ptr(dirs), stream_ptr())
         return dirs
-    p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).reshape(16))
-    k = np.ascontiguousarray(np.asarray(K, dtype=np.float32).reshape(9))
+    # host arrays: uploaded (one small blocking copy; the per-chunk path hands device tensors over)
+    to_np = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     uv = _f32(uv)
+    p = torch.from_numpy(np.ascontiguousarray(to_np(pose), dtype=np.float32).reshape(16).copy()).to(uv.device)
+    k = torch.from_numpy(np.ascontiguousarray(to_np(K), dtype=np.float32).reshape(9).copy()).to(uv.device)
     N = uv.shape[0]
     dirs = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
-    call("rb_camera_rays", p.ctypes.data_as(ctypes.c_void_p), k.ctypes.data_as(ctypes.c_void_p), ptr(uv), c_long(N),
-         ptr(dirs), stream_ptr())
+    call("rb_camera_rays_dev", ptr(p), ptr(k), ptr(uv), c_long(N), ptr(dirs), stream_ptr())
     return dirs
 
 

@@ -151,7 +151,10 @@ class IDRNetwork(nn.Module):
             sig = (trainstage, fun_spec, lin_diff, hdr is None, uv.device, hook, (id(input["pose"]), input["pose"]._version),
                    (id(input["intrinsics"]), input["intrinsics"]._version))
             spec = deferred.output_spec(trainstage, self.indirect_illum_network.num_lgt_sgs, hdr is not None)
-            q = deferred.ChunkQueue(self, sig, spec, N, limit, pose, K, hdr is not None, uv.device,
+            # pass sizes ramp up: 16, 32, 64, ... `limit` chunks (deferred.RAMP_START) -- the GPU starts after 16 recorded chunks
+            ramp = self.__dict__.get("_defer_ramp") or (min(limit, deferred.RAMP_START) if deferred.RAMP_START else limit)
+            self.__dict__["_defer_ramp"] = min(limit, 2 * ramp)
+            q = deferred.ChunkQueue(self, sig, spec, N, min(limit, ramp), pose, K, hdr is not None, uv.device,
                                     (trainstage, fun_spec, lin_diff, None, None, None))
             # the signature identifies the caller's pose / intrinsics tensors by id(): keep them alive while the queue is, so
             # that a freed tensor's id cannot come back as another view's pose at version 0

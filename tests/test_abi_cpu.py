@@ -212,3 +212,19 @@ def test_forward_only_guard():
         for p in m.parameters():
             p.requires_grad_(False)
         nets.forward_only_guard(m)
+
+
+def test_no_compiler_written_m0_in_the_lds_dma_kernels():
+    """The two-tile exact-operand kernels issue the LDS-DMA pieces of a chunk behind ONE M0 write (x6t_engine.h: xt_copy_piece_seq); that is
+    sound only while the compiler writes M0 nowhere in those kernels.  tools/check_m0.py disassembles both libraries and fails on any M0
+    write that is not the inline-assembly `s_mov_b32 m0, sN ; s_nop 0 ; global_load_lds_*` pattern."""
+    import importlib.util
+    from robir_amd import _lib
+    spec = importlib.util.spec_from_file_location("check_m0", os.path.join(ROOT, "tools", "check_m0.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    for lib in (_lib.LIB_PATH, _lib.LEGACY_PATH):
+        kernels, writes, bad = mod.check(lib)
+        assert kernels >= 15 and writes > 1000 and not bad, (lib, kernels, writes, bad[:5])

@@ -94,13 +94,17 @@ def plot_loop(model, split, total):
 
 
 def _batched(model, mi, total, seed, per_pass):
-    """render_chunks on consecutive blocks of `per_pass` chunks, one seed in front."""
+    """render_chunks on the consecutive blocks of chunks a recorded loop runs as passes, one seed in front."""
     tm = model.gamma.hdr_shift
     torch.manual_seed(seed)
     hdr = tm.as_input().expand(total, 1).contiguous()
-    parts = [model.render_chunks(mi["uv"][0, a:a + per_pass * 1024], mi["pose"][0], mi["intrinsics"][0],
-                                 hdr[a:a + per_pass * 1024], chunk=1024, trainstage="Material")
-             for a in range(0, total, per_pass * 1024)]
+    # the passes of an uninterrupted loop: 16, 32, 64, ... per_pass chunks (robir_amd.deferred.pass_sizes)
+    from robir_amd import deferred
+    sizes = deferred.pass_sizes((total + 1023) // 1024, per_pass)
+    starts = [sum(sizes[:i]) * 1024 for i in range(len(sizes))]
+    parts = [model.render_chunks(mi["uv"][0, a:a + n * 1024], mi["pose"][0], mi["intrinsics"][0],
+                                 hdr[a:a + n * 1024], chunk=1024, trainstage="Material")
+             for a, n in zip(starts, sizes)]
     o = {k: torch.cat([p[k] for p in parts]) for k in ("roughness", "diffuse_albedo", "indir_rgb", "sg_rgb", "vis_shadow",
                                                        "network_object_mask")}
     return {"roughness": o["roughness"][..., 0:1].expand(total, 3), "diffuse_albedo": o["diffuse_albedo"],

@@ -281,8 +281,8 @@ def test_round3_second_half_entry_points_on_empty_tiny_and_bad_inputs(dev, synth
             ("rb_cesr_net_ring_points", (nul, ctypes.c_long(4), ctypes.c_int(2), ctypes.c_int(128), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
             ("rb_cesr_net_ring_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_int(1), ctypes.c_int(128), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
             ("rb_cesr_net_ring_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_int(2), ctypes.c_int(200), ops.ptr(sh16), ctypes.c_int(s), ops.ptr(y), ctypes.c_int(0), nul)),
-            ("rb_sdf_x6_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_float(1.0), ops.ptr(x6f), ctypes.c_int(3), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_int(0), nul)),
-            ("rb_color_x6_points", (nul, ctypes.c_long(257), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_float(1.0), ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ops.ptr(col6), ops.ptr(y), ctypes.c_int(0), nul)),
+            ("rb_sdf_x6_points", (ops.ptr(y), ctypes.c_long(4), ctypes.c_float(1.0), ops.ptr(x6f), ctypes.c_int(3), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_int(0), ctypes.c_int(0), nul)),
+            ("rb_color_x6_points", (nul, ctypes.c_long(257), ctypes.c_float(1.0), ops.ptr(y), ctypes.c_float(1.0), ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ops.ptr(col6), ops.ptr(y), ctypes.c_int(0), ctypes.c_int(0), nul)),
             ("rb_octree_cast_coop", (nul,) * 6 + (ops.ptr(y), ops.ptr(y), ctypes.c_long(4), ctypes.c_int(32), ctypes.c_double(0.005), ctypes.c_int(64), ctypes.c_float(0.1)) + (nul,) * 9)):
         L, fn = _lib.resolve(name)                # the default library, or the legacy one for a retired entry point
         assert fn(*args) != 0, name
@@ -330,14 +330,14 @@ def test_round4_entry_points_on_empty_tiny_and_ragged_inputs(dev, synth_weights)
     L = _lib.lib()
     one = torch.zeros(1, 3, device=dev)
     out = torch.zeros(257, device=dev)
-    rc = L.rb_sdf_x6t_points(_lib.ptr(one), ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(7), ctypes.c_float(1.0),
-                             _lib.ptr(out), ctypes.c_int(0), _lib.stream_ptr())
+    rc = L.rb_sdf_x6_points(_lib.ptr(one), ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(7), ctypes.c_float(1.0),
+                            _lib.ptr(out), ctypes.c_int(1), ctypes.c_int(0), _lib.stream_ptr())
     assert rc != 0 and b"mode" in L.rb_last_error()
-    rc = L.rb_sdf_x6t_points(None, ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(1), ctypes.c_float(1.0),
-                             _lib.ptr(out), ctypes.c_int(0), _lib.stream_ptr())
+    rc = L.rb_sdf_x6_points(None, ctypes.c_long(1), ctypes.c_float(1.0), _lib.ptr(x6f), ctypes.c_int(1), ctypes.c_float(1.0),
+                            _lib.ptr(out), ctypes.c_int(1), ctypes.c_int(0), _lib.stream_ptr())
     assert rc != 0 and b"null" in L.rb_last_error()
-    assert L.rb_sdf_x6t_points(None, ctypes.c_long(0), ctypes.c_float(1.0), None, ctypes.c_int(1), ctypes.c_float(1.0), None,
-                               ctypes.c_int(0), _lib.stream_ptr()) == 0          # zero rows: nothing to do, not an error
+    assert L.rb_sdf_x6_points(None, ctypes.c_long(0), ctypes.c_float(1.0), None, ctypes.c_int(1), ctypes.c_float(1.0), None,
+                              ctypes.c_int(1), ctypes.c_int(0), _lib.stream_ptr()) == 0          # zero rows: nothing to do, not an error
     # the two-tile colour kernel: zero rows, one row, rows that do not fill a round; null pointers refused
     col6 = packing.pack_color_x6(synth_weights, dev)
     for n in (0, 1, 17, 129):
@@ -347,11 +347,11 @@ def test_round4_entry_points_on_empty_tiny_and_ragged_inputs(dev, synth_weights)
         a, b = (ops.color_x6_points(x, v, v, feat[:, 1:], col6, two_tile=t) for t in (False, True))
         assert a.shape == b.shape == (n, 3) and (n == 0 or float((a - b).abs().max()) <= 2e-6), n
     y3 = torch.zeros(3, device=dev)
-    rc = L.rb_color_x6t_points(None, ctypes.c_long(256), ctypes.c_float(1.0), _lib.ptr(y3), ctypes.c_float(1.0), _lib.ptr(y3), _lib.ptr(y3),
-                               ctypes.c_long(1), _lib.ptr(col6), _lib.ptr(y3), ctypes.c_int(0), _lib.stream_ptr())
+    rc = L.rb_color_x6_points(None, ctypes.c_long(256), ctypes.c_float(1.0), _lib.ptr(y3), ctypes.c_float(1.0), _lib.ptr(y3), _lib.ptr(y3),
+                              ctypes.c_long(1), _lib.ptr(col6), _lib.ptr(y3), ctypes.c_int(1), ctypes.c_int(0), _lib.stream_ptr())
     assert rc != 0 and b"null" in L.rb_last_error()
-    assert L.rb_color_x6t_points(None, ctypes.c_long(256), ctypes.c_float(1.0), None, ctypes.c_float(1.0), None, None, ctypes.c_long(0), None,
-                                 None, ctypes.c_int(0), _lib.stream_ptr()) == 0
+    assert L.rb_color_x6_points(None, ctypes.c_long(256), ctypes.c_float(1.0), None, ctypes.c_float(1.0), None, None, ctypes.c_long(0), None,
+                                None, ctypes.c_int(1), ctypes.c_int(0), _lib.stream_ptr()) == 0
     # light visibility: 8 lobes x 4 samples, three points (one whose normal faces away from every direction: all culled)
     m = renderer.build_synthetic_model(dev, build_octrees=False)
     lgt = torch.from_numpy(synth.synth_light_sgs(0, 128))[:8].to(dev)
