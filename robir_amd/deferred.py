@@ -31,9 +31,11 @@ import weakref
 import torch
 
 DEFAULT_CHUNKS = int(os.environ.get("ROBIR_DEFER_CHUNKS", "128") or 0)      # round 4: on by default (0 = every forward() runs at once)
-# The first pass of a loop is SHORT and the following ones double up to the limit (16, 32, 64, 128, 128, ...): the GPU has work after 16
-# recorded chunks (7 ms of host time) instead of idling while 128 are recorded (58 ms of a 1.5 s view); 0 = every pass `limit` chunks.
-RAMP_START = int(os.environ.get("ROBIR_DEFER_RAMP", "16") or 0)
+# ROBIR_DEFER_RAMP=n: the first pass of a loop is n chunks and the following ones double up to the limit (16, 32, 64, 128, 128, ...), so
+# that the GPU has work after n recorded chunks instead of idling while `limit` are recorded.  MEASURED NEUTRAL on the 800 x 800 plot loop
+# (one box, tools/prof_deferred.py: 1.522 / 1.539 / 1.516 s for n = 0 / 16 / 64 at 128 chunks per pass; the 80 ms over one
+# render_chunks pass are the loop's own per-chunk tone-mapping / merge kernels, not idle time): off by default (0 = every pass `limit` chunks).
+RAMP_START = int(os.environ.get("ROBIR_DEFER_RAMP", "0") or 0)
 
 
 def pass_sizes(n_chunks, limit, start=None):

@@ -29,8 +29,12 @@ def main():
         model.get_sg_render = make_pbr_runner_hook(types.SimpleNamespace(model=model, train_spec=True, no_normal=False,
                                                                          is_training=False))
         mi, total = _view(dev, 800, 800)
-        for limit in limits:
+        from robir_amd import deferred
+        ramps = [int(a) for a in os.environ.get("PROF_RAMPS", str(deferred.RAMP_START)).split(",")]
+        for limit, ramp in [(l, r) for l in limits for r in ramps]:
             model.deferred_chunks = limit
+            deferred.RAMP_START = ramp
+            model.__dict__.pop("_defer_ramp", None)
             best = (1e9, 0, 0)
             for _ in range(3):
                 split = split_input(mi, total)
@@ -42,7 +46,7 @@ def main():
                 torch.cuda.synchronize()
                 t2 = time.time()
                 best = min(best, (t2 - t0, t1 - t0, t2 - t1))
-            print(f"deferred_chunks={limit:5d}: {best[0]:.3f} s = {total / best[0]:.3g} rays/s  (recording loop {best[1]:.3f} s, "
+            print(f"deferred_chunks={limit:5d} ramp start {ramp:3d} ({len(deferred.pass_sizes(625, limit, ramp))} passes): {best[0]:.3f} s = {total / best[0]:.3g} rays/s  (recording loop {best[1]:.3f} s, "
                   f"reading the merged image {best[2]:.3f} s)")
         model.deferred_chunks = 0
         split = split_input(mi, total)[280:344]
