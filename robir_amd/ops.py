@@ -527,7 +527,8 @@ DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6t", "f16x6
 
 
 DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
-DVIS_STREAM_MAX_POINTS = 8192     # "f16x3-auto": launches up to this many surface points take the streaming family
+DVIS_STREAM_MAX_POINTS = 8192     # launches up to this many surface points take the tile-list (streaming) form
+DVIS_STREAM_SHORT_LIST = 1024     # ... and any launch whose points have at most this many sampled directions (L * nsamp)
 DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "auto")          # what "f16x6" runs: auto | f16x6-pt | f16x6-stream | f16x6-1t
 
 
@@ -549,7 +550,10 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         # over the CUs, 0.4 % tile padding), one workgroup per point beyond (no scratch); the two are bit-identical
         # (same bits); a light whose L*nsamp is not a multiple of 16 (odd lobe counts with nsamp = 8) cannot be cut into whole tiles of
         # the global list and takes the per-point form at every size
-        stream_ok = normals.shape[0] <= DVIS_STREAM_MAX_POINTS and (L * nsamp) % 16 == 0
+        # ... and at EVERY size for short direction lists (L * nsamp <= 1024: the CESR hook's nsamp = 8): a point then has four rounds of
+        # 128 pairs, the per-point prologue / half-empty last round weigh 5-6 % (tools/ab_dvis_forms.py, 8 / 32 / 128 chunks: 0.94-0.95 of
+        # the per-point form's time; with 4096 directions 0.99-1.00 -- there the per-point form stays: one launch, no 10 GB of scratch)
+        stream_ok = (L * nsamp) % 16 == 0 and (normals.shape[0] <= DVIS_STREAM_MAX_POINTS or L * nsamp <= DVIS_STREAM_SHORT_LIST)
         precision = DVIS_X6_FORM if DVIS_X6_FORM != "auto" else ("f16x6-stream" if stream_ok else "f16x6-pt")
     if precision == "f16x1" and (L * nsamp) % 16 != 0:
         raise ValueError(f"the f16 throughput kernel (ROBIR_PRECISION=f16) exists in the tile-list form only: L*nsamp = {L}*{nsamp} must be a "

@@ -3,7 +3,7 @@
 # of the dominant kernels, per-chunk / deferred rates.  usage: bash tools/run_final_profiles.sh [tag]
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/final
 mkdir -p $O
 prof() {  # name, command...
@@ -23,7 +23,7 @@ python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --precision split --steps 5 --warmup 2 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_split.json 2>> $O/bench.err
 python bench.py --vis octree --steps 3 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_octree_vis.json 2>> $O/bench.err
 python bench.py --scene nonconvex --steps 3 --no-legs --no-configs --no-cpu-baseline > $O/${TAG}_bench_nonconvex.json 2>> $O/bench.err
-python bench.py --gpus 2 --steps 2 --warmup 1 --precision split > $O/${TAG}_bench_2rank_shared_gpu.json 2>> $O/bench.err
+python bench.py --gpus 8 --steps 1 --warmup 1 > $O/${TAG}_bench_8rank_shared_gpu.json 2>> $O/bench.err
 for C in 2 3 5; do python bench.py --config $C --precision split --steps 2 > $O/${TAG}_config${C}_split.json 2>> $O/bench.err; done
 prof bench python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-configs
 prof bench_split python bench.py --precision split --steps 2 --warmup 1 --no-cpu-baseline --no-legs --no-configs
