@@ -265,7 +265,7 @@ def test_sdf_value_grad_nan_and_inf_rows_do_not_hang():
 
 def test_sdf_value_kernels_eight_and_four_waves_agree(dev, synth_weights):
     """Value rows (modes 0, 1, and the value pass + sigmoid blob of the reverse-mode gradient) as eight waves of one tile
-    (csrc/sdf_ring8.hip, the default) and as four waves of two tiles (csrc/sdf_ring.hip): bit-identical outputs -- the blob through
+    (csrc/sdf_ring8.hip, the split policy's default) and as four waves of two tiles (csrc/sdf_ring.hip): bit-identical outputs -- the blob through
     the backward pass that reads it."""
     from robir_amd import _lib, ops, packing
     g = torch.Generator().manual_seed(21)
