@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 6
+#define RB_ABI_VERSION 7
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -210,6 +210,22 @@ int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long n, const f
 int rb_dvis_stream_f16(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
                        const float* wdir, const float* wsum, const float* W49, int L, int nsamp, int argmax_vis, int scale_log2,
                        unsigned short* pair_j, float* pair_vis, int* tile_info, int* point_info, unsigned long long* counters,
+                       int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
+/* scale_log2 of rb_dvis_stream_f16 names the weight blob: 0 = rb_dvis_stream_x6's exact-operand blob (its h pieces read in place, the
+ * round-4 kernel), 1 = the f16 blob (49 x 16 bias floats, then the h fragments of the 49 chunks, 8 KB each: what W49h below is) and the
+ * second-generation kernel (two chunks per barrier step; the same bits).
+ *
+ * The f16 mode in the POINT-BLOCK form (csrc/vis_diffuse_f16p.hip, round 5; ABI 7): a 16-sample tile = SIXTEEN consecutive points x ONE
+ * direction of their chunk, kept when any of the sixteen faces it (lanes that do not are computed and dropped): a round of sixteen tiles
+ * reads 16 rows of A and 16 rows of Bd by whole-row LDS-DMA copies instead of 256 Bd rows sixteen cache lines at a time -- the gather
+ * that one MFMA per multiply-add cannot hide.  Three launches on `stream` (cull per point block, persistent grid over the rounds,
+ * reduce per block); every pair goes through rb_dvis_stream_f16's instruction sequence: vis_out is bit-identical to it.
+ *   chunk_id must be ASCENDING (the renderer's hit points are); if it is not, vis_out comes back NaN (never wrong numbers).
+ *   items_max >= ceil(n / 16) + (number of distinct chunk ids) - 1.  Scratch (device, caller-provided): entries[items_max * L*nsamp] u32,
+ *   pair_vis[items_max * L*nsamp * 16] f32, round_info[items_max * L*nsamp / 16][4] i32, item_info[items_max][4] i32, counters[4] u64. */
+int rb_dvis_pblock_f16(const float* normals, const int* chunk_id, long n, const float* A, const float* Bd, const float* dirs,
+                       const float* wdir, const float* wsum, const float* W49h, int L, int nsamp, int argmax_vis, int items_max,
+                       unsigned* entries, float* pair_vis, int* round_info, int* item_info, unsigned long long* counters,
                        int n_workgroups, float* vis_out, unsigned long long* eval_count, rb_stream_t stream);
 /* ------------------------------------------------------------------------------------------------------------
  * Traced light visibility -- OctreeVisModel (model/octree_tracing.py:63-85) as the VisModel of get_diffuse_visibility

@@ -522,13 +522,28 @@ def dvis_dirs(lgt, u_theta, u_phi, thr=1.0, direct=False):
 
 
 DVIS_KERNEL_NAMES = {"fp32": "k_dvis_fused<fp32>", "f16x6": "k_dvis_x6t", "f16x6-pt": "k_dvis_x6t", "f16x6-stream": "k_dvis_x6t<stream>",
-                     "f16x6-1t": "k_dvis_x6", "f16x1": "k_dvis_f16t", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
+                     "f16x6-1t": "k_dvis_x6", "f16x1": "k_dvis_f16p", "f16x3-auto": "k_dvis_v2", "f16x3-v3": "k_dvis3_stream",
                      "f16x3-v2": "k_dvis_v2", "f16x3": "k_dvis_fused<H3>"}
 
 
 DVIS_STREAM_WORKGROUPS = 0        # persistent workgroups of the streaming visibility kernel; 0 = one per compute unit
 DVIS_STREAM_MAX_POINTS = 8192     # launches up to this many surface points take the tile-list (streaming) form
 DVIS_STREAM_SHORT_LIST = 1024     # ... and any launch whose points have at most this many sampled directions (L * nsamp)
+# the f16 throughput mode's kernel: 3 = the point-block form (csrc/vis_diffuse_f16p.hip: sixteen points x one direction per tile; needs
+# ascending chunk ids, else 2), 2 = the per-point tile list, two-chunk steps, 1 = round 4's kernel -- the same bits, 1 / 2 kept for A/B
+DVIS_F16_GEN = int(os.environ.get("ROBIR_DVIS_F16_GEN", "3"))
+
+
+def chunk_ids_ascending(chunk_id):
+    """True if chunk_id (int32 [n] or None) never decreases.  The answer is remembered ON the tensor (`_robir_ascending`): constructors that
+    know (the renderer's hit lists: pixel order) set it and save the device -> host read this costs otherwise."""
+    if chunk_id is None or chunk_id.numel() < 2:
+        return True
+    known = getattr(chunk_id, "_robir_ascending", None)
+    if known is None:
+        known = bool((chunk_id[1:] >= chunk_id[:-1]).all())
+        chunk_id._robir_ascending = known
+    return known
 DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "auto")          # what "f16x6" runs: auto | f16x6-pt | f16x6-stream | f16x6-1t
 
 
@@ -572,15 +587,32 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         # worst case (every direction front-facing) so that nothing has to be read back to the host
         LS = L * nsamp
         dev = normals.device
+        if precision == "f16x1" and DVIS_F16_GEN == 3 and chunk_ids_ascending(chunk_id):
+            # point-block form: scratch by items (a block of 16 points, two items where a block spans a chunk boundary)
+            n_chunks = max(1, dirs.shape[0] // LS)
+            items_max = (n + 15) // 16 + n_chunks - 1
+            entries = torch.empty(items_max * LS, dtype=torch.int32, device=dev)
+            pair_vis = torch.empty(items_max * LS * 16, dtype=torch.float32, device=dev)
+            round_info = torch.empty(items_max * LS // 16, 4, dtype=torch.int32, device=dev)
+            item_info = torch.empty(items_max, 4, dtype=torch.int32, device=dev)
+            counters = torch.empty(4, dtype=torch.int64, device=dev)
+            call("rb_dvis_pblock_f16", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
+                 ptr(split["hidden_f16_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(items_max), ptr(entries),
+                 ptr(pair_vis), ptr(round_info), ptr(item_info), ptr(counters), c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count),
+                 stream_ptr())
+            return out
         pair_j = torch.empty(n * LS, dtype=torch.int16, device=dev)
         pair_vis = torch.empty(n * LS, dtype=torch.float32, device=dev)
         tile_info = torch.empty(n * LS // 16, 2, dtype=torch.int32, device=dev)
         point_info = torch.empty(n, 2, dtype=torch.int32, device=dev)
         counters = torch.empty(2, dtype=torch.int64, device=dev)
         x6 = precision in ("f16x6-stream", "f16x1")      # "f16x1": plain f16, one product (csrc/vis_diffuse_f16t.hip): NARROWER than fp32
+        blob, fmt = split["hidden_x6_head" if x6 else "hidden_h3_head"], split["x6_head_scale_log2" if x6 else "h3_head_scale_log2"]
+        if precision == "f16x1" and DVIS_F16_GEN >= 2:
+            blob, fmt = split["hidden_f16_head"], 1       # rb_dvis_stream_f16: format 1 = the h-only blob -> second-generation kernel
         call("rb_dvis_stream_f16" if precision == "f16x1" else ("rb_dvis_stream_x6" if x6 else "rb_dvis_stream"), ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
-             ptr(split["hidden_x6_head" if x6 else "hidden_h3_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
-             c_int(split["x6_head_scale_log2" if x6 else "h3_head_scale_log2"]), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
+             ptr(blob), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(fmt), ptr(pair_j), ptr(pair_vis), ptr(tile_info), ptr(point_info), ptr(counters),
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
     if precision in X6:

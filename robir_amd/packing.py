@@ -160,6 +160,17 @@ def pack_vis_split(sd, device):
                           h3_head_scale_log2=H3_SCALE_LOG2, w_last=w_last, b_last=b_last), hl, device)
 
 
+def pack_vis_f16_head(x6_head):
+    """The weights of the f16 THROUGHPUT mode's second-generation kernel (k_dvis_f16t2, csrc/vis_diffuse_f16t.hip) as a blob of their own:
+    [49 chunks x 16 biases] then the h pieces (the weights rounded to f16) of the 49 chunks, 8 KB each ([k-block 8][lane 64] x 16 B),
+    contiguous -- cut out of the exact-operand blob (a chunk there: 16 biases, then [k-block][piece h, m, l][lane]), so that the two
+    generations multiply the same halves."""
+    x = x6_head.view(-1)[:49 * 1540 * 4].view(49, 1540, 4)
+    bias = x[:, :4].reshape(-1)
+    h = x[:, 4:].reshape(49, 8, 3, 64, 4)[:, :, 0].reshape(-1)
+    return torch.cat([bias, h]).contiguous()
+
+
 class _VisSplit(dict):
     """pack_vis_split's blobs; the split-precision ones (`hidden_h3`: the hidden stack, `hidden_h3_head`: the 49 chunks of
     rb_dvis_fused_v2 / rb_dvis_stream) are packed by the LEGACY library on first use -- the default policy never asks for them."""
@@ -173,6 +184,8 @@ class _VisSplit(dict):
             v = pack_layers_h3(self._hl, self._device)
         elif k == "hidden_h3_head":
             v = pack_layers_h3(self._hl + [dict(W=self["w_last"], b=self["b_last"], n_pad=16, k_pad=256)], self._device)
+        elif k == "hidden_f16_head":
+            v = pack_vis_f16_head(self["hidden_x6_head"])
         else:
             raise KeyError(k)
         self[k] = v

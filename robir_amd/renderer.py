@@ -283,6 +283,8 @@ class IDRNetwork(nn.Module):
         n = idx.shape[0]
         hp = points[idx].contiguous()
         cid = (idx // chunk).to(torch.int32).contiguous() if n_chunks > 1 else None
+        if cid is not None:
+            cid._robir_ascending = True          # idx ascends (pixel order): ops.chunk_ids_ascending need not read it back
         indirect_sgs = torch.ones(N, self.indirect_illum_network.num_lgt_sgs, 7, device=dev)
         indirect_sgs[:, :, -3:] = 0
         indirect_integral = torch.ones(N, 3, device=dev)

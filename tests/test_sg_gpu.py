@@ -364,6 +364,18 @@ def test_f16_throughput_mode_error_is_measured(dev, vis_net):
         sg_render.VIS_PRECISION = "f16x1"
         again = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, 3, None)
         assert torch.equal(again, outs["f16x1"])
+        # the kernel generations -- 1: round 4 (the exact-operand blob's h pieces in place), 2: two-chunk steps over the h-only blob,
+        # 3: the point-block form (sixteen points x one direction per tile) -- multiply the same halves in the same order per pair: the
+        # same bits.  The interleaved chunk ids above are NOT ascending: generation 3 then takes generation 2's path (ops.dvis_fused)
+        from robir_amd import ops
+        gen = ops.DVIS_F16_GEN
+        try:
+            for other_gen in (1, 2, 3):
+                ops.DVIS_F16_GEN = other_gen
+                other = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, 3, None)
+                assert torch.equal(other, outs["f16x1"]), (other_gen, float((other - outs["f16x1"]).abs().max()))
+        finally:
+            ops.DVIS_F16_GEN = gen
         for am in (False, True):       # the argmax form (testing=True paths): a flipped sample moves a lobe by 1 / 32
             sg_render.VIS_PRECISION = "f16x1"
             a = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, am, cid, 3, None)
@@ -378,6 +390,68 @@ def test_f16_throughput_mode_error_is_measured(dev, vis_net):
                 assert float(q[0]) <= 2e-3 and float(q[1]) <= 2e-2 and float(d.max()) <= 0.25, (float(q[0]), float(q[1]), float(d.max()))
     finally:
         sg_render.VIS_PRECISION = old
+
+
+@pytest.mark.parametrize("n,n_chunks", [(3000, 3), (1, 1), (17, 2), (1000, 1), (2500, 7)])
+def test_f16_point_block_form_is_bit_identical(dev, vis_net, n, n_chunks):
+    """ROBIR_PRECISION=f16, csrc/vis_diffuse_f16p.hip: tiles of sixteen consecutive points x one direction (the rows of a round by
+    whole-row LDS-DMA copies instead of a 16-line gather per load) against the per-point tile list (rb_dvis_stream_f16): ascending chunk
+    ids with blocks that straddle chunk boundaries, a last block with padding lanes, a single point, empty chunks, points with a NaN
+    normal (they face nothing: visibility 0) -- the same bits, and the same count of evaluated pairs."""
+    from robir_amd import ops, sg_render, synth
+    g = np.random.Generator(np.random.PCG64(80 + n))
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32)).to(dev)
+    nrm = torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    if n > 100:
+        nrm[5] = float("nan")
+        nrm[40:44] = nrm[40]                                   # a run of equal normals: whole tiles kept / dropped together
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128)).to(dev)
+    u = torch.from_numpy(g.random((2, n_chunks, 128, 32), dtype=np.float32)).to(dev)
+    if n_chunks == 1:
+        cid = None
+    else:
+        c = np.sort(g.integers(0, n_chunks, n)).astype(np.int32)
+        if n_chunks == 7:
+            c[c == 3] = 4                                        # an empty chunk in the middle
+        cid = torch.from_numpy(c).to(dev)
+    old, gen = sg_render.VIS_PRECISION, ops.DVIS_F16_GEN
+    try:
+        sg_render.VIS_PRECISION = "f16x1"
+        res = {}
+        for k in (2, 3):
+            ops.DVIS_F16_GEN = k
+            for am in (False, True):
+                st = {}
+                res[k, am] = (sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, am, cid, n_chunks, st), st)
+        for am in (False, True):
+            assert torch.equal(res[2, am][0], res[3, am][0]), float((res[2, am][0] - res[3, am][0]).abs().max())
+            assert not torch.isnan(res[3, am][0]).any()
+            a, b = res[2, am][1], res[3, am][1]
+            assert {k: int(v) for k, v in a.items()} == {k: int(v) for k, v in b.items()}, (a, b)
+    finally:
+        sg_render.VIS_PRECISION, ops.DVIS_F16_GEN = old, gen
+
+
+def test_f16_point_block_entry_refuses_unsorted_chunk_ids(dev, vis_net):
+    """rb_dvis_pblock_f16 called directly with chunk ids that are not ascending (the Python mirror never does: ops.dvis_fused checks and
+    takes the per-point form): NaN everywhere instead of numbers for the wrong directions."""
+    from robir_amd import ops, sg_render, synth
+    g = np.random.Generator(np.random.PCG64(9))
+    n = 200
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32)).to(dev)
+    nrm = torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)).to(dev)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128)).to(dev)
+    u = torch.from_numpy(g.random((2, 2, 128, 32), dtype=np.float32)).to(dev)
+    cid = (torch.arange(n, dtype=torch.int32, device=dev) % 2).contiguous()
+    cid._robir_ascending = True                                  # a caller lying about the order
+    old, gen = sg_render.VIS_PRECISION, ops.DVIS_F16_GEN
+    try:
+        sg_render.VIS_PRECISION, ops.DVIS_F16_GEN = "f16x1", 3
+        out = sg_render._diffuse_vis_core(pts, nrm, vis_net, lgt, u[0], u[1], 1.0, False, cid, 2, None)
+        assert torch.isnan(out).all()
+    finally:
+        sg_render.VIS_PRECISION, ops.DVIS_F16_GEN = old, gen
 
 
 def test_specular_term_conditioning(dev):
