@@ -44,7 +44,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (n
 # HBM bytes per (point, direction) pair: (2 x FETCH_SIZE + WRITE_SIZE) / pairs at 32 chunks per launch.  DERIVED, not a counter of the
 # timed run (PMC passes cannot run inside the timed region): f16x6 from the PMC passes of this round's kernel
 # (profiles/r05_dvis_x6t_pmc.md), the split-precision kernel from profiles/r03_pmc_summary.md
-TRAFFIC_B_PER_PAIR = {"f16x6": 33.0, "default": 22.1}
+# f16 mode, point-block form (profiles/r05_dvis_f16p_pmc.md, 64 chunks per launch): its pair values go out as 16-lane rows and its rounds
+# fetch whole table rows (L2 / MALL hits mostly): more bytes per pair, still < 0.1 TB/s
+TRAFFIC_B_PER_PAIR = {"f16x6": 33.0, "f16x1": 68.4, "default": 22.1}
+TRAFFIC_PROFILE = {"f16x1": "profiles/r05_dvis_f16p_pmc.md"}
 H = W = 800
 CHUNK = 1024
 
@@ -450,7 +453,7 @@ def main():
                 # 1 % of the HBM roofline -- the bound is the matrix pipe
                 "traffic": TRAFFIC_B_PER_PAIR.get(vis, TRAFFIC_B_PER_PAIR["default"]) * evals / max(k_n, 1),
                 "traffic_unit": "B/launch -- DERIVED: bytes per pair of a separate PMC pass of the same kernel build (2 x FETCH_SIZE + WRITE_SIZE, "
-                                "profiles/r05_dvis_x6t_pmc.md) x the pairs of this launch; not a counter of the timed run",
+                                + TRAFFIC_PROFILE.get(vis, "profiles/r05_dvis_x6t_pmc.md") + ") x the pairs of this launch; not a counter of the timed run",
                 "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                 "flops_per_eval": 2 * VIS_MACS_PER_EVAL}

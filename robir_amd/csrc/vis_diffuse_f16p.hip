@@ -41,9 +41,6 @@ constexpr int FP_TILES = 4;
 constexpr int FP_BIAS_F4 = 49 * 4;       // the f16 blob's bias head (packing.pack_vis_f16_head)
 constexpr int FP_SLOTS = 8;              // ring slots (8 KB): slot = chunk % 8
 constexpr int FP_DIST = FP_SLOTS / 2 - 2;
-#ifndef FP_SPREAD
-#define FP_SPREAD 0
-#endif
 constexpr int FP_AROW_F4 = 65;           // an A row in the LDS: 1 KB + 16 B (the 16 points of a quarter-wave then read 16 different bank groups)
 
 struct PbRound {
@@ -240,7 +237,9 @@ __global__ __launch_bounds__(256, 1) void k_dvis_f16p(const FpArgs a, const unsi
 #define FP_MFMA(ACC, WREG, XREG) \
   ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, WREG), __builtin_bit_cast(h8, XREG), ACC, 0, 0, 0)
 
-  PbRound nxt = cur;
+  // round r + G's record is requested a round early (top of round r - G), its entries at the top of round r: both scalar loads are in
+  // flight together and long back when the second layer uses them
+  PbRound nxt = lookup(rd + G), nn = nxt;
   fp_u4 ent_n = {0u, 0u, 0u, 0u};
   // one hidden layer: operands X -> outputs Y (the next layer's operands); cb = the layer's first chunk (0, 16, 32).  Steps of two
   // chunks: the copies of step s + FP_DIST at the top of step s, one counted wait + barrier per 64 MFMAs (vis_diffuse_f16t.hip,
@@ -273,29 +272,19 @@ __global__ __launch_bounds__(256, 1) void k_dvis_f16p(const FpArgs a, const unsi
 #pragma unroll
         for (int k_ = 0; k_ < 8; ++k_) {
           const int k = (jb & 1) ? 7 - k_ : k_;       // k_dvis_f16t's summation order (odd chunks downwards): the same bits per pair
-          // FP_SPREAD: at most ONE other instruction behind each MFMA (the fragment read of the next chunk, the truncation, the relu of
-          // one value pair of the previous chunk) instead of the three in a cluster behind the fourth
-          const int et = k_ >> 1, pj = jb - 1;
-          unsigned cv = 0;
 #pragma unroll
           for (int t = 0; t < FP_TILES; ++t) {
             if (k_ == 0) ac[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, wc[k]), __builtin_bit_cast(h8, X[t][k]), bias, 0, 0, 0);
             else FP_MFMA(ac[t], wc[k], X[t][k]);
-#if FP_SPREAD
-            if (t == 0) wn[k_] = nfrag[k_ * 64];
-            if (t == 1 && jb > 0) cv = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(pv[et][(k_ & 1) * 2], pv[et][(k_ & 1) * 2 + 1]));
-            if (t == 2 && jb > 0) {
-              const fp_h2 z = fp_h2{(_Float16)0.0f, (_Float16)0.0f};
-              Y[et][pj >> 1][(pj & 1) * 2 + (k_ & 1)] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fp_h2, cv), z));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#endif
           }
-#if !FP_SPREAD
+          // the other work of a k-step behind its four MFMAs: one fragment read of the next chunk, relu + truncation of one value pair
+          // of the previous chunk (one instruction behind EACH MFMA instead: measured the same, 74.1 against 74.4 ms)
           wn[k_] = nfrag[k_ * 64];
-          if (jb > 0) Y[et][pj >> 1][(pj & 1) * 2 + (k_ & 1)] = fp_relu_pack(pv[et][(k_ & 1) * 2], pv[et][(k_ & 1) * 2 + 1]);
+          if (jb > 0) {
+            const int t = k_ >> 1, pj = jb - 1;
+            Y[t][pj >> 1][(pj & 1) * 2 + (k_ & 1)] = fp_relu_pack(pv[t][(k_ & 1) * 2], pv[t][(k_ & 1) * 2 + 1]);
+          }
           __builtin_amdgcn_sched_barrier(0);
-#endif
         }
         bias = nbias;
       }
@@ -312,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_f16p(const FpArgs a, const unsi
   int trounds = 0;
 #endif
   for (; rd < total_rounds; rd += G) {
-    nxt = lookup(rd + G);
+    nn = lookup(rd + 2 * (long)G);
     ent_n = load_entries(nxt);
 #ifdef FP_TIMING
     ++trounds;
@@ -381,6 +370,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_f16p(const FpArgs a, const unsi
       }
     }
     cur = nxt;
+    nxt = nn;
     FP_T(4)
   }
 #ifdef FP_TIMING

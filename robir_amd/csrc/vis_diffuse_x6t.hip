@@ -297,8 +297,19 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
   int parity = 0;
   if constexpr (STREAM) tile_lookup(rd);
   if (rounds > 0) fetch_rows(rd, 0);
+#ifdef XT_TIMING   // phase stamps (tools/build_variant.sh ... -DXT_TIMING): profiles/r05_dvis_f16_phases.md
+#define XT_T(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; }
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  int trounds = 0;
+#else
+#define XT_T(i)
+#endif
   for (; rd < rd_end; rd += rd_step) {
     if constexpr (STREAM) tile_lookup(rd + rd_step);
+#ifdef XT_TIMING
+    ++trounds;
+#endif
+    XT_T(3)
     // ---- layer 0: relu(A[point] + Bd[dir]) straight into the operand registers
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -319,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
         }
       }
     }
+    XT_T(0)
     auto layer = [&](int l, Ops& X, Ops& Y) {
       const f4* Wl = W49 + (long)l * 16 * XT_CF4 + 4;                          // this layer's chunk 0 weights
       const f4* Wn = W49 + (long)(l == 2 ? 0 : l + 1) * 16 * XT_CF4 + 4;        // next layer's (next round wraps to 0)
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
     // ---- head: chunk 48 from its resident LDS copy; `bias` holds its bias (fetched by the last chunk of layer 2) and the fragment
     // window already holds the first half of the next round's chunk 0.  Next round's rows are requested first: they arrive under
     // the head's MFMAs (clamped to this round's samples after the final round: harmless)
+    XT_T(1)
     if constexpr (STREAM) fetch_rows(rd + rd_step, parity ^ 1);
     else fetch_rows(rd + 1 < rd_end ? rd + 1 : rd, 0);
     {
@@ -506,7 +519,13 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
       }
     }
     parity ^= 1;
+    XT_T(2)
   }
+#ifdef XT_TIMING
+  if ((blockIdx.x == 7 || blockIdx.x == 4000) && tid == 0 && trounds > 0)
+    printf("x6t wg %d rounds %d cycles/round: conv %llu layers %llu head+fetch %llu lookup %llu\n", (int)blockIdx.x, trounds, tacc[0] / trounds,
+           tacc[1] / trounds, tacc[2] / trounds, tacc[3] / trounds);
+#endif
 #undef XT_MFMA
   range_report<true>(sat, a.range_word);
   // drain the ring (copies still target this workgroup's LDS)
