@@ -392,12 +392,13 @@ def test_f16_throughput_mode_error_is_measured(dev, vis_net):
         sg_render.VIS_PRECISION = old
 
 
-@pytest.mark.parametrize("n,n_chunks", [(3000, 3), (1, 1), (17, 2), (1000, 1), (2500, 7)])
-def test_f16_point_block_form_is_bit_identical(dev, vis_net, n, n_chunks):
+@pytest.mark.parametrize("n,n_chunks,L,nsamp", [(3000, 3, 128, 32), (1, 1, 128, 32), (17, 2, 128, 32), (1000, 1, 128, 32), (2500, 7, 128, 32),
+                                                 (700, 2, 6, 8), (300, 1, 128, 8), (40, 3, 4, 4)])
+def test_f16_point_block_form_is_bit_identical(dev, vis_net, n, n_chunks, L, nsamp):
     """ROBIR_PRECISION=f16, csrc/vis_diffuse_f16p.hip: tiles of sixteen consecutive points x one direction (the rows of a round by
     whole-row LDS-DMA copies instead of a 16-line gather per load) against the per-point tile list (rb_dvis_stream_f16): ascending chunk
     ids with blocks that straddle chunk boundaries, a last block with padding lanes, a single point, empty chunks, points with a NaN
-    normal (they face nothing: visibility 0) -- the same bits, and the same count of evaluated pairs."""
+    normal (they face nothing: visibility 0), short direction lists (the CESR hook's 128 x 8, 6 x 8 = three rounds, 4 x 4 = one round) -- the same bits, and the same count of evaluated pairs."""
     from robir_amd import ops, sg_render, synth
     g = np.random.Generator(np.random.PCG64(80 + n))
     pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32)).to(dev)
@@ -406,8 +407,8 @@ def test_f16_point_block_form_is_bit_identical(dev, vis_net, n, n_chunks):
     if n > 100:
         nrm[5] = float("nan")
         nrm[40:44] = nrm[40]                                   # a run of equal normals: whole tiles kept / dropped together
-    lgt = torch.from_numpy(synth.synth_light_sgs(3, 128)).to(dev)
-    u = torch.from_numpy(g.random((2, n_chunks, 128, 32), dtype=np.float32)).to(dev)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, L)).to(dev)
+    u = torch.from_numpy(g.random((2, n_chunks, L, nsamp), dtype=np.float32)).to(dev)
     if n_chunks == 1:
         cid = None
     else:
