@@ -406,26 +406,50 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
   xt_request(win.m, ring_lane + slot_b[0], 0, 2, 1, true);
   xt_request(win.l, ring_lane + slot_b[0], 0, 2, 2, true);
 
+#ifdef SXT_TIMING   // phase stamps per round (tools/build_variant.sh ... -DSXT_TIMING; profiles/r05_sdf_phases.md)
+#define SXT_T(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; }
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  int trounds = 0;
+#else
+#define SXT_T(i)
+#endif
   for (round = blockIdx.x; round < nrounds; round += gridDim.x) {
+#ifdef SXT_TIMING
+    ++trounds;
+#endif
     {
       const long row0 = round * 128, rows = M - row0 < 128 ? M - row0 : 128;
       out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out0 + row0 * (FULL ? 257 : 1), 0, (int)rows * (FULL ? 257 : 1) * 4, 0x00020000);
       if constexpr (STORE) sig_rsrc = __builtin_amdgcn_make_buffer_rsrc(sig + round * (8L * 8 * 16 * 64), 0, 8 * 8 * 16 * 64 * 16, 0x00020000);
     }
     load_layer0();
+    SXT_T(0)
     // layer 0 | 1, 2 (one instance) | 3 (skip layer's own outputs) | 4 (K = 288) | 5, 6 (a second copy of the instance of 1, 2) | 7 | 8:
     // straight-line, so that the skip layer's ninth k-block is live between layers 3 and 4 only (inside one loop over all nine layers it is
     // carried through every iteration: 24 registers this kernel does not have)
     run_layer(std::integral_constant<int, 0>{}, 0, 0);
+    SXT_T(1)
 #pragma unroll 1
     for (int l = 1; l < 3; ++l) run_layer(std::integral_constant<int, 1>{}, 16 * l, l);
+    SXT_T(2)
     run_layer(std::integral_constant<int, 3>{}, 48, 3);
+    SXT_T(3)
     run_layer(std::integral_constant<int, 4>{}, 61, 4);
+    SXT_T(4)
 #pragma unroll 1
     for (int l = 5; l < 7; ++l) run_layer(std::integral_constant<int, 1>{}, 16 * (l - 1) + 13, l);
+    SXT_T(5)
     run_layer(std::integral_constant<int, 7>{}, 109, 7);
+    SXT_T(6)
     run_layer(std::integral_constant<int, 8>{}, 125, 8);
+    SXT_T(7)
   }
+#ifdef SXT_TIMING
+  if ((blockIdx.x == 3 || blockIdx.x == 200) && tid == 0)
+    printf("sdf_x6t<%d> wg %d rounds %d cycles/round: load+encode %llu L0 %llu L1-2 %llu L3 %llu L4 %llu L5-6 %llu L7 %llu L8 %llu\n", MODE, (int)blockIdx.x,
+           trounds, tacc[0] / trounds, tacc[1] / trounds, tacc[2] / trounds, tacc[3] / trounds, tacc[4] / trounds, tacc[5] / trounds,
+           tacc[6] / trounds, tacc[7] / trounds);
+#endif
   range_report<false>(sat, range_word);
   sx_wait<0>();
   __syncthreads();
