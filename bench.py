@@ -59,9 +59,9 @@ PRECISIONS = {
               "fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the 32 -> 128 "
               "-> 16 auto-encoder decoders on the f32-input MFMA) -- not narrower than the reference's fp32"),
     "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
-    "f16": ("f16x1", "f16x6", "f16 (light-visibility MLP: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
-                              "every other net as under `exact`) -- NARROWER than the reference's fp32: a labelled throughput mode "
-                              "(BASELINE.json configs[4]: 'fp16 MLP weights on MFMA'), not a parity claim; error table in DESIGN.md"),
+    "f16": ("f16x1", "f16x3", "f16 (light-visibility MLP: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
+                              "every other net in split precision: f16 hi/lo pairs, 3 products) -- NARROWER than the reference's fp32: a labelled "
+                              "throughput mode (BASELINE.json configs[4]: 'fp16 MLP weights on MFMA'), not a parity claim; error table in DESIGN.md"),
     "split": ("f16x3-auto", "f16x3", "f32 operands as 22-bit f16 hi/lo pairs, 3 f16 MFMA products per multiply-add, fp32 accumulate "
                                      "(parity-tested throughput mode; NARROWER than fp32)"),
 }

@@ -9,17 +9,20 @@
   ROBIR_PRECISION=split             22-bit operands: (hi, lo) f16 pairs, three products per multiply-add, fp32 accumulate --
                                     2x the throughput, parity-tested against the oracle at the same 1e-4 (tests/test_precision_gpu.py),
                                     guarded by the activation-range sentinel (ops.range_check).
-  ROBIR_PRECISION=f16               the labelled THROUGHPUT mode `BASELINE.json configs[4]` names ("fp16 MLP weights on MFMA"), round 4:
+  ROBIR_PRECISION=f16               the labelled THROUGHPUT policy `BASELINE.json configs[4]` names ("fp16 MLP weights on MFMA"):
                                     the light-visibility MLP in PLAIN f16 -- one f16 MFMA product per multiply-add, f16 weights
                                     (round-to-nearest) and f16 activations (truncated between the layers), fp32 accumulation
-                                    (csrc/vis_diffuse_f16t.hip); every other net as under `exact` (no one-product kernels exist for
-                                    them).  NARROWER than the reference's fp32: never a default, never a parity claim; its measured
-                                    error against the oracle is in DESIGN.md and printed by tests/test_precision_gpu.py.
+                                    (csrc/vis_diffuse_f16p.hip, vis_diffuse_f16t.hip) -- and, since round 5, every other net in SPLIT
+                                    precision (f16 hi/lo weight and activation pairs, three products: the parity-tested family of
+                                    `split`, legacy library) instead of the exact-operand kernels: no one-product kernels exist for
+                                    those nets, and a throughput policy that left them at six products gave the CESR stage 18 %.
+                                    NARROWER than the reference's fp32: never a default, never a parity claim; its measured
+                                    error against a float64 evaluation is in DESIGN.md and printed by tests/test_precision_gpu.py.
 ROBIR_VIS_PRECISION / ROBIR_MLP_PRECISION override the two halves of the policy separately (A/B runs, tests).
 """
 import os
 
-POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3"), "f16": ("f16x1", "f16x6")}
+POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3"), "f16": ("f16x1", "f16x3")}
 VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3", "f16x1", "f16x6-1t", "f16x6-pt", "f16x6-stream")
 
 

@@ -59,7 +59,7 @@ def _oracle_chain(sd, pts, view, hdr, draws, dtype):
 
 @pytest.mark.parametrize("seed,variance,sharp", [(0, 0.3, False), (3, 0.6, True)])
 def test_chained_error_budget(monkeypatch, seed, variance, sharp):
-    from robir_amd import renderer, sg_render, synth
+    from robir_amd import precision, renderer, sg_render, synth
     from robir_oracle import nets as on
     dev = torch.device("cuda:0")
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
@@ -124,9 +124,10 @@ def test_chained_error_budget(monkeypatch, seed, variance, sharp):
         assert st["kh3_p99"] <= max(1e-4, 2.0 * st["o32_p99"]), (f, st)
     record_metric(f"chained_error_budget/seed{seed}/worst_ratio_h3_over_fp32mfma", ratio=worst_ratio)
     record_metric(f"chained_error_budget/seed{seed}/worst_ratio_x6_over_fp32mfma", ratio=worst_x6)
-    # ROBIR_PRECISION=f16 (light-visibility MLP in plain f16, one product; every other net exact): NARROWER than fp32 -- measured against
-    # the same float64 anchor, printed and recorded (DESIGN.md quotes the table), held only to a sanity band: no parity claim
-    monkeypatch.setenv("ROBIR_MLP_PRECISION", "f16x6")
+    # ROBIR_PRECISION=f16 (light-visibility MLP in plain f16, one product; every other net in split precision): NARROWER than fp32 --
+    # measured against the same float64 anchor, printed and recorded (DESIGN.md quotes the table), held only to a sanity band: no parity claim
+    assert precision.POLICIES["f16"] == ("f16x1", "f16x3")
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", "f16x3")
     monkeypatch.setattr(sg_render, "VIS_PRECISION", "f16x1")
     kf = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in model(inp, trainstage="Material", train_spec=True, draws=dd).items()}
     assert torch.equal(kf["network_object_mask"], hit)
