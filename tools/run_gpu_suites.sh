@@ -6,5 +6,4 @@ ROBIR_RECORD_CAPS=1 python -m pytest tests -m gpu -q > $O/suite_exact.log 2>&1; 
 cp gpurun_out/test_metrics.jsonl $O/metrics_exact.jsonl; rm -f gpurun_out/test_metrics.jsonl
 ROBIR_RECORD_CAPS=1 ROBIR_PRECISION=split python -m pytest tests -m gpu -q > $O/suite_split.log 2>&1; tail -2 $O/suite_split.log; grep "^FAILED\|^ERROR" $O/suite_split.log | head -20
 cp gpurun_out/test_metrics.jsonl $O/metrics_split.jsonl; rm -f gpurun_out/test_metrics.jsonl
-ROBIR_RECORD_CAPS=1 ROBIR_PRECISION=f16 python -m pytest tests -m gpu -q -x tests/test_renderer_gpu.py tests/test_sg_gpu.py tests/test_deferred_gpu.py > $O/suite_f16.log 2>&1; tail -2 $O/suite_f16.log; grep "^FAILED\|^ERROR" $O/suite_f16.log | head -20
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
