@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define RB_ABI_VERSION 7
+#define RB_ABI_VERSION 8
 
 typedef void* rb_stream_t; /* hipStream_t */
 
@@ -145,7 +145,7 @@ int rb_illum_decode(const float* raw, long M, float* sgs, rb_stream_t stream);
 int rb_cesr_net(const float* X, long M, int kind, int n_label, const float* Wp, float* Y, rb_stream_t stream);
 /* SparseAE (model/sg_envmap_material.py:40-99): encoder X[M,64] -> raw latent[M,32]
  * (packed [64->512, 512->512 x3, 512->32]); latent = act(raw*(1-var)) [+ lat2 = latent + noise*noise_scale];
- * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus. */
+ * decoder latent[M,32] -> Y[M,n_out] (packed [32->128, 128->128, 128->16]). act: 0 sigmoid, 1 softplus, 2 none (SparseAE.encode, :96-99). */
 int rb_ae_encode(const float* X, long M, const float* Wp, float* raw_latent, rb_stream_t stream);
 int rb_ae_latent(const float* raw, long M, const float* var, int act, const float* noise, float noise_scale, float* lat,
                  float* lat2, rb_stream_t stream);
@@ -459,6 +459,36 @@ int rb_raytrace_pick(const float* sdf, const float* z, const float* P, const uns
                      float* out_pts, float* out_dist, unsigned char* out_hit, float* bracket, rb_stream_t stream);
 int rb_raytrace_secant(const float* cam, int cam_stride, const float* dirs, const unsigned char* on, const float* smid, long m, int phase,
                        float* bracket, float* zp, float* pmid, rb_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Helper functions of the overlaid reference modules (ABI 8; robir_amd/csrc/surface.hip).  The fused forward never calls these;
+ * they back the PUBLIC helper names a caller of the reference can import.
+ * rb_pe_encode        PE.embed / Embedder.embed for any (input_dims d, bands): out[n, (include_input ? d : 0) + 2 d n_freq] =
+ *                     [x | sin(x f_0) | cos(x f_0) | ...], freq[n_freq] DEVICE band values (model/neus_model.py:136-184,
+ *                     model/embedder.py:7-38)
+ * rb_expected_sin     y = exp(-var/2) sin(x), yvar = relu((1 - exp(-2 var) cos(2x))/2 - y^2) (yvar may be NULL), arguments wrapped
+ *                     mod 100 pi beyond 100 pi (model/neus_model.py:14-24)
+ * rb_tonemap_curve    the free functions of model/color_correction.py:31-73, NO clamp of t: curve 0 aces_fn(x), 1 aces_inv(x),
+ *                     2 warp_aces_fn, 3 warp_aces_inv, 4 scale_aces_fn, 5 scale_aces_inv, 6 identity_fn, 7 ln_space_fn, 8 ln_space_inv;
+ *                     t = shift[(i / width) * shift_stride] for element i (shift may be NULL for curves 0, 1, 6)
+ * rb_sample_pdf       sample_pdf (model/sdf_render.py:37-67): bins[R,n], weights[R,n-1], u[n_s] (u_stride 0) or u[R,n_s]
+ *                     (u_stride n_s, any order) -> samples[R,n_s]; cdf[R,n] is written as a by-product
+ * rb_neus_core_aux    render_core's `dists`, `cdf` (= sigmoid(sdf inv_s)) and `inside_sphere` entries (model/sdf_render.py:186-225);
+ *                     each output may be NULL
+ * rb_sample_dirs      IDRNetwork.sample_dirs (model/implicit_differentiable_renderer.py:548-564), one row per (normal, theta, phi)
+ * rb_intersect_sphere OctreeVisModel.intersect_sphere (model/octree_tracing.py:70-76)
+ * ------------------------------------------------------------------------------------------------------------ */
+int rb_pe_encode(const float* x, long n, int d, const float* freq, int n_freq, int include_input, float* out,
+                 rb_stream_t stream);
+int rb_expected_sin(const float* x, const float* var, long n, float* y, float* yvar, rb_stream_t stream);
+int rb_tonemap_curve(const float* x, long n, int width, const float* shift, int shift_stride, int curve, float* y,
+                     rb_stream_t stream);
+int rb_sample_pdf(const float* bins, const float* weights, long R, int n, const float* u, long u_stride, int n_s,
+                  float* cdf, float* samples, rb_stream_t stream);
+int rb_neus_core_aux(const float* sdf, long sdf_stride, const float* pts, const float* z, long R, int n, float inv_s,
+                     float radius, float sample_dist, float* dists, float* cdf, float* inside, rb_stream_t stream);
+int rb_sample_dirs(const float* normals, const float* theta, const float* phi, long n, float* dirs, rb_stream_t stream);
+int rb_intersect_sphere(const float* origins, const float* dirs, long n, float radius, float* out, rb_stream_t stream);
 
 /* Host-only helper (no GPU work): one PIZ-compressed OpenEXR chunk -> 16-bit words, channel-major
  * ([channel][line][pixel][word]); chan = n_ch rows of (pixels per line, lines, words per pixel: 1 HALF, 2 FLOAT/UINT).

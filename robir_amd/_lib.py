@@ -26,7 +26,7 @@ class RobirHipError(RuntimeError):
 
 LEGACY_PATH = os.path.join(_HERE, "librobir_hip_legacy.so")
 _legacy = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def build(verbose=False, legacy=True):

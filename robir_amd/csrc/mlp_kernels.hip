@@ -936,8 +936,10 @@ __global__ void k_ae_latent(const float* __restrict__ raw, long M, const float* 
   float a;
   if (act == 0) {
     a = 1.0f / (1.0f + expf(-v));
-  } else {
+  } else if (act == 1) {
     a = v > 20.0f ? v : log1pf(expf(v));
+  } else {
+    a = v;                      // SparseAE.encode: the pre-activation latent
   }
   lat[i] = a;
   if (lat2) lat2[i] = a + noise[i] * noise_scale;
@@ -1252,6 +1254,7 @@ int rb_ae_latent(const float* raw, long M, const float* var, int act, const floa
   if (M <= 0) return 0;
   RB_REQUIRE(raw && lat, "null pointer");
   RB_REQUIRE(!lat2 || noise, "lat2 needs noise");
+  RB_REQUIRE(act >= 0 && act <= 2, "act: 0 sigmoid, 1 softplus, 2 none");
   hipLaunchKernelGGL(k_ae_latent, grid1d(M * 32, 256), dim3(256), 0, (hipStream_t)stream, raw, M, var, act, noise,
                      noise_scale, lat, lat2);
   return check_launch("k_ae_latent");

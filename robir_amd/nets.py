@@ -274,8 +274,26 @@ class SparseAE(nn.Module):
         lat, _ = ops.ae_latent(self._encode(X), self._var(X.device), self._latent_act_code())
         return ops.ae_decode(lat, dec, self.out_dim, self.out_act is not None)
 
-    def forward(self, values, noise=None):
-        """values [n,in_dim] already-embedded inputs (as the reference passes them)."""
+    def encode(self, values):
+        """sg_envmap_material.py:96-99: encoder output * (1 - var) on already-embedded rows [n, in_dim] (the pre-activation latent)."""
+        forward_only_guard(self)
+        flat = values.reshape(-1, values.shape[-1]).float()
+        X = torch.zeros(flat.shape[0], 64, device=flat.device)
+        X[:, :self.in_dim] = flat
+        raw, _ = ops.ae_latent(self._encode(X), self._var(flat.device), 2)
+        return raw.reshape(list(values.shape[:-1]) + [self.latent_dim])
+
+    def kl_divergence(self, rho, rho_hat):
+        raise NotImplementedError("SparseAE.kl_divergence: a training loss term (model/sg_envmap_material.py:101-105; callers model/loss.py) -- "
+                                  "losses are OUT OF SCOPE for the forward renderer (SURVEY.md section 2 row 9)")
+
+    def kl_smooth_loss(self, points, kl_w, smooth_w):
+        raise NotImplementedError("SparseAE.kl_smooth_loss: a training loss term (model/sg_envmap_material.py:107-118) -- losses are OUT OF "
+                                  "SCOPE for the forward renderer (SURVEY.md section 2 row 9)")
+
+    def forward(self, points, noise=None):
+        """points [n,in_dim]: already-embedded inputs (the reference's parameter name, sg_envmap_material.py:74)."""
+        values = points
         n = values.shape[0]
         X = torch.zeros(n, 64, device=values.device)
         X[:, :self.in_dim] = values
@@ -312,7 +330,7 @@ class IndirctIllumNetwork(nn.Module):
         self.integral_layer.lc_act = torch.nn.functional.softplus
         self._packed = _Packed()
 
-    def forward(self, points, hdr_shift=None, noise=None):
+    def forward(self, points, hdr_shift, noise=None):
         forward_only_guard(self)
         n = points.shape[0]
         dev = points.device
@@ -458,9 +476,12 @@ class SDFNetwork(nn.Module):
       (d_in 63,  d_out 3,   512 x 8, skip [4], multires 0)   -- CESR normal_net  (training/train_cesr.py:109)
       (d_in 191, d_out 2,   512 x 8, skip [4], multires 0)   -- CESR shadow_net  (training/train_cesr.py:107)"""
 
-    def __init__(self, d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=10, bias=0.5, scale=1,
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=10, bias=0.5, scale=1,
                  geometric_init=True, weight_norm=True, inside_outside=False, embed="Default"):
         super().__init__()
+        if multires > 0 and embed == "IPE":
+            raise NotImplementedError("SDFNetwork(embed='IPE'): the HIP SDF kernels encode with PE (every shipped configuration sets "
+                                      "ENCODING = 'PE', confs_sg/env_path.py:5); the IPE-SDF variant is OUT OF SCOPE (SURVEY.md section 2 row 2)")
         key = (d_in, d_out, d_hidden, n_layers, tuple(skip_in), multires)
         kinds = {(3, 257, 256, 8, (4,), 10): "neus", (63, 3, 512, 8, (4,), 0): "normal", (191, 2, 512, 8, (4,), 0): "shadow"}
         if key not in kinds or not weight_norm or scale != 1:
@@ -616,8 +637,14 @@ class SDFNetwork(nn.Module):
 class RenderingNetwork(nn.Module):
     """neus_model.py:489-560, mode 'idr' (d_feature 256, d_hidden 256, 4 layers, multires_view 4)."""
 
-    def __init__(self):
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=4, squeeze_out=True):
         super().__init__()
+        got = (d_feature, mode, d_in, d_out, d_hidden, n_layers, bool(weight_norm), multires_view, bool(squeeze_out))
+        want = (256, "idr", 9, 3, 256, 4, True, 4, True)
+        if got != want:
+            raise NotImplementedError(f"RenderingNetwork{got}: the HIP colour kernels are compiled for {want} (what NeuSModel builds, "
+                                      "model/neus_model.py:717-718)")
+        self.mode, self.squeeze_out = mode, True
         dims = [289, 256, 256, 256, 256, 3]
         for l in range(5):
             setattr(self, "lin%d" % l, _wn_linear(dims[l], dims[l + 1]))
@@ -663,16 +690,71 @@ class SingleVarianceNetwork(nn.Module):
         return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
 
 
+class HashSDFNetwork(nn.Module):
+    def __init__(self, d_in, d_out, multires=12, dx_curve=0.1, separated=False):
+        raise NotImplementedError("HashSDFNetwork: tinycudann hash-grid SDF, never instantiated (hashing=False, model/neus_model.py:774) -- "
+                                  "OUT OF SCOPE (SURVEY.md section 2 row 2)")
+
+    def forward(self, inputs):
+        raise NotImplementedError("HashSDFNetwork is OUT OF SCOPE (SURVEY.md section 2 row 2)")
+
+    def sdf(self, x):
+        raise NotImplementedError("HashSDFNetwork is OUT OF SCOPE (SURVEY.md section 2 row 2)")
+
+    def sdf_hidden_appearance(self, x):
+        raise NotImplementedError("HashSDFNetwork is OUT OF SCOPE (SURVEY.md section 2 row 2)")
+
+    def gradient(self, x, dx=None):
+        raise NotImplementedError("HashSDFNetwork is OUT OF SCOPE (SURVEY.md section 2 row 2)")
+
+
+class NeRF(nn.Module):
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True):
+        raise NotImplementedError("NeRF: the NeRF++ outside-the-sphere background model, built only when NeuSModel(outside=True) -- no shipped "
+                                  "configuration does (n_outside=0, neus/config/render.gin:12) -- OUT OF SCOPE (SURVEY.md section 2 rows 2, 6)")
+
+    def forward(self, input_pts, input_views):
+        raise NotImplementedError("NeRF is OUT OF SCOPE (SURVEY.md section 2 rows 2, 6)")
+
+
+def auto_flatten(f):
+    """neus_model.py:653-662: call `f(self, x [M,3], ...)` on the flattened points and give the result x's leading shape."""
+    import functools
+
+    @functools.wraps(f)
+    def wrapper(self, x, *args, **kwargs):
+        lead = list(x.shape[:-1])
+        return f(self, x.reshape(-1, 3), *args, **kwargs).reshape(lead + [-1])
+    return wrapper
+
+
+def auto_flatten2(f):
+    """neus_model.py:665-678: the two-output form for `f(self, x, dirs, ...) -> (rgb, a)`; dirs [R,3] broadcast over the samples of x [R,S,3]."""
+    import functools
+
+    @functools.wraps(f)
+    def wrapper(self, x, dirs, *args, **kwargs):
+        lead = list(x.shape[:-1])
+        if len(lead) + 1 > dirs.dim():
+            dirs = dirs[:, None, :].expand(x.shape)
+        rgb, a = f(self, x.reshape(-1, 3), dirs.reshape(-1, 3), *args, **kwargs)
+        return rgb.reshape(lead + [-1]), a.reshape(lead + [-1])
+    return wrapper
+
+
 class NeuSModel(nn.Module):
     """neus_model.py:682-752 (mode 'idr', hashing False, no outside NeRF)."""
 
-    def __init__(self, mode="idr", hashing=False, outside=False, embed="PE"):
+    def __init__(self, mode="idr", hashing=False, outside=False, embed="IPE"):
         super().__init__()
         if mode != "idr" or hashing or outside or embed != "PE":
-            raise NotImplementedError("only the shipped NeuS configuration (idr / PE / no hash / no outside) is built")
-        self.color_network = RenderingNetwork()
-        self.sdf_network = SDFNetwork()
-        self.deviation_network = SingleVarianceNetwork(0.3)
+            raise NotImplementedError(f"NeuSModel(mode={mode!r}, hashing={hashing}, outside={outside}, embed={embed!r}): only the shipped NeuS "
+                                      "configuration is built -- mode 'idr', no hash grid, no outside NeRF, embed='PE' (ImplicitNetworkMy passes "
+                                      "confs_sg.env_path.ENCODING = 'PE', model/neus_model.py:771-776; the constructor's own default 'IPE' is not "
+                                      "what any shipped checkpoint uses).  OUT OF SCOPE: SURVEY.md section 2 row 2")
+        self.color_network = RenderingNetwork(d_feature=256, mode=mode, d_in=9, d_out=3, d_hidden=256, n_layers=4)
+        self.sdf_network = SDFNetwork(d_in=3, d_out=257, d_hidden=256, n_layers=8, embed=embed)
+        self.deviation_network = SingleVarianceNetwork(init_val=0.3)
 
     def sdf(self, x):
         return self.sdf_network.sdf(x)
@@ -693,6 +775,10 @@ class NeuSModel(nn.Module):
 
     def radius(self):
         return 2.0
+
+    def background(self, x, dirs):
+        raise NotImplementedError("NeuSModel.background: the NeRF++ outside model is never built (outside=False, n_outside=0 in every "
+                                  "configuration) -- OUT OF SCOPE (SURVEY.md section 2 rows 2, 6)")
 
     def inv_s(self):
         """exp(10 * variance) clipped to [1e-6, 1e6] as a host float.  Reading it is a device synchronisation, and borrow_color
@@ -753,11 +839,16 @@ class ImplicitNetworkMy(nn.Module):
     def __init__(self, feature_vector_size=None, d_in=None, d_out=None, dims=None, geometric_init=True, bias=1.0,
                  skip_in=(), weight_norm=True, multires=0, bgr=False):
         super().__init__()
-        self.neus_model = NeuSModel(mode="idr", hashing=False, embed="PE")
-        self.bgr = bgr
         try:
             from confs_sg.env_path import NEUS_LOG_DIR, NEUS_ITER      # reference-side global (confs_sg/env_path.py)
+            from confs_sg import env_path as _env
+            encoding = getattr(_env, "ENCODING", "PE")
         except ImportError:
+            NEUS_LOG_DIR = None
+            encoding = "PE"
+        self.neus_model = NeuSModel(mode="idr", hashing=False, embed=encoding)        # raises for anything but 'PE'
+        self.bgr = bgr
+        if NEUS_LOG_DIR is None:
             # stand-alone use (tests, bench, robir_amd.render): the caller loads the NeuS weights itself
             import warnings
             warnings.warn("ImplicitNetworkMy: confs_sg.env_path is not set up -- the NeuS SDF / colour networks keep their "
@@ -885,6 +976,14 @@ class ACESToneMapping(nn.Module):
 
     def fit_data(self, data):
         raise NotImplementedError("Energy.gen_cache is a training-time pre-fit (out of scope, SURVEY.md section 2 #9)")
+
+    def plot(self, shift=1.0):
+        raise NotImplementedError("ACESToneMapping.plot: a matplotlib debugging plot (model/color_correction.py:103-109) -- plots are OUT OF "
+                                  "SCOPE (SURVEY.md section 2)")
+
+    def scalar(self, shift):
+        raise NotImplementedError("ACESToneMapping.scalar: reads the Energy cache that fit_data pre-fits at training time "
+                                  "(model/color_correction.py:111-113, model/energy_integral.py) -- OUT OF SCOPE (SURVEY.md section 2 #9)")
 
 
 class GammaCorrect(nn.Module):

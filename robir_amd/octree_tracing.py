@@ -162,7 +162,11 @@ class OctreeTracing(nn.Module):
         and its gradient with the HIP kernels instead of calling the opaque sdf_fn."""
         object.__setattr__(self, "_implicit", implicit_network)
 
-    def generate(self, sdf_fn=None, tex_sampler=None):
+    def generate(self, sdf_fn, tex_sampler=None):
+        """octree_tracing.py:31-41.  The tables are built from the BOUND network (values with the library-grade softplus, gradients by the
+        reverse pass -- an opaque callable cannot be differentiated on the device), so `sdf_fn` is CHECKED against it instead of being
+        evaluated cell by cell: on a fixed probe lattice inside the box it must reproduce the bound network's signed distance to 1e-5, else
+        this raises (a caller handing over a different field would otherwise get the wrong octree silently).  sdf_fn=None: no check."""
         box_min, box_max = [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]
         if tex_sampler is not None:      # mesh bounding box +- 1e-3 in halved coordinates (octree_tracing.py:33-37)
             v = tex_sampler.tex_sampler.vert.view(3, -1).permute(1, 0) * 0.5
@@ -173,7 +177,30 @@ class OctreeTracing(nn.Module):
         if self._implicit is None:
             raise RuntimeError("OctreeTracing.generate: bind(implicit_network) first (the HIP build evaluates the SDF "
                                "network directly; an opaque sdf_fn callable cannot be differentiated on the device)")
+        if sdf_fn is not None:
+            self._check_sdf_fn(sdf_fn, box_min, box_max)
         self.sdf_octree = OctreeSDF.build(self._implicit.neus_model.sdf_network, [box_min, box_max], max_iter=self.max_iter)
+
+    def _check_sdf_fn(self, sdf_fn, box_min, box_max, n=4096, tol=1e-5):
+        dev = next(self._implicit.parameters()).device
+        # a fixed low-discrepancy lattice (no draw from torch's generators: the renderer's random streams must not move)
+        i = np.arange(n, dtype=np.float64) + 0.5
+        frac = np.stack([(i * a) % 1.0 for a in (0.8191725133961645, 0.6710436067037893, 0.5497004779019703)], -1)
+        lo, hi = np.array(box_min, dtype=np.float64), np.array(box_max, dtype=np.float64)
+        probe = torch.from_numpy((lo + frac * (hi - lo)).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            got = sdf_fn(probe)
+            want = self._implicit.sdf_only(probe)
+        from . import deferred
+        got = deferred.plain(got)
+        got = got.reshape(-1).float()
+        if got.shape[0] != n:
+            raise ValueError(f"OctreeTracing.generate: sdf_fn returned {tuple(got.shape)} for {n} probe points")
+        err = float((got - want.reshape(-1)).abs().max())
+        if not err <= tol:
+            raise ValueError(f"OctreeTracing.generate: sdf_fn differs from the bound implicit network by {err:.3g} on the probe lattice "
+                             f"(> {tol:g}).  The HIP octree is built from the bound network (bind(implicit_network)); pass that network's own "
+                             "signed distance (what every runner does: `lambda x: model.implicit_network(x)[:, 0]`) or bind the other network")
 
     def forward(self, sdf, cam_loc, object_mask, ray_directions):
         """cam_loc [K,3], ray_directions [K,P,3] -> x [K*P,3], hit [K*P] bool, t [K*P]; one lock-step batch."""
@@ -195,6 +222,12 @@ class OctreeVisModel(nn.Module):
         super().__init__()
         self.ray_tracer = ray_tracer
         self.ray_tracer.sdf_octree.max_iter = 32
+
+    def intersect_sphere(self, points, view_dirs, radius=1.0):
+        """octree_tracing.py:70-76: where the ray from a point INSIDE the sphere of `radius` leaves it (NaN outside, like the reference)."""
+        shape = points.shape
+        return ops.intersect_sphere(points.reshape(-1, 3).float().contiguous(), view_dirs.reshape(-1, 3).float().contiguous(),
+                                    float(radius)).reshape(shape)
 
     def forward(self, points, view_dirs):
         with torch.no_grad():

@@ -1156,3 +1156,80 @@ def raytrace_secant(cam, dirs, on, smid, phase, bracket, zp, pmid):
     s = _f32(smid) if smid is not None else None
     call("rb_raytrace_secant", ptr(cam), c_int(0 if cam.shape[0] == 1 else 3), ptr(dirs), ptr(on), ptr(s),
          c_long(dirs.shape[0]), c_int(phase), ptr(bracket), ptr(zp), ptr(pmid), stream_ptr())
+
+
+# ------------------------------------------------------------------------------------------------ public helper names (csrc/surface.hip)
+def pe_encode(x, freq, include_input=True):
+    """x [n,d], freq [n_freq] device band values -> [n, (d if include_input) + 2 d n_freq]."""
+    x, freq = _f32(x), _f32(freq)
+    n, d = x.shape
+    out = torch.empty(n, (d if include_input else 0) + 2 * d * freq.shape[0], dtype=torch.float32, device=x.device)
+    call("rb_pe_encode", ptr(x), c_long(n), c_int(d), ptr(freq), c_int(freq.shape[0]), c_int(1 if include_input else 0), ptr(out),
+         stream_ptr())
+    return out
+
+
+def expected_sin(x, var, want_var=True):
+    x, var = _f32(x), _f32(var)
+    assert x.shape == var.shape
+    y = torch.empty_like(x)
+    yv = torch.empty_like(x) if want_var else None
+    call("rb_expected_sin", ptr(x), ptr(var), c_long(x.numel()), ptr(y), ptr(yv), stream_ptr())
+    return y, yv
+
+
+def tonemap_curve(x, shift, curve):
+    """Free functions of model/color_correction.py:31-73 (no clamp).  x any shape; shift None, one value, [..., 1] against x [..., w], or
+    anything that broadcasts to x's shape."""
+    x = _f32(x)
+    y = torch.empty_like(x)
+    width, stride, sh = 1, 0, None
+    if shift is not None:
+        sh = shift.to(device=x.device, dtype=torch.float32)
+        if sh.numel() == 1:
+            sh = sh.reshape(1).contiguous()
+        elif sh.dim() == x.dim() and sh.shape[-1] == 1 and sh.shape[:-1] == x.shape[:-1]:
+            width, stride, sh = x.shape[-1], 1, sh.contiguous()
+        else:
+            width, stride, sh = 1, 1, sh.expand(x.shape).contiguous()
+    call("rb_tonemap_curve", ptr(x), c_long(x.numel()), c_int(width), ptr(sh), c_int(stride), c_int(curve), ptr(y), stream_ptr())
+    return y
+
+
+def sample_pdf(bins, weights, u):
+    """bins [R,n], weights [R,n-1], u [n_s] (shared) or [R,n_s] -> (samples [R,n_s], cdf [R,n])."""
+    bins, weights, u = _f32(bins), _f32(weights), _f32(u)
+    R, n = bins.shape
+    assert weights.shape == (R, n - 1)
+    n_s = u.shape[-1]
+    assert u.dim() == 1 or u.shape == (R, n_s)
+    cdf = torch.empty(R, n, dtype=torch.float32, device=bins.device)
+    out = torch.empty(R, n_s, dtype=torch.float32, device=bins.device)
+    call("rb_sample_pdf", ptr(bins), ptr(weights), c_long(R), c_int(n), ptr(u), c_long(0 if u.dim() == 1 else n_s), c_int(n_s), ptr(cdf),
+         ptr(out), stream_ptr())
+    return out, cdf
+
+
+def neus_core_aux(sdf, sdf_stride, pts, z, R, n, inv_s, radius, sample_dist):
+    dev = pts.device
+    dists, cdf, inside = (torch.empty(R, n, dtype=torch.float32, device=dev) for _ in range(3))
+    call("rb_neus_core_aux", ptr(sdf), c_long(sdf_stride), ptr(pts), ptr(z), c_long(R), c_int(n), c_float(inv_s), c_float(radius),
+         c_float(sample_dist), ptr(dists), ptr(cdf), ptr(inside), stream_ptr())
+    return dists, cdf, inside
+
+
+def sample_dirs(normals, theta, phi):
+    normals, theta, phi = _f32(normals), _f32(theta), _f32(phi)
+    n = theta.numel()
+    assert normals.numel() == 3 * n and phi.numel() == n
+    out = torch.empty(n, 3, dtype=torch.float32, device=normals.device)
+    call("rb_sample_dirs", ptr(normals), ptr(theta), ptr(phi), c_long(n), ptr(out), stream_ptr())
+    return out
+
+
+def intersect_sphere(origins, dirs, radius):
+    origins, dirs = _f32(origins), _f32(dirs)
+    n = origins.shape[0]
+    out = torch.empty(n, 3, dtype=torch.float32, device=origins.device)
+    call("rb_intersect_sphere", ptr(origins), ptr(dirs), c_long(n), c_float(radius), ptr(out), stream_ptr())
+    return out

@@ -132,7 +132,7 @@ def main():
         if a.stage_ckpt:
             load_stage_checkpoint(model, a.stage_ckpt)
         model = model.to(dev).eval()
-        model.ray_tracer.generate()
+        model.ray_tracer.generate(None)
         uv, pose, K = blender_camera(a.cameras, a.index, H, W)
     if a.light:
         model.envmap_material_network.load_light(a.light)

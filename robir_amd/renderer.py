@@ -36,6 +36,33 @@ def _cfg(conf, key):
     return {k: sub[k] for k in sub.keys()} if hasattr(sub, "keys") else dict(sub)
 
 
+_LEGACY_IDR = ("the legacy IDR geometry / appearance networks are built only for use_neus=False, which no shipped configuration sets "
+               "(confs_sg/hotdog.conf:68) -- dead code in the reference, OUT OF SCOPE (SURVEY.md section 2 row 1)")
+
+
+class ImplicitNetwork(nn.Module):
+    """model/implicit_differentiable_renderer.py:19-104 (legacy IDR SDF network): present, not built."""
+
+    def __init__(self, feature_vector_size, d_in, d_out, dims, geometric_init=True, bias=1.0, skip_in=(), weight_norm=True, multires=0):
+        raise NotImplementedError("ImplicitNetwork: " + _LEGACY_IDR)
+
+    def forward(self, input, compute_grad=False):
+        raise NotImplementedError("ImplicitNetwork: " + _LEGACY_IDR)
+
+    def gradient(self, x):
+        raise NotImplementedError("ImplicitNetwork: " + _LEGACY_IDR)
+
+
+class RenderingNetwork(nn.Module):
+    """model/implicit_differentiable_renderer.py:107-167 (legacy IDR colour network): present, not built."""
+
+    def __init__(self, feature_vector_size, mode, d_in, d_out, dims, weight_norm=True, multires_view=0):
+        raise NotImplementedError("RenderingNetwork (legacy IDR): " + _LEGACY_IDR)
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        raise NotImplementedError("RenderingNetwork (legacy IDR): " + _LEGACY_IDR)
+
+
 class IDRNetwork(nn.Module):
     def __init__(self, conf):
         super().__init__()
@@ -69,6 +96,34 @@ class IDRNetwork(nn.Module):
         feature_vectors = self.implicit_network(points)[:, 1:]
         view_dirs = ops.normalize3(view_dirs.contiguous(), 1e-6, 0)
         return normals, self.rendering_network(points, normals, view_dirs, feature_vectors)
+
+    def batch_idr_forward(self, points, viewdirs, n_pixels=4096):
+        """implicit_differentiable_renderer.py:531-546: NeuS radiance of (points, viewdirs) with the L2-normalised SDF gradient as the
+        normal -> [M,3].  The reference walks n_pixels rows at a time to bound ITS autograd memory; the rows are independent and the
+        kernels are forward-only, so a slab here is max(n_pixels, 2^16) rows (same values)."""
+        points, viewdirs = points.float(), viewdirs.float()
+        if points.shape[0] == 0:
+            return torch.zeros_like(points)
+        step = max(int(n_pixels), 1 << 16)
+        outs = []
+        with torch.no_grad():
+            for i in range(0, points.shape[0], step):
+                p, v = points[i:i + step].contiguous(), viewdirs[i:i + step].contiguous()
+                out, g = self.implicit_network.neus_model.sdf_network.eval_points(p, 2.0, 0.5, full=True, grad=True)
+                normals = ops.normalize3(g.contiguous(), TINY_NUMBER, 0)
+                outs.append(self.rendering_network(p, normals, v, out[:, 1:]))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def sample_dirs(self, normals, r_theta, r_phi):
+        """implicit_differentiable_renderer.py:548-564: directions at polar angle r_phi / azimuth r_theta [num_cam, num_samples] in the
+        tangent frame of normals [num_cam, num_samples, 3] (U = norm(x_axis x n), V = norm(n x U)) -> [num_cam, num_samples, 3]."""
+        if normals.dim() != 3 or normals.shape[-1] != 3:
+            raise ValueError("sample_dirs: normals [num_cam, num_samples, 3]")
+        if 3 in normals.shape[:-1]:
+            # the reference's torch.cross has no dim=: with a leading size of 3 it crosses along THAT axis (a deprecated torch default)
+            raise NotImplementedError("sample_dirs with num_cam == 3 or num_samples == 3: the reference's dim-less torch.cross picks the first "
+                                      "axis of size 3, not the vector axis -- not reproduced")
+        return ops.sample_dirs(normals.float().contiguous(), r_theta.float().contiguous(), r_phi.float().contiguous()).reshape(normals.shape)
 
     def get_sg_render(self, points, view_dirs, indir_lgtSGs, albedo_ratio=None, fun_spec=False, lin_diff=False,
                       train_spec=False, indir_integral=None, draws=None, chunk_id=None, n_chunks=1, stats=None, **kwargs):
@@ -573,9 +628,9 @@ def build_synthetic_model(device, seed=0, variance=0.3, sharp_light=False, build
     model = model.to(device).eval()
     if build_octrees:
         if use_octree:
-            model.ray_tracer.generate()
+            model.ray_tracer.generate(None)
             tree = model.ray_tracer.sdf_octree
             model.octree_ray_tracer.sdf_octree = type(tree)(tree.tables, 32)
         else:                   # secondary rays (trace_radiance) always use the octree tracer, primary rays the IDR tracer
-            model.octree_ray_tracer.generate()
+            model.octree_ray_tracer.generate(None)
     return model

@@ -27,12 +27,12 @@ def test_library_exports_header_symbols():
     if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.LEGACY_PATH)):
         _lib.build()
     L = _lib.lib()
-    assert L.rb_abi_version() == 7
+    assert L.rb_abi_version() == 8
     syms, leg = _header_symbols("robir_hip.h"), _header_symbols("robir_hip_legacy.h")
     assert 40 <= len(syms) <= 90 and len(leg) >= 30 and not set(syms) & set(leg)
     assert _exported(_lib.LIB_PATH) == syms                                      # nothing missing, nothing undeclared, nothing legacy
     assert _exported(_lib.LEGACY_PATH) == sorted(syms + leg)                     # the superset
-    assert _lib.legacy().rb_abi_version() == 7
+    assert _lib.legacy().rb_abi_version() == 8
     assert L.rb_packed_layer_floats(256, 256) == 16 * (16 + 256 * 16)
     # a retired entry point resolves to the legacy library, a current one to the default library
     assert _lib.resolve("rb_dvis_fused_v2")[0] is _lib.legacy() and _lib.resolve("rb_dvis_fused_x6t")[0] is L

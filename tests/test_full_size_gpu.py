@@ -174,7 +174,7 @@ def test_config3_trace_radiance_800(model, view800, dev):
 
 def test_config2_render_neus_400x400(dev, synth_weights):
     from robir_amd import nets, sdf_render, synth
-    m = nets.NeuSModel()
+    m = nets.NeuSModel(embed="PE")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
     m = m.to(dev).eval()
     uv, pose, K = synth.synth_camera(400, 400)
@@ -197,7 +197,7 @@ def test_config2_render_neus_400x400(dev, synth_weights):
     g = torch.Generator().manual_seed(0)
     perm = torch.randperm(R, generator=g)[:20000].to(dev)
     sub = sdf_render.Rays(ro[perm], dirs[perm].contiguous(), dirs[perm].contiguous(), None, None, near[perm], far[perm])
-    o2 = sdf_render.render_neus(sub, m, 1.0, is_eval=True)
+    o2 = sdf_render.render_neus(sub, m, 1.0, n_outside=0, is_eval=True)
     for k in ("rgb", "dist", "acc", "weights"):
         assert torch.equal(o2[k], out[k][perm]), k
 
@@ -208,7 +208,7 @@ def test_config1_sdf_forward_64x64x64(dev, synth_weights):
     where they need fewer than two thirds of the one-tile form's passes, one tile elsewhere (ops.sdf_two_tile) -- which sum a weight class's products in different orders: the whole batch
     and its 1024-row chunks agree to fp32 summation order (<= 2e-6 of the largest output), each form with itself bit for bit."""
     from robir_amd import nets, ops, synth
-    m = nets.NeuSModel()
+    m = nets.NeuSModel(embed="PE")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
     net = m.to(dev).eval().sdf_network
     uv, pose, K = synth.synth_camera(64, 64)

@@ -295,7 +295,7 @@ def test_sdf_value_kernels_eight_and_four_waves_agree(dev, synth_weights):
 
 def test_eval_points_picks_the_reverse_mode_for_large_batches(dev, synth_weights, monkeypatch):
     from robir_amd import nets, ops, synth
-    model = nets.NeuSModel()
+    model = nets.NeuSModel(embed="PE")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
     net = model.to(dev).eval().sdf_network
     g = torch.Generator().manual_seed(3)

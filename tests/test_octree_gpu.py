@@ -17,7 +17,7 @@ def dev():
 @pytest.fixture(scope="module")
 def neus(dev, synth_weights):
     from robir_amd import nets, synth
-    m = nets.NeuSModel()
+    m = nets.NeuSModel(embed="PE")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(synth_weights).items()})
     return m.to(dev).eval()
 
@@ -171,7 +171,7 @@ def test_build_second_sdf_and_mesh_box(dev):
     from robir_oracle import nets as on, octree as ooct
     import os
     w = synth.synth_state_dict(3, variance=0.6)
-    m = nets.NeuSModel()
+    m = nets.NeuSModel(embed="PE")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.neus_state_dict(w).items()})
     m = m.to(dev).eval()
     sd = on.as_torch(w)

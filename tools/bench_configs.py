@@ -133,7 +133,7 @@ def config2(model, reps=2):
     ro = (torch.from_numpy(pose[:3, 3]).to(dev) * 2.0).expand(R, 3).contiguous()
     near, far = torch.full((R, 1), 0.8, device=dev), torch.full((R, 1), 2.8, device=dev)
     rays = sdf_render.Rays(ro, dirs, dirs, None, None, near, far)
-    t = timed(lambda: sdf_render.render_neus(rays, neus, 1.0, n_samples=64, n_importance=64, up_sample_steps=4, is_eval=True),
+    t = timed(lambda: sdf_render.render_neus(rays, neus, 1.0, n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, is_eval=True),
               reps, (SDF_TIMER,))
     # 112 SDF evaluations for the sampling + 128 x (SDF+features, gradient, colour) = 0.59 GFLOP per ray
     return {"config": 2, "workload": "render_neus 400x400, 64+64 samples/ray, 4 up-sampling steps, colour net (Norm stage)",
