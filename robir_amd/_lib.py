@@ -68,8 +68,10 @@ def legacy():
     state (range sentinel block, device caches)."""
     global _legacy
     if _legacy is None:
-        _legacy = _load(LEGACY_PATH, "(the split-precision family and the other retired kernel generations live in the LEGACY library; the "
-                                     "default policy ROBIR_PRECISION=exact does not need it)")
+        _legacy = _load(LEGACY_PATH, "(the split-precision family and the other retired kernel generations live in the LEGACY library: build it "
+                                     "with `make -C robir_amd/csrc legacy` or ROBIR_BUILD_LEGACY=1.  ROBIR_PRECISION=split needs it, and so does "
+                                     "ROBIR_PRECISION=f16 for every net but the light-visibility MLP -- ROBIR_PRECISION=f16-vis and the default "
+                                     "policy ROBIR_PRECISION=exact do not; current policy: " + os.environ.get("ROBIR_PRECISION", "exact") + ")")
         if os.environ.get("ROBIR_SDF_RING_WAVES") in ("4", "8"):      # value rows of the split SDF net: csrc/sdf_ring8.hip | sdf_ring.hip
             _legacy.rb_sdf_ring_waves(int(os.environ["ROBIR_SDF_RING_WAVES"]))
     return _legacy

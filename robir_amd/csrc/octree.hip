@@ -16,6 +16,7 @@
 // (-ffp-contract=off, IEEE 1/d, NaN-propagating min/max like torch.minimum/maximum).
 #include "../../include/robir_hip.h"
 #include "common.h"
+#include <atomic>
 
 #include "octree_dev.h"
 #include <cstdlib>
@@ -548,10 +549,13 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
   if (R <= 0) return 0;
   RB_REQUIRE(node && nrm && origins && dirs && t && leaf && active && counters && arrive && x_out && hit_out && t_out, "null pointer");
   RB_REQUIRE(max_total >= 1, "max_total >= 1");
-  // Co-residency of the whole grid is a REQUIREMENT (the grid barrier spins): the launch is a cooperative one, which the runtime
-  // refuses (instead of deadlocking) when the grid cannot be resident -- another stream's kernel holding compute units, a second rank
-  // on the same device -- and the grid is sized from the occupancy query of THIS device (cached per device id: ranks of one process
-  // group may sit on different parts).  Status 2 = "not launched, take the per-iteration launches" (ops.octree_cast_general does).
+  // Co-residency of the whole grid is a REQUIREMENT (the grid barrier spins).  What guarantees it: (a) the grid never exceeds ONE workgroup
+  // per compute unit of THIS device (cached per device id; the callers' 16 384 rays x 4 lanes are 64 workgroups of 1024 threads) and the
+  // launch is a cooperative one, which the runtime validates against the kernel's STATIC occupancy (hipErrorCooperativeLaunchTooLarge:
+  // status 2 = "not launched, take the per-iteration launches", ops.octree_cast_general does); (b) under concurrent work on other streams /
+  // by a second rank on the device, residency rests on the runtime's cooperative queue, which dispatches a cooperative grid as a unit --
+  // the HIP API does not test DYNAMIC residency itself, and this repository has no stress test of that case (a hang would cost a GPU box);
+  // ROBIR_CAST_ONE_LAUNCH=0 takes the per-iteration launches wherever that guarantee is in doubt.
   static int lpr = 0;
   if (!lpr) {
     const char* e = getenv("ROBIR_CAST_LPR");
@@ -560,10 +564,10 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
   }
   const void* kern = lpr == 1 ? (const void*)k_cast_coop<1> : lpr == 4 ? (const void*)k_cast_coop<4> : (const void*)k_cast_coop<16>;
   constexpr int MAX_DEV = 64;
-  static int resident[MAX_DEV] = {};          // workgroups of this kernel the device holds at once; 0 = not queried yet
+  static std::atomic<int> resident[MAX_DEV];  // workgroups of this kernel the grid may have on the device; 0 = not queried yet (any thread may fill it: same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return rb::fail(__func__, "device query failed");
-  if (!resident[dev]) {
+  if (!resident[dev].load(std::memory_order_acquire)) {
     hipDeviceProp_t prop;
     int per_cu = 0;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
@@ -572,11 +576,12 @@ int rb_octree_cast_coop(const float* node, const float* nrm, long B, const float
       rb::fail(__func__, "cooperative launch not available on this device");
       return 2;
     }
-    resident[dev] = prop.multiProcessorCount * per_cu;
+    resident[dev].store(prop.multiProcessorCount, std::memory_order_release);      // one workgroup per compute unit, whatever per_cu allows
   }
   Oct T = make_oct(node, nrm, B, root_min, root_size, res);
   const long want = (R * lpr + 1023) / 1024;
-  const long cap = resident[dev] < CC_MAX_GROUPS ? resident[dev] : CC_MAX_GROUPS;
+  const int res_dev = resident[dev].load(std::memory_order_acquire);
+  const long cap = res_dev < CC_MAX_GROUPS ? res_dev : CC_MAX_GROUPS;
   const unsigned grid = (unsigned)(want < cap ? want : cap);
   int it_limit = max_iter > 0 ? max_iter + 1 : max_total;
   unsigned long long* arrive64 = (unsigned long long*)arrive;

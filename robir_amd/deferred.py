@@ -20,7 +20,9 @@ What a recorded pass computes is exactly IDRNetwork._render on the concatenated 
 execution, all stated in INTEGRATION.md: random numbers are drawn when the pass runs, starting from the generator state at the
 time of its first recorded chunk -- a caller that re-seeds or draws BETWEEN two chunk forwards is detected at the next forward()
 (the generator no longer is in the state the pass was recorded under): the pending chunks then run from their own state, the new
-chunk runs at once, i.e. such a loop gets immediate-execution results chunk for chunk (tests/test_deferred_gpu.py); weights must not
+chunk runs at once, i.e. such a loop gets immediate-execution results chunk for chunk (tests/test_deferred_gpu.py) -- also when it sets
+the SAME seed every time (the seeding functions of torch bump `seed_epoch()`; seeding through a Generator object's own methods is the one
+case that needs deferred_chunks = 0); weights must not
 change in place while chunks are pending (checked: RuntimeError); train(), eval(), load_state_dict(), load_light() and flush() run
 what is pending.  A pass holds the outputs of up to `deferred_chunks` chunks (128 x 1024 rays x 240 B = 31 MB) plus the pass's scratch
 (the direction tables of its chunks, 4.2 MB each: 0.5 GB for 128) -- sized for a 288 GB part, set ROBIR_DEFER_CHUNKS lower elsewhere.
@@ -53,6 +55,39 @@ def pass_sizes(n_chunks, limit, start=None):
 
 _NO_TF = torch._C.DisableTorchFunctionSubclass
 _LIVE = weakref.WeakSet()            # queues with recorded chunks that have not run
+
+# Seeding epoch: a caller that re-seeds with the SAME seed before every chunk leaves the generator in the state the pending
+# pass was recorded under, so comparing states cannot see it.  Every seeding / state-setting entry point of torch that is a Python
+# function is wrapped to bump a counter; a pass remembers the count at its first chunk and a different count at the next forward() is
+# treated like a changed state (the pending chunks run from their own state, the new chunk runs at once: immediate-execution results).
+# Not visible from here: methods called on a Generator OBJECT (gen.manual_seed / gen.set_state on torch.cuda.default_generators[i] or
+# torch.default_generator with an unchanged resulting state) -- C methods of an extension type; such loops set deferred_chunks = 0.
+_SEED_EPOCH = [0]
+
+
+def seed_epoch():
+    return _SEED_EPOCH[0]
+
+
+def _wrap_seeding(mod, name):
+    fn = getattr(mod, name, None)
+    if fn is None or getattr(fn, "_rb_seed_hook", False):
+        return
+    import functools
+
+    @functools.wraps(fn)
+    def hooked(*a, **k):
+        _SEED_EPOCH[0] += 1
+        return fn(*a, **k)
+    hooked._rb_seed_hook = True
+    setattr(mod, name, hooked)
+
+
+for _mod, _names in ((torch, ("manual_seed", "seed", "set_rng_state")), (torch.random, ("manual_seed", "seed", "set_rng_state")),
+                     (torch.cuda, ("manual_seed", "manual_seed_all", "seed", "seed_all", "set_rng_state", "set_rng_state_all")),
+                     (torch.cuda.random, ("manual_seed", "manual_seed_all", "seed", "seed_all", "set_rng_state", "set_rng_state_all"))):
+    for _n in _names:
+        _wrap_seeding(_mod, _n)
 
 # need the numbers (or write into them): run what is pending, then call the function on ordinary tensors
 _FORCE = frozenset((
@@ -244,6 +279,7 @@ class ChunkQueue:
         self.versions = _versions(model)
         gen = torch.cuda.default_generators[device.index or 0] if device.type == "cuda" else torch.default_generator
         self.gen, self.gen_state = gen, gen.get_state()
+        self.seed_epoch = seed_epoch()
         # recorded trace_radiance calls on this pass's chunks (slot -> nsamp; IDRNetwork.trace_radiance): they run behind the pass as ONE
         # grouped call, every chunk its own lock-step batch, the CPU generator's draws taken chunk by chunk in slot order
         self.trace, self.trace_nsamp, self.cpu_state, self.trace_result = {}, None, None, None
@@ -294,7 +330,11 @@ class ChunkQueue:
         if keys != set(self.spec):
             raise RuntimeError(f"deferred pass returned {sorted(keys ^ set(self.spec))} unexpectedly")
         if self.trace:
-            self._run_traces(model, hdr_rows)
+            try:
+                self._run_traces(model, hdr_rows)
+            except BaseException as e:          # keep the failure: get_trace re-raises it instead of unpacking a missing result
+                self.trace_error = e
+                raise
 
     # ------------------------------------------------------------------ recorded trace_radiance calls
     def record_trace(self, slot, nsamp):
@@ -343,6 +383,9 @@ class ChunkQueue:
 
     def get_trace(self, slot, name):
         self.flush()
+        if self.trace_result is None:
+            err = getattr(self, "trace_error", None)
+            raise RuntimeError("the recorded trace_radiance calls of this pass failed" + (f": {err!r}" if err is not None else "")) from err
         out, row0, hit0 = self.trace_result
         a, n = hit0[slot] if name == "sample_dirs" else row0[slot]
         return out[name][a:a + n]
@@ -383,6 +426,24 @@ class ChunkOutputs(dict):
     def pop(self, *a):
         self._dirty = True
         return dict.pop(self, *a)
+
+    def popitem(self):
+        self._dirty = True
+        return dict.popitem(self)
+
+    def clear(self):
+        self._dirty = True
+        dict.clear(self)
+
+    def setdefault(self, k, default=None):
+        if dict.__contains__(self, k) or k in self._q.spec:       # an output of the chunk: setdefault returns it, nothing changes
+            return self[k]
+        self._dirty = True
+        return dict.setdefault(self, k, default)
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
 
     def __missing__(self, k):
         q = self._q

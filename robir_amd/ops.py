@@ -600,6 +600,11 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
                  ptr(split["hidden_f16_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0), c_int(items_max), ptr(entries),
                  ptr(pair_vis), ptr(round_info), ptr(item_info), ptr(counters), c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count),
                  stream_ptr())
+            if os.environ.get("ROBIR_RANGE_CHECK", "") == "sync" and int(counters[3].item()) != 0:
+                # counters[3]: chunk ids not ascending (a list whose order was only ASSERTED through the `_robir_ascending` attribute) or more
+                # items than the scratch holds -- the kernel then leaves its NaN fill in `out`.  Read in the debug mode only: a host sync.
+                raise _lib.RobirHipError("rb_dvis_pblock_f16: chunk ids are not ascending or the item scratch overflowed -- the outputs "
+                                         "of this call are NaN (ADVICE r5; run without the `_robir_ascending` tag to let ops check the order)")
             return out
         pair_j = torch.empty(n * LS, dtype=torch.int16, device=dev)
         pair_vis = torch.empty(n * LS, dtype=torch.float32, device=dev)
@@ -756,8 +761,10 @@ def octree_cast_general(T, origins, dirs, max_iter, step, check_every=16, max_to
         t_out = torch.empty(R, dtype=torch.float32, device=dev)
         rc = 0
         if R > 0:
-            # status 2: the cooperative launch was refused (the grid could not be co-resident: a side stream or another rank holds
-            # compute units) and nothing ran -- the per-iteration launches below give the same bits
+            # status 2: the cooperative launch was refused by the runtime's STATIC occupancy check (or the device lacks cooperative
+            # launches) and nothing ran -- the per-iteration launches below give the same bits.  The grid is at most one workgroup per
+            # compute unit; residency beside concurrent work on other streams rests on the runtime's cooperative queue and is not
+            # stress-tested here: ROBIR_CAST_ONE_LAUNCH=0 where in doubt (csrc/octree.hip)
             rc = _lib.lib().rb_octree_cast_coop(*a, ptr(origins), ptr(dirs), c_long(R), c_int(max_iter), ctypes.c_double(step),
                                                 c_int(max_total), c_float(T.clamp_dt), ptr(t), ptr(leaf), ptr(active), ptr(counters),
                                                 ptr(arrive), ptr(x), ptr(hit), ptr(t_out), stream_ptr())

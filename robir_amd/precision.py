@@ -18,18 +18,20 @@
                                     those nets, and a throughput policy that left them at six products gave the CESR stage 18 %.
                                     NARROWER than the reference's fp32: never a default, never a parity claim; its measured
                                     error against a float64 evaluation is in DESIGN.md and printed by tests/test_precision_gpu.py.
+  ROBIR_PRECISION=f16-vis           round 4's meaning of `f16`, kept selectable: plain f16 for the light-visibility MLP only,
+                                    every other net on the exact-operand kernels -- needs the default library only.
 ROBIR_VIS_PRECISION / ROBIR_MLP_PRECISION override the two halves of the policy separately (A/B runs, tests).
 """
 import os
 
-POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3"), "f16": ("f16x1", "f16x3")}
+POLICIES = {"exact": ("f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3"), "f16": ("f16x1", "f16x3"), "f16-vis": ("f16x1", "f16x6")}
 VIS_MODES = ("fp32", "f16x6", "f16x3-auto", "f16x3-v3", "f16x3-v2", "f16x3", "f16x1", "f16x6-1t", "f16x6-pt", "f16x6-stream")
 
 
 def policy():
     p = os.environ.get("ROBIR_PRECISION", "exact")
     if p not in POLICIES:
-        raise ValueError("ROBIR_PRECISION must be exact, split or f16")
+        raise ValueError("ROBIR_PRECISION must be exact, split, f16 or f16-vis")
     return p
 
 

@@ -182,8 +182,9 @@ class IDRNetwork(nn.Module):
         mask = input["object_mask"].reshape(-1)
         hook = self.get_sg_render
         q = self.__dict__.get("_pending")
-        if q is not None and not torch.equal(q.gen.get_state(), q.gen_state):
-            # The caller re-seeded or drew random numbers since the pending pass recorded its first chunk: it manages the generator per
+        if q is not None and (q.seed_epoch != deferred.seed_epoch() or not torch.equal(q.gen.get_state(), q.gen_state)):
+            # The caller re-seeded (deferred.seed_epoch: also with the SAME seed, which leaves the state unchanged -- ADVICE r5) or drew
+            # random numbers since the pending pass recorded its first chunk: it manages the generator per
             # chunk, and a pass would draw this chunk's numbers from the wrong state.  Run what is pending -- from the state
             # its chunks were recorded under, q.flush() then puts the caller's state back -- and run THIS chunk at once: both are exactly
             # what immediate execution gives.  (None: forward() falls through to the immediate path.)
@@ -248,6 +249,7 @@ class IDRNetwork(nn.Module):
         """Batch size B > 1 (no runner uses it): the reference casts the B x N rays of the B views as ONE lock-step batch from their
         own camera centres and flattens every output to [B N, ...] (implicit_differentiable_renderer.py:299-305,324); every ray is
         traced, `object_mask` only travels along."""
+        self.flush()          # a pass recorded by earlier uv-form chunk forwards runs first (ADVICE r5: it must not stay pending across this call)
         uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
         if pose.dim() == 2 and pose.shape[1] == 7:       # quaternion form, one 7-vector per view (rend_util.py:52-57)
             pose = torch.stack([ops.pose_matrix(pose[b]) for b in range(pose.shape[0])])
@@ -265,6 +267,7 @@ class IDRNetwork(nn.Module):
     def _forward_points_dirs(self, input, trainstage, fun_spec, lin_diff, draws, stats):
         """Second input form (implicit_differentiable_renderer.py:306-322): per-ray origins `points` and directions
         `dirs`; rays outside `object_mask` are not traced (dist 0, no hit).  One lock-step batch."""
+        self.flush()          # a pass recorded by earlier uv-form chunk forwards runs first (ADVICE r5: it must not stay pending across this call)
         o = input["points"].reshape(-1, 3).float()
         d = input["dirs"].reshape(-1, 3).float().contiguous()
         N = o.shape[0]

@@ -17,6 +17,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _legacy_missing(excinfo):
+    """A test reached a retired kernel generation (split precision, first-generation kernels: robir_amd/librobir_hip_legacy.so) on a
+    tree whose legacy library was not built -- `make -C robir_amd/csrc legacy` / ROBIR_BUILD_LEGACY=1 (round 6: no longer on
+    __graft_entry__.build()'s default path).  Such a test is SKIPPED, not failed: the default policy never needs that library
+    (tests/test_default_library_gpu.py proves it with the loader made to fail)."""
+    if excinfo is None:
+        return False
+    e = excinfo[1]
+    return type(e).__name__ == "RobirHipError" and "librobir_hip_legacy.so not found" in str(e)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_setup(item):
+    outcome = yield
+    if _legacy_missing(outcome.excinfo):
+        outcome.force_exception(pytest.skip.Exception("needs robir_amd/librobir_hip_legacy.so (ROBIR_BUILD_LEGACY=1)"))
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    outcome = yield
+    if _legacy_missing(outcome.excinfo):
+        outcome.force_exception(pytest.skip.Exception("needs robir_amd/librobir_hip_legacy.so (ROBIR_BUILD_LEGACY=1)"))
+
+
 @pytest.fixture(autouse=True)
 def _inference_mode_like_the_plot_path():
     """The kernels are forward-only and guard against training-mode calls (robir_amd.nets.forward_only_guard); tests render
@@ -158,3 +183,33 @@ def oracle_tables_from_device(Td):
     T.sdf_nrm, T.centre = Td.nrm.cpu(), T.box_min + T.box_size * 0.5
     T.hit, T.min_step = T.sdf_val <= 1e-4, Td.min_step
     return T
+
+
+def cull_marked_points(lgt_sgs, u_theta, u_phi, n_oracle, n_kernel, thr=1.0, ulps=4):
+    """Which surface points have a sampled light direction ON the reference's `n.d > 1e-6` cull (model/sg_render.py:155)?
+
+    lgt_sgs [L,7] the light (first row's light is used for every point, sg_render.py:388-390), u_theta / u_phi [L,nsamp] the recorded
+    draws, n_oracle / n_kernel [n,3] the shading normal of the two evaluations.  The sampled directions depend on the light and the draws
+    only, so they are rebuilt here with the oracle's own functions.  A (point, direction) pair is MARKED if the two normals put it on
+    different sides of the threshold, or if the oracle's cosine lies within the rounding of an fp32 dot product of the threshold:
+    |n.d - 1e-6| <= ulps * 2^-24 * sum_i |n_i d_i|  (the products are O(1) and cancel to 1e-6: the sum's absolute rounding error is set
+    by the terms, not by the result).  Returns (marked_points bool [n], marked_pairs int): a marked point may differ between two
+    fp32-accurate evaluations by one sample of a lobe's 32 moving in or out of the average -- O(1e-4 .. 1e-3) of a lobe, by construction
+    not an arithmetic error; every UNMARKED point took the same cull decisions in both."""
+    from robir_oracle import sg as osg
+    lobe = lgt_sgs[:, :3] / (lgt_sgs[:, :3].norm(dim=-1, keepdim=True) + osg.TINY)
+    lam = lgt_sgs[:, 3:4].abs()
+    axis = osg.unit_eps(lobe.unsqueeze(-2))
+    sharp = lam.unsqueeze(-2)[:, :, 0].clamp(min=1e-4)
+    rng = sharp.min().clamp(max=thr)
+    dirs = osg._cone_dirs(axis, u_theta, u_phi, torch.arccos((-0.95 * rng) / sharp + 1)).reshape(-1, 3).double()     # [L*nsamp,3]
+    no, nk = n_oracle.double(), n_kernel.double()
+    marked = torch.zeros(no.shape[0], dtype=torch.bool)
+    pairs = 0
+    for a in range(0, no.shape[0], 256):                       # [256, L*nsamp] blocks
+        o, k = no[a:a + 256] @ dirs.T, nk[a:a + 256] @ dirs.T
+        band = ulps * 2.0 ** -24 * (no[a:a + 256].abs() @ dirs.abs().T)
+        m = ((o > osg.TINY) != (k > osg.TINY)) | ((o - osg.TINY).abs() <= band)
+        marked[a:a + 256] = m.any(-1)
+        pairs += int(m.sum())
+    return marked, pairs

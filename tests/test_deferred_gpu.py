@@ -271,6 +271,49 @@ def test_reseeding_per_chunk_under_default_settings_gives_immediate_results(dev,
         model.__dict__.pop("deferred_chunks", None)
 
 
+def test_constant_seed_per_chunk_gives_immediate_results(dev, model):
+    """a loop that calls torch.manual_seed(0) before EVERY chunk leaves the generator in exactly the state the pending pass was
+    recorded under -- comparing states cannot see it.  The seeding entry points bump deferred.seed_epoch(); forward() treats a new epoch
+    like a changed state: chunk k draws from the seed, not from the stream advanced by chunks 0..k-1.  torch.cuda.manual_seed_all and
+    torch.cuda.set_rng_state count too."""
+    from robir_amd import deferred
+    model.__dict__.pop("deferred_chunks", None)
+    if not deferred.DEFAULT_CHUNKS:
+        pytest.skip("ROBIR_DEFER_CHUNKS=0 in this environment")
+    mi, total = _view(dev, 64, 64)
+    split = split_input(mi, total)
+    for s in split:
+        s["hdr_shift"] = torch.full((1024, 1), 0.5, device=dev)
+    keys = ("sg_rgb", "indir_rgb", "vis_shadow")
+    e0 = deferred.seed_epoch()
+    torch.manual_seed(0)
+    assert deferred.seed_epoch() > e0            # (torch.manual_seed seeds the CUDA generators through torch.cuda.manual_seed_all: two bumps)
+    state0 = torch.cuda.get_rng_state(dev)
+    seeders = (lambda: torch.manual_seed(0), lambda: torch.cuda.manual_seed_all(0), lambda: torch.cuda.set_rng_state(state0, dev),
+               lambda: torch.manual_seed(0))
+    try:
+        lazy = []
+        for s, seed in zip(split, seeders):
+            seed()
+            lazy.append(model(s, trainstage="Material"))
+        got = [{k: o[k].cpu() for k in keys} for o in lazy]
+        model.flush()
+        model.deferred_chunks = 0
+        for i, s in enumerate(split):
+            torch.manual_seed(0)
+            now = model(s, trainstage="Material")
+            for k in keys:
+                assert _same(got[i][k], now[k]), (i, k)
+        # the draws matter: without the per-chunk seed chunk 1 differs
+        torch.manual_seed(0)
+        model(split[0], trainstage="Material")
+        other = model(split[1], trainstage="Material")
+        assert not _same(got[1]["vis_shadow"], other["vis_shadow"])
+    finally:
+        model.flush()
+        model.__dict__.pop("deferred_chunks", None)
+
+
 @pytest.mark.parametrize("stage", ["Material", "Illum"])
 def test_recorded_trace_radiance_per_chunk_equals_the_immediate_calls(dev, deferring, stage):
     """The CESR / visibility runners call `trace_radiance(out, nsamp=8)` right after every chunk forward and only reduce its results

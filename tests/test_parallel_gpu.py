@@ -123,6 +123,16 @@ def test_bench_starts_its_own_ranks():
     if torch.cuda.device_count() < 2:
         assert d["config"]["ranks_share_one_gpu"] and d["config"]["collective_backend"] == "gloo"
     assert "weak_views" in d and d["roofline"]["frac"] > 0
+    # SCALE-run diagnostics (VERDICT r5 task 6): per-rank chunks / own step time / kernel time, the collective alone, the roofline of the
+    # slowest rank, DESIGN section 7's prediction -- a reader can tell imbalance from collective time from start-up skew from the line alone
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and sum(r["chunks"] for r in pr) == 625 and abs(pr[0]["chunks"] - pr[1]["chunks"]) <= 1
+    assert all(r["step_ms"] > 0 and 0 < r["dvis_kernel_ms_per_step"] <= r["step_ms"] * 1.05 and r["visibility_pairs_per_step"] > 0 for r in pr)
+    assert d["allgather_ms"] > 0 and d["predicted_ms_per_step"]["value"] > 0
+    slow = max(pr, key=lambda r: r["dvis_kernel_ms_per_step"])
+    assert d["roofline"]["of_rank"] == slow["rank"]
+    assert abs(d["roofline"]["avg_launch_ms"] * d["roofline"]["launches"] / d["steps"] - slow["dvis_kernel_ms_per_step"]) <= 1e-6 * slow["dvis_kernel_ms_per_step"] + 1e-9
+    assert max(r["step_ms"] for r in pr) <= d["ms_per_step"] * 1.001
 
 
 def _rccl_worker(port, q):

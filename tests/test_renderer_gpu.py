@@ -43,6 +43,46 @@ FIELDS = ("sg_rgb", "indir_rgb", "sg_diffuse_rgb", "sg_specular_rgb", "indir_dif
           "random_xi_metallic", "random_xi_diffuse_albedo")
 
 
+# fields whose only > 1e-4 differences between two fp32 evaluations are cull flips; the two specular-lobe sums are differences of
+# hemisphere integrals that cancel to ~1e-3 of their terms -- there two fp32 evaluations of the reference's own formulas are a few 1e-4
+# apart (tests/test_sg_gpu.py::test_render_with_sg_fun_spec_vs_oracle anchors both on float64), cull or no cull
+CULL_EXACT_FIELDS = ("vis_shadow", "sg_rgb", "sg_diffuse_rgb", "indir_rgb", "indir_diffuse_rgb", "diffuse_albedo", "roughness", "metallic",
+                     "normals", "normal_map", "random_xi_roughness", "random_xi_metallic", "random_xi_diffuse_albedo")
+
+
+def _assert_unmarked_within_1e4(out, ref, lgt_sgs, draws, tag, hit=None, max_marked_frac=0.01, skip=()):
+    """-> number of UNATTRIBUTED entries beyond 1e-4 over CULL_EXACT_FIELDS (asserted 0 by the callers); prints / records the marked count."""
+    from conftest import cull_marked_points, record_metric
+    h = ref["network_object_mask"] if hit is None else hit
+    h = torch.as_tensor(h).bool()
+    marked, pairs = cull_marked_points(torch.as_tensor(lgt_sgs), draws["dvis_theta"], draws["dvis_phi"], torch.as_tensor(ref["normal_map"])[h],
+                                       out["normal_map"].cpu()[h])
+    n_hit = int(h.sum())
+    assert int(marked.sum()) <= max(2, max_marked_frac * n_hit), (int(marked.sum()), n_hit)        # a handful of points: 0.1-0.4 % measured
+    bad = 0
+    worst = {}
+    for k in CULL_EXACT_FIELDS:
+        if k in skip:
+            worst[k] = float("nan")
+            continue
+        a, b = out[k].cpu()[h].double(), torch.as_tensor(ref[k])[h].double()
+        e = (a - b).abs() / (b.abs() + b.abs().mean())                      # the repo's floored relative error (conftest.rel_err)
+        eu = e[~marked]
+        worst[k] = float(eu.max()) if eu.numel() else 0.0
+        bad += int((eu > 1e-4).sum())
+    plain = {}
+    for k in ("vis_shadow", "sg_rgb"):                                       # the plain relative error of the same entries, where |ref| is not tiny
+        a, b = out[k].cpu()[h].double()[~marked], torch.as_tensor(ref[k])[h].double()[~marked]
+        big = b.abs() > 1e-3 * b.abs().mean()
+        plain[k] = float(((a - b).abs()[big] / b.abs()[big]).max()) if bool(big.any()) else 0.0
+    print(f"[cull attribution/{tag}] {int(marked.sum())} of {n_hit} hit points ({pairs} of {n_hit * 4096} pairs) on the n.d > 1e-6 cull; "
+          f"{bad} unattributed entries > 1e-4; worst unmarked: vis_shadow {worst['vis_shadow']:.1e}, sg_rgb {worst['sg_rgb']:.1e}, "
+          f"indir_rgb {worst['indir_rgb']:.1e} (plain relative: vis_shadow {plain['vis_shadow']:.1e}, sg_rgb {plain['sg_rgb']:.1e})")
+    record_metric("cull_attribution/" + tag, marked_points=int(marked.sum()), hit_points=n_hit, marked_pairs=pairs, unattributed=bad,
+                  worst_unmarked_vis_shadow=worst["vis_shadow"], worst_unmarked_sg_rgb=worst["sg_rgb"])
+    return bad
+
+
 def test_forward_material_vs_oracle_same_tables(dev, model_oracle_tables, oracle_sd, oracle_octree):
     from robir_amd import synth
     from robir_oracle import renderer as orend
@@ -76,6 +116,13 @@ def test_forward_material_vs_oracle_same_tables(dev, model_oracle_tables, oracle
     for k in FIELDS:
         assert bad_frac(out[k].cpu(), ref[k], 2e-4) <= 0.005, (k, bad_frac(out[k].cpu(), ref[k], 2e-4))
         assert rel_err(out[k].cpu(), ref[k]) <= 1e-3, (k, rel_err(out[k].cpu(), ref[k]))
+    # north_star's 1e-4 on EVERY entry that is not attributable to a threshold decision (VERDICT r5 task 4): the points with a sampled
+    # light direction ON the reference's n.d > 1e-6 cull (model/sg_render.py:155) are identified from the oracle's own directions and the
+    # two evaluations' normals (conftest.cull_marked_points); every other hit point took the same 4096 cull decisions in both, and
+    # there every field but the two specular-lobe sums holds 1e-4 (floored) -- measured: 1.9e-7 for vis_shadow, whose 2.2e-4 outliers
+    # are exactly the marked points.
+    unattributed = _assert_unmarked_within_1e4(out, ref, oracle_sd["envmap_material_network.lgtSGs"], drt, "same_tables")
+    assert unattributed == 0
     # every key / shape / dtype of the reference's return dict
     g = load_golden("forward_material_c1")
     for k in g:
@@ -448,18 +495,33 @@ def test_relight_forward_vs_reference_golden(dev, env_id):
     uv_t, pose_t, K_t = torch.from_numpy(uv[sl])[None], torch.from_numpy(pose)[None], torch.from_numpy(K)[None]
     dirs, cam = orend.camera_rays(uv_t, pose_t, K_t)
     _, hit, _ = ooct.trace(T, cam, dirs, -1)
-    if int(hit.sum()) == int(g["n_hit"]):          # the draws are sized by the reference's hit count
-        env = m.envmap_material_network.envmap.cpu()
-        ref = orend.forward(sd, T, uv_t, pose_t, K_t, torch.ones(1, 1024, dtype=torch.bool), hdr, draws, "Material", testing=True, envmap=env)
-        assert bool((out["network_object_mask"] == ref["network_object_mask"]).all())
-        assert rel_err(out["bg_rgb"], ref["bg_rgb"]) <= 1e-4
-        for k in FIELDS:
-            frac, worst = bad_frac(out[k], ref[k], 2e-4), rel_err(out[k], ref[k])
-            record_metric("forward_relit_%d_vs_oracle_same_cells/%s" % (env_id, k), frac_gt_2e4=frac, max=worst)
-            if k in loose:
-                assert frac <= 0.1 and worst <= 5e-3, (k, frac, worst)
-            else:
-                assert frac <= 0.005 and worst <= 1e-3, (k, frac, worst)
+    # The recorded draws are sized by the REFERENCE's hit count.  Should this octree (device-built) disagree by a ray, the per-hit draws are
+    # re-sized (recorded rows kept, rows of extra hits drawn from robir_amd.synth) and the kernel forward is repeated with them, so that this
+    # leg ALWAYS runs (it used to be skipped silently on a one-ray difference).
+    n_here = int(hit.sum())
+    if n_here != int(g["n_hit"]):
+        extra = synth.pbr_draws(1234, n_here, chunk_id=c)
+        draws = {k: (torch.cat([v[:n_here], torch.from_numpy(extra[k])[v.shape[0]:n_here]]) if v.shape[0] == int(g["n_hit"]) and k.split("_")[0] in ("illum", "spec", "normal", "svis") else v)
+                 for k, v in draws.items()}
+        out = m(inp, trainstage="Material", train_spec=True, draws={k: v.to(dev) for k, v in draws.items()})
+        out = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+    env = m.envmap_material_network.envmap.cpu()
+    ref = orend.forward(sd, T, uv_t, pose_t, K_t, torch.ones(1, 1024, dtype=torch.bool), hdr, draws, "Material", testing=True, envmap=env)
+    assert bool((out["network_object_mask"] == ref["network_object_mask"]).all())
+    assert rel_err(out["bg_rgb"], ref["bg_rgb"]) <= 1e-4
+    for k in FIELDS:
+        frac, worst = bad_frac(out[k], ref[k], 2e-4), rel_err(out[k], ref[k])
+        record_metric("forward_relit_%d_vs_oracle_same_cells/%s" % (env_id, k), frac_gt_2e4=frac, max=worst)
+        if k in loose:
+            assert frac <= 0.1 and worst <= 5e-3, (k, frac, worst)
+        else:
+            assert frac <= 0.005 and worst <= 1e-3, (k, frac, worst)
+    # the cull attribution under the shipped (sharp, un-normalised) light: sg_rgb joins the ill-conditioned specular fields here (see
+    # `loose`), every other cull-exact field holds 1e-4 on the points off the cull
+    dev_out = {k: v for k, v in out.items()}
+    bad = _assert_unmarked_within_1e4(dev_out, ref, sd["envmap_material_network.lgtSGs"], draws, "relit_%d" % env_id, max_marked_frac=0.02,
+                                      skip=("sg_rgb",))
+    assert bad == 0
 
 
 def test_exact_and_split_precision_forward_agree(dev, model, monkeypatch):
