@@ -177,6 +177,58 @@ __device__ __forceinline__ void xt_chunk(int part0, SxAcc (&acc)[2], XtWin& w, c
   }
 }
 
+// The K-MAJOR form of a chunk (round 6, VERDICT r5 task 2): the same MFMAs, but k-block by k-block -- the twelve products of one k-block
+// (six per tile) go to twelve DIFFERENT accumulator/piece combinations, so no two consecutive MFMAs extend the same chain -- with a filler
+// slot behind EVERY MFMA instead of a cluster behind every run of WK.  tools/microbench/mfma_order.hip: two independent vector
+// instructions behind every MFMA cost 17.9 cycles per MFMA, the same instructions in clusters of eight behind every fourth 23.8 -- only the
+// last MFMA of a run shadows its cluster.  filler(slot): slot = 0 .. 12 K/32 - 1, at most ~2 single-issue instructions each (the caller
+// cuts its epilogue into such steps); a sched_barrier pins every [MFMA, fillers] group.  refill(piece, part, k): the window entry k of
+// `piece` is free (its last product of this part has been issued): request the fragment of the next part / the next chunk into it.
+// Summation order: a class's products are added k-block by k-block (c2: h.xl, m.xm, l.xh of k-block 0, then of k-block 1, ...) instead of
+// product by product over a part -- another fp32 order than xt_chunk's (last-bit differences, like the one-tile kernels').
+template <int K, int KBX, class Filler, class Refill>
+__device__ __forceinline__ void xt_chunk_km(SxAcc (&acc)[2], XtWin& w, const XtOps<KBX>& x, Filler&& filler, Refill&& refill) {
+  constexpr int WK = xt_wk(K), NPART = xt_parts(K);
+  static_assert(K / 32 <= KBX, "");
+#pragma unroll
+  for (int part = 0; part < NPART; ++part) {
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+      const int kb = part * WK + k, s0 = (part * WK + k) * 12;
+#define XT_KM_(I, ACC, WP, XP)            \
+  XT_MFMA_(ACC, WP[k], XP[kb]);           \
+  filler(s0 + (I));                       \
+  __builtin_amdgcn_sched_barrier(0)
+      XT_KM_(0, acc[0].c0, w.h, x.h[0]);
+      XT_KM_(1, acc[1].c0, w.h, x.h[1]);
+      XT_KM_(2, acc[0].c1, w.h, x.m[0]);
+      XT_KM_(3, acc[1].c1, w.h, x.m[1]);
+      XT_KM_(4, acc[0].c2, w.h, x.l[0]);
+      XT_MFMA_(acc[1].c2, w.h[k], x.l[1][kb]);
+      refill(0, part, k);
+      filler(s0 + 5);
+      __builtin_amdgcn_sched_barrier(0);
+      XT_KM_(6, acc[0].c1, w.m, x.h[0]);
+      XT_KM_(7, acc[1].c1, w.m, x.h[1]);
+      XT_KM_(8, acc[0].c2, w.m, x.m[0]);
+      XT_MFMA_(acc[1].c2, w.m[k], x.m[1][kb]);
+      refill(1, part, k);
+      filler(s0 + 9);
+      __builtin_amdgcn_sched_barrier(0);
+      XT_KM_(10, acc[0].c2, w.l, x.h[0]);
+      XT_MFMA_(acc[1].c2, w.l[k], x.h[1][kb]);
+      refill(2, part, k);
+      filler(s0 + 11);
+      __builtin_amdgcn_sched_barrier(0);
+#undef XT_KM_
+    }
+  }
+}
+// one window entry (k-block `kb` of the chunk in `slot_lane_addr`) of one piece
+__device__ __forceinline__ void xt_request_one(u4& dst, unsigned slot_lane_addr, int kb, int piece) {
+  dst = ((xt_lds_u4p)slot_lane_addr)[(kb * 3 + piece) * 64];
+}
+
 // positions of a chunk that carry fillers: all but the three refill runs of a part (5, 9, 11) -> 9 per part; index of position pos among
 // them, or -1
 __host__ __device__ constexpr int xt_free_index(int pos) {

@@ -315,7 +315,10 @@ class ChunkQueue:
         self.running = True
         try:
             now = self.gen.get_state()
-            untouched = torch.equal(now, self.gen_state)
+            # "untouched": nobody seeded or drew since the first chunk was recorded -- then the pass consuming the stream is what immediate
+            # execution would have done.  A re-seed with the SAME seed leaves an equal state but is a touch (seed_epoch): the caller's
+            # state is put back afterwards, so that the chunk it seeded for draws from the seed
+            untouched = torch.equal(now, self.gen_state) and self.seed_epoch == seed_epoch()
             self.gen.set_state(self.gen_state)       # draw as if the pass had run when its first chunk was recorded
             n = self.rays
             hdr = self.hdr[:n] if self.hdr is not None else None
