@@ -59,7 +59,7 @@ PRECISIONS = {
               "fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the 32 -> 128 "
               "-> 16 auto-encoder decoders on the f32-input MFMA) -- not narrower than the reference's fp32"),
     "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
-    "f16": ("f16x1", "f16x3", "f16 (light-visibility MLP: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
+    "f16": ("f16x1", "f16x3", "f16 (light-visibility MLP and the two CESR nets: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
                               "every other net in split precision: f16 hi/lo pairs, 3 products) -- NARROWER than the reference's fp32: a labelled "
                               "throughput mode (BASELINE.json configs[4]: 'fp16 MLP weights on MFMA'), not a parity claim; error table in DESIGN.md"),
     "split": ("f16x3-auto", "f16x3", "f32 operands as 22-bit f16 hi/lo pairs, 3 f16 MFMA products per multiply-add, fp32 accumulate "
@@ -269,6 +269,7 @@ def set_precision(name, vis_override=None):
     vis = vis_override or vis
     sg_render.VIS_PRECISION = vis
     os.environ["ROBIR_MLP_PRECISION"] = mlp
+    os.environ["ROBIR_CESR_PRECISION"] = "f16x1" if name == "f16" else mlp      # the f16 policy's CESR nets: plain f16 too (csrc/cesr_f16.hip, round 6)
     return vis, mlp, dtype
 
 

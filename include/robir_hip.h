@@ -108,6 +108,13 @@ int rb_wide_x6(const float* X /* feature rows [M,64] */, long M, const float* Wp
 /* The CESR nets on exact three-piece operands (csrc/cesr_x6.hip; Wp = packing.pack_softplus512_x6): the arguments of rb_cesr_net_points
  * (kind 0: normal_net on PE10(x), 2: shadow_net on (point, one-hot label) rows). */
 int rb_cesr_net_x6_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, int n_workgroups, rb_stream_t stream);
+/* The CESR nets in PLAIN f16 (csrc/cesr_f16.hip, round 6): ONE f16 MFMA product per multiply-add, f16 weights (the h pieces of the
+ * exact-operand blob: Wp = packing.pack_softplus512_f16 = [16 biases per chunk of the stream][1 KB fragments, k-block major]), f16
+ * activations truncated between the layers, fp32 accumulation -- the labelled THROUGHPUT mode BASELINE.json configs[4] names
+ * ("fp16 MLP weights on MFMA", ROBIR_PRECISION=f16): NARROWER than the reference's fp32, never a parity claim.  The arguments of
+ * rb_cesr_net_x6_points + tiles = 16-row tiles per wave the library was built with (3). */
+int rb_cesr_net_f16_points(const float* x, long M, int kind, int n_label, const float* Wp, float* Y, int tiles, int n_workgroups,
+                           rb_stream_t stream);
 /* two_tile = 1: two tiles per wave in the value and the reverse pass (csrc/sdf_x6t.hip, sdf_back_x6t.hip); Wt then = the transposed layers
  * packed with W3^T's K padded to 256 (packing.pack_sdf_back_x6(two_tile=True)).  Same scratch. */
 int rb_sdf_value_grad_x6_points(const float* x, long M, float in_scale, const float* Wp, const float* Wt, const float* w8row,

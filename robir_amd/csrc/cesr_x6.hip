@@ -250,7 +250,11 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
         }
         {
           const int s2 = st + D;
+#ifdef QX_ABL_NOREAD                     // timing ablation (wrong results): the fragment registers are never refilled
+          if (false) {
+#else
           if (s2 < NSTEP) {
+#endif
             const u4* f = frag_of(s2 / KB) + (3 * (s2 % KB)) * 64;
             wfl[s2 % NB] = f[128];
             wfm[s2 % NB] = f[64];
@@ -268,14 +272,19 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           QX_MFMA(acc.c0, wfh[st % NB], xh[xk]);
 #undef QX_MFMA
         }
+#ifndef QX_ABL_NOEPI                     // timing ablation (wrong results): no softplus / split between the MFMAs
         if (c > 0 && hvi == 0) {              // softplus + three-way split (or the store) of chunk c-1
           if (kb == 0) epilogue(accs[(c - 1) & 1], c - 1, 0);
           if (kb == (KB >= 6 ? 3 : 1)) epilogue(accs[(c - 1) & 1], c - 1, 1);
         }
+#endif
         if (kb >= HB) {
 #pragma unroll
           for (int un = 0; un < 3; ++un)
             if (un < nu3 && (un * (KB - HB)) / nu3 == kb - HB) {
+#ifdef QX_ABL_NODMA                      // timing ablation (wrong results): no LDS-DMA copies after the prologue's
+              continue;
+#endif
               if (K3 == 64) qx_copy<64>(un, src3, lane4, lane16, bdst3, dst3, wave);
               else if (K3 == 192) qx_copy<192>(un, src3, lane4, lane16, bdst3, dst3, wave);
               else if (K3 == 256) qx_copy<256>(un, src3, lane4, lane16, bdst3, dst3, wave);

@@ -24,6 +24,9 @@
 #include "x6t_engine.h"
 #include <type_traits>
 
+#ifndef SXT_FINE
+#define SXT_FINE 0          // 1: hidden 256 x 256 layers (the instance of layers 1, 2, 5, 6) in the K-MAJOR form with the epilogue cut into single-instruction steps, two behind every MFMA (x6t_engine.h: xt_chunk_km)
+#endif
 #ifndef SXT_STORE128
 #define SXT_STORE128 0      // 1: one 16-byte sigmoid store per tile and chunk instead of two 8-byte ones: measured equal (11.14 vs 11.09 ms value + gradient), more spills
 #endif
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       if (out_layer) return FULL ? (pj < 16 ? 8 : 2) : (pj == 0 ? 2 : 0);
       return STORE ? (SXT_STORE128 ? 2 : 4) : 0;
     };
-    SxAcc acc[2];
+    constexpr bool FINE = SXT_FINE != 0 && LI == 1;      // K = 256, hidden, not the skip layer
+    SxAcc accs[FINE ? 2 : 1][2];                          // FINE: chunk jb accumulates into set jb & 1 while the steps of chunk jb - 1 read the other
     constexpr bool PREV_SKIPOUT = LI == 4, PEND = LI != 0;      // the layer before this one: its outputs are scaled (layer 3) / it left its last chunk pending (every hidden layer)
     const f4* wl = Wp + sx_coff(cb, LAST);
     const f4* wnext[3];
@@ -300,9 +304,107 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
       const f4* src3 = (jb + 3 < NCH ? wl + (long)(jb + 3) * sx_cf4(K) : wnext[jb + 3 - NCH < 3 ? jb + 3 - NCH : 0]) + 4 + f3 * 64;
       const unsigned dst3 = ring_b + slot_b[(jb + 3) & 3] + (unsigned)f3 * 1024u;
       f4 nbias;
+      SxAcc(&acc)[2] = accs[FINE ? (jb & 1) : 0];
       acc[0].c0 = bias;
       acc[1].c0 = bias;
       acc[0].c1 = acc[0].c2 = acc[1].c1 = acc[1].c2 = f4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FINE) {
+        if (jb >= 1) {
+          // ---- K-major chunk: the epilogue of chunk jb - 1 (both tiles' accumulators are still in the other set) as NM single-instruction
+          // steps, two behind every MFMA from slot NC3 on (the copies take the first NC3 slots: their stores / the next wait see the same
+          // order as in the coarse form).  Per tile: combine (2 x 4), -|z| k, exp2, 1 + e, log2, max(z, 0), fma (4 each) [, sigmoid: select,
+          // rcp, mul (4 each) + the tile's two 8-byte stores], then the exact three-way split of its two value pairs, interleaved step by
+          // step (a step's input was produced >= 2 steps = one MFMA slot earlier).
+          const SxAcc(&pa)[2] = accs[(jb - 1) & 1];
+          constexpr int NSIG = STORE ? 14 : 0, NT = 32 + NSIG + 22, NM = 2 * NT;
+          float zc[4], tt[4], uu[4], lg[4], mx[4], vv[4], sgm[4];
+          unsigned hu[2], mu[2], lu[2];
+          float s0[2], s1[2], d0[2], d1[2], e0[2], e1[2];
+          const int pj = jb - 1;
+          auto micro = [&](int sidx) {
+            const int t = sidx / NT, u = sidx % NT;
+            const SxAcc& a = pa[t];
+            if (u < 4) zc[u] = __builtin_fmaf(a.c2[u], C11, a.c1[u]);
+            else if (u < 8) zc[u - 4] = __builtin_fmaf(zc[u - 4], C11, a.c0[u - 4]);
+            else if (u < 12) tt[u - 8] = -__builtin_fabsf(zc[u - 8]) * SP_T_PER_Z;
+            else if (u < 16) tt[u - 12] = __builtin_amdgcn_exp2f(tt[u - 12]);
+            else if (u < 20) uu[u - 16] = 1.0f + tt[u - 16];
+            else if (u < 24) lg[u - 20] = __builtin_amdgcn_logf(uu[u - 20]);
+            else if (u < 28) mx[u - 24] = __builtin_fmaxf(zc[u - 24], 0.0f);
+            else if (u < 32) vv[u - 28] = __builtin_fmaf(lg[u - 28], SP_LN2_OVER_100, mx[u - 28]);
+            else if (u < 32 + NSIG) {
+              if constexpr (STORE) {
+                const int w_ = u - 32;
+                if (w_ < 4) sgm[w_] = zc[w_] > 0.0f ? 1.0f : tt[w_];
+                else if (w_ < 8) uu[w_ - 4] = __builtin_amdgcn_rcpf(uu[w_ - 4]);
+                else if (w_ < 12) sgm[w_ - 8] = sgm[w_ - 8] * uu[w_ - 8];
+                else {
+                  const int q = w_ - 12;
+                  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                  const unsigned voff = lv;                      // the chunk's copies are in front of every step: lane 16 (+ 4 KB once piece 4 has gone)
+                  int sbase = sig_wave + lrt * (16 * 1024) - ep_voff_adj;
+                  asm volatile("" : "+s"(sbase));
+                  __builtin_amdgcn_raw_buffer_store_b64(u2v{__builtin_bit_cast(unsigned, sgm[2 * q]), __builtin_bit_cast(unsigned, sgm[2 * q + 1])}, sig_rsrc,
+                                                        (int)voff, sbase + (t * 4 * 8 * 16 + pj) * 1024 + q * 8, 0);
+                }
+              }
+            } else {
+              const int v_ = u - 32 - NSIG, q = v_ & 1, st = v_ >> 1;
+              const float v0 = vv[2 * q], v1 = vv[2 * q + 1];
+              if (st == 0) hu[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+              else if (st == 1) s0[q] = v0 * 2048.0f;
+              else if (st == 2) s1[q] = v1 * 2048.0f;
+              else if (st == 3) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d0[q]) : "v"(hu[q]), "s"(negk), "v"(s0[q]));
+              else if (st == 4) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1[q]) : "v"(hu[q]), "s"(negk), "v"(s1[q]));
+              else if (st == 5) mu[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d0[q], d1[q]));
+              else if (st == 6) e0[q] = d0[q] * 2048.0f;
+              else if (st == 7) e1[q] = d1[q] * 2048.0f;
+              else if (st == 8) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu[q]) : "v"(mu[q]), "s"(negk), "v"(e0[q]));
+              else if (st == 9) asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu[q]) : "v"(mu[q]), "s"(negk), "v"(e1[q]));
+              else {
+                sat = sat_acc_pos(sat, hu[q]);
+                const int kq = (pj & 1) * 2 + q;
+                Q.h[t][pj >> 1][kq] = hu[q];
+                Q.m[t][pj >> 1][kq] = mu[q];
+                Q.l[t][pj >> 1][kq] = lu[q];
+              }
+            }
+          };
+          ep_voff_adj = NC3 > 4 ? 4096 : 0;
+          auto filler_km = [&](int slot) {
+            if (slot == 12 * WK * (NPART - 1)) nbias = bias_of(cb + jb + 1);      // before the last part's fragment requests (see the coarse form)
+            if (slot < NC3) {
+#ifndef SXT_NODMA
+              xt_copy_piece_seq(slot, src3, dst3, lv);
+#endif
+              return;
+            }
+            const int m0 = 2 * (slot - NC3);
+            if (m0 < NM) micro(m0);
+            if (m0 + 1 < NM) micro(m0 + 1);
+          };
+          auto refill_km = [&](int piece, int part, int k) {
+            int slot, kb;
+            bool ok = true;
+            if (part + 1 < NPART) {
+              slot = jb & 3, kb = (part + 1) * WK + k;
+            } else {
+              slot = (jb + 1) & 3, kb = k, ok = k < (jb + 1 < NCH ? WK : WKN);
+            }
+#ifndef SXT_NOREAD
+            if (ok) xt_request_one(piece == 0 ? win.h[k] : (piece == 1 ? win.m[k] : win.l[k]), ring_lane + slot_b[slot], kb, piece);
+#endif
+          };
+          xt_chunk_km<K, 9>(acc, win, P, filler_km, refill_km);
+          static_assert((12 * K / 32 - 8) * 2 >= NM, "the steps fit behind the chunk's MFMAs (at most 8 copy slots in front)");
+          if (jb == NCH - 1) {      // the layer's last chunk is finished beside the next layer's first chunk: hand it over in the coarse form
+            item_z(0, acc[0]);
+            prev[1] = acc[1];
+          }
+          bias = nbias;
+          continue;
+        }
+      }
       const int ne = jb > 0 ? NE : 0, ni = ne + NC3;
       ep_voff_adj = NC3 > 4 ? 4096 : 0;
       auto filler = [&](int pos) {
@@ -358,9 +460,13 @@ __global__ __launch_bounds__(256, 1) void k_sdf_x6t(const float* __restrict__ xy
 #endif
       };
       xt_chunk<K, 9>(jb * NPART, acc, win, P, filler, refill);
-      if constexpr (OUT) prev[0] = acc[0];
-      else item_z(0, acc[0]);
-      prev[1] = acc[1];
+      if constexpr (FINE) {
+        // chunk 0 stays in set 0: the steps beside chunk 1 read it there
+      } else {
+        if constexpr (OUT) prev[0] = acc[0];
+        else item_z(0, acc[0]);
+        prev[1] = acc[1];
+      }
       bias = nbias;
     }
     {   // slot 0 = the slot of the next layer's first chunk

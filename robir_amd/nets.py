@@ -591,6 +591,11 @@ class SDFNetwork(nn.Module):
     def _cesr_points(self, pts, M, kind, n_label=1):
         """_cesr on PE10(pts) with the encoding evaluated inside the kernel (kind 0 normal_net, 2 shadow_net x labels)."""
         forward_only_guard(self)
+        from .precision import cesr_precision
+        if cesr_precision() == "f16x1":     # plain f16, ONE product per multiply-add (csrc/cesr_f16.hip): the labelled throughput mode, NARROWER than fp32
+            blob = self._packed.get("w512_f16", self, lambda sd: packing.pack_softplus512_f16(
+                {"net." + k: v for k, v in sd.items()}, "net.", self.d_in, _dev(self)))
+            return ops.cesr_net_f16_points(pts, M, kind, blob, n_label)
         if mlp_precision() == "f16x3":
             return ops.cesr_net_points(pts, M, kind, self.packed_w512_h3(), n_label, packing.H3_SCALE_LOG2)
         if mlp_precision() == "f16x6":      # exact three-piece operands (csrc/cesr_x6.hip)

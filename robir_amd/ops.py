@@ -1082,6 +1082,19 @@ def cesr_net_x6_points(x, M, kind, blob, n_label=1):
     return Y
 
 
+CESR_F16_TILES = int(os.environ.get("ROBIR_CESR_F16_TILES", "3"))        # 16-row tiles per wave of the f16 CESR kernel (what the library is built with: csrc/cesr_f16.hip FX_TILES)
+
+
+def cesr_net_f16_points(x, M, kind, blob, n_label=1):
+    """The CESR nets in PLAIN f16 (csrc/cesr_f16.hip; blob = packing.pack_softplus512_f16): the f16 throughput mode -- NARROWER than fp32."""
+    x = _f32(x)
+    Y = torch.empty(M, 3 if kind == 0 else 2, dtype=torch.float32, device=x.device)
+    if M > 0:
+        call("rb_cesr_net_f16_points", ptr(x), c_long(M), c_int(kind), c_int(n_label), ptr(blob), ptr(Y), c_int(CESR_F16_TILES), c_int(0),
+             stream_ptr())
+    return Y
+
+
 def material_decode(brdf, brdf_r):
     brdf, brdf_r = _f32(brdf), _f32(brdf_r)
     n, dev = brdf.shape[0], brdf.device

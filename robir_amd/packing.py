@@ -439,6 +439,25 @@ def pack_softplus512_x6(sd, prefix, k_in, device):
     return torch.cat([blob, torch.zeros(2048, device=device)])
 
 
+def pack_softplus512_f16(sd, prefix, k_in, device):
+    """The CESR nets for the f16 THROUGHPUT mode (rb_cesr_net_f16_points, csrc/cesr_f16.hip): the h pieces (the weights as halves) cut out
+    of the exact-operand blob, so that both kernels multiply the same halves -- [16 biases per chunk, all chunks of the stream] then the
+    chunks' fragments ([k-block][lane 64] x 16 B), contiguous.  Chunk K per layer: K0P, 512 x3, 576 (skip), 512 x4."""
+    x6 = pack_softplus512_x6(sd, prefix, k_in, device).view(-1)
+    k0p = _pad16(k_in)
+    n3p = _pad16(512 - k_in)
+    ks = [k0p, 512, 512, 512, 576, 512, 512, 512, 512]
+    nch = [32, 32, 32, n3p // 16, 32, 32, 32, 32, 1]
+    bias, frags, off = [], [], 0
+    for K, n in zip(ks, nch):
+        cf = 4 * (4 + 6 * K)                          # floats of a packed exact-operand chunk: 16 biases + K / 32 x 3 pieces x 64 lanes x 4
+        lay = x6[off:off + n * cf].view(n, cf)
+        bias.append(lay[:, :16].reshape(-1))
+        frags.append(lay[:, 16:].reshape(n, K // 32, 3, 256)[:, :, 0].reshape(-1))
+        off += n * cf
+    return torch.cat(bias + frags + [torch.zeros(4096, device=x6.device)]).contiguous()
+
+
 def pack_softplus512_h3(sd, prefix, k_in, device):
     """pack_softplus512 in split-precision form (rb_cesr_net_h3): the skip layer padded to 544 slots."""
     sdt = {k: _t(sd, k) for k in sd if k.startswith(prefix)}

@@ -12,7 +12,8 @@
   ROBIR_PRECISION=f16               the labelled THROUGHPUT policy `BASELINE.json configs[4]` names ("fp16 MLP weights on MFMA"):
                                     the light-visibility MLP in PLAIN f16 -- one f16 MFMA product per multiply-add, f16 weights
                                     (round-to-nearest) and f16 activations (truncated between the layers), fp32 accumulation
-                                    (csrc/vis_diffuse_f16p.hip, vis_diffuse_f16t.hip) -- and, since round 5, every other net in SPLIT
+                                    (csrc/vis_diffuse_f16p.hip, vis_diffuse_f16t.hip) -- the two CESR nets likewise since round 6
+                                    (csrc/cesr_f16.hip: 52 % of config 5) -- and, since round 5, every other net in SPLIT
                                     precision (f16 hi/lo weight and activation pairs, three products: the parity-tested family of
                                     `split`, legacy library) instead of the exact-operand kernels: no one-product kernels exist for
                                     those nets, and a throughput policy that left them at six products gave the CESR stage 18 %.
@@ -42,6 +43,18 @@ def mlp_precision():
     p = os.environ.get("ROBIR_MLP_PRECISION") or POLICIES[policy()][1]
     if p not in ("f16x3", "fp32", "f16x6"):
         raise ValueError("ROBIR_MLP_PRECISION must be f16x6, fp32 or f16x3")
+    return p
+
+
+def cesr_precision():
+    """Arithmetic of the two CESR nets (shadow_net, normal_net: training/train_cesr.py:106-110): 'f16x1' -- plain f16, ONE MFMA product per
+    multiply-add (csrc/cesr_f16.hip, round 6; NARROWER than fp32) -- under ROBIR_PRECISION=f16, the policy `BASELINE.json configs[4]` names
+    ("CESR stage full pipeline, fp16 MLP weights on MFMA"); else whatever mlp_precision() says.  ROBIR_CESR_PRECISION overrides (A/B runs)."""
+    p = os.environ.get("ROBIR_CESR_PRECISION")
+    if p is None:
+        p = "f16x1" if (policy() == "f16" and not os.environ.get("ROBIR_MLP_PRECISION")) else mlp_precision()
+    if p not in ("f16x1", "f16x3", "fp32", "f16x6"):
+        raise ValueError("ROBIR_CESR_PRECISION must be f16x1, f16x6, fp32 or f16x3")
     return p
 
 

@@ -75,3 +75,55 @@ def test_forward_cesr_vs_oracle_and_golden(dev, cesr_nets, oracle_sd, oracle_oct
     assert rel_err(out["gradient_error"].cpu(), ref["gradient_error"]) <= 1e-3
     for k in ("sg_rgb", "vis_shadow", "normal_map"):                       # reference's own output (independent octree)
         bounded("cesr_vs_reference_golden/" + k, out[k].cpu(), g["out_" + k], 2e-3, 0.003)
+
+
+def _f64_softplus_net(sd, x, skip_scale=True):
+    """float64 evaluation of SDFNetwork(d_in, d_out, 512, 8, skip_in=[4], multires=0) (model/neus_model.py:385-438) from a state dict."""
+    def lin(l, v):
+        g, vv, b = (torch.from_numpy(np.asarray(sd[f"lin{l}.{k}"])).double() for k in ("weight_g", "weight_v", "bias"))
+        W = vv * (g / vv.norm(dim=1, keepdim=True))
+        return v @ W.T + b
+    inp, h = x.double(), x.double()
+    for l in range(9):
+        if l == 4:
+            h = torch.cat([h, inp], -1) / np.sqrt(2)
+        h = lin(l, h)
+        if l < 8:
+            h = torch.nn.functional.softplus(h, beta=100)
+    return h
+
+
+def test_cesr_f16_throughput_mode_error_band(dev, cesr_nets, monkeypatch):
+    """ROBIR_PRECISION=f16 for the CESR nets (csrc/cesr_f16.hip, round 6: `BASELINE.json configs[4]` -- "fp16 MLP weights on MFMA"): plain f16
+    weights and activations, ONE MFMA product per multiply-add.  NARROWER than fp32: NO parity claim -- this test measures its distance from a
+    float64 evaluation and holds it to a sanity band (median <= 3e-3, 99th percentile <= 1e-2 of the floored relative error; the exact policy
+    sits at 1e-6 on the same rows); ragged row counts agree with the full launch bit for bit; the range sentinel stays quiet."""
+    from conftest import record_metric
+    from robir_amd import ops, precision, synth
+    shadow, normal = cesr_nets
+    c = synth.synth_cesr_nets(0)
+    g = np.random.Generator(np.random.PCG64(11))
+    pts = torch.from_numpy((g.standard_normal((203, 3)) * 0.25).astype(np.float32)).to(dev)
+    Xp = ops.feat_pe10(pts)
+    dense = torch.cat([Xp[:, None, :63].expand(-1, 128, -1), torch.eye(128, device=dev)[None].expand(203, -1, -1)], -1).reshape(-1, 191)
+    ref_s = _f64_softplus_net(c["shadow_net"], dense.cpu())
+    ref_n = _f64_softplus_net(c["normal_net"], Xp[:, :63].cpu())
+    exact_s = shadow.eval_point_labels(pts, 128).cpu()
+    monkeypatch.setenv("ROBIR_CESR_PRECISION", "f16x1")
+    assert precision.cesr_precision() == "f16x1"
+    f16_s = shadow.eval_point_labels(pts, 128).cpu()
+    f16_n = normal._cesr_points(pts, pts.shape[0], 0).cpu()
+    ops.range_check(sync=True)
+    for name, got, ref in (("shadow_net", f16_s, ref_s), ("normal_net", f16_n, ref_n)):
+        e = ((got.double() - ref).abs() / (ref.abs() + ref.abs().mean())).flatten()
+        p50, p99, mx = float(e.median()), float(e.kthvalue(max(1, int(0.99 * e.numel()))).values), float(e.max())
+        record_metric("cesr_f16_mode/" + name, p50=p50, p99=p99, max=mx)
+        print(f"f16 CESR {name}: vs float64 p50 {p50:.2e} p99 {p99:.2e} max {mx:.2e}")
+        assert bool(torch.isfinite(got).all()) and p50 <= 3e-3 and p99 <= 1e-2 and mx <= 5e-2, (name, p50, p99, mx)
+        assert p50 >= 1e-5, "this IS the narrower mode (the exact policy's kernels must not have run)"
+    e_exact = float(((exact_s.double() - ref_s).abs() / (ref_s.abs() + ref_s.abs().mean())).max())
+    assert e_exact <= 1e-5, e_exact
+    # ragged launches: the first rows of a longer launch, bit for bit (rounds of 64 x tiles rows, rows beyond M masked)
+    for m in (1, 129, 128 * 5 + 77):
+        part = shadow._cesr_points(pts[: (m + 127) // 128], m, 2, 128).cpu()
+        assert torch.equal(part, f16_s[:m]), m

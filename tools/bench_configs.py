@@ -54,6 +54,12 @@ class OpTimer:
     def roofline(self, kernel, precision, x6=False):
         ms = sum(s.elapsed_time(e) for s, e in self.pairs)
         split = precision == "f16x3"
+        if precision == "f16x1":      # plain f16: ONE MFMA product per multiply-add (csrc/cesr_f16.hip) -- NARROWER than fp32
+            ach = self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": PEAK_F16_MFMA, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA,
+                    "traffic": None, "calls": len(self.pairs), "op_ms_total": ms,
+                    "peak_note": "dense f16 MFMA 2500 TFLOP/s, one product per multiply-add (plain f16 operands: NARROWER than fp32, a labelled throughput mode)",
+                    "flops_note": "algorithmic MACs of SURVEY.md 8d x evaluations executed"}
         if x6 and not split:      # the op runs on exact three-piece operands: six f16 MFMA products per multiply-add
             ach = self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_F16_MFMA / 6.0
@@ -71,6 +77,11 @@ class OpTimer:
 
 
 SDF_TIMER, SHADOW_TIMER = OpTimer(), OpTimer()
+
+
+def _cesr_precision():
+    from robir_amd.precision import cesr_precision
+    return cesr_precision()
 _installed = False
 
 
@@ -202,7 +213,7 @@ def config5(model, reps=1, first=875, nch=125, trace=True):
             "deferred_chunks": dc,
             "value": nch * 1024 / t, "unit": "rays/s", "ms": t * 1e3, "chunks": nch, "hit_rays": state["hits"],
             "hit_rays_per_s": state["hits"] / t,
-            "roofline": SHADOW_TIMER.roofline("shadow_net (512 x 8 softplus net over 128 one-hot labels)", nets.mlp_precision(), nets.mlp_precision() == "f16x6")}
+            "roofline": SHADOW_TIMER.roofline("shadow_net (512 x 8 softplus net over 128 one-hot labels)", _cesr_precision(), _cesr_precision() == "f16x6")}
 
 
 CONFIGS = {1: config1, 2: config2, 3: config3, 5: config5}
