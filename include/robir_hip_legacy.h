@@ -1,6 +1,6 @@
 /* include/robir_hip_legacy.h -- the RETIRED entry points of librobir_hip (round 5).
  *
- * None of these is in the default library `robir_amd/librobir_hip.so` (ABI version 7, include/robir_hip.h) and no default precision
+ * None of these is in the default library `robir_amd/librobir_hip.so` (ABI version 8, include/robir_hip.h) and no default precision
  * policy calls them.  `make -C robir_amd/csrc legacy` builds `robir_amd/librobir_hip_legacy.so`, a SUPERSET of the default library compiled
  * with -DRB_LEGACY, which exports them next to everything robir_hip.h declares; robir_amd/_lib.py loads it on demand
  * (`ROBIR_PRECISION=split`, the bit-identity tests that compare kernel generations, `ROBIR_SDF_FUSED_PE=0`).  What lives here:

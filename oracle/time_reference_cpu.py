@@ -36,7 +36,11 @@ def main():
     from robir_amd import synth
     cores = os.cpu_count() or 1
     sd_np = synth.synth_state_dict(0, variance=0.3)
-    out = {"host": {"cpu": platform.processor() or open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t"),
+    try:
+        cpu = open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t")
+    except (OSError, IndexError):
+        cpu = platform.processor()
+    out = {"host": {"cpu": cpu,
                     "cores": cores, "torch": torch.__version__},
            "what": "the reference's own IDRNetwork.forward('Material') + PBRTrainRunner.get_sg_render through oracle/ref_shim.py, synthetic "
                    "weights (robir_amd.synth seed 0), 1024-px chunks, torch's own random draws; median of the timed runs after one warm-up",

@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256, 1) void k_cesr_f16(const float* __restrict__ X
   auto pack2 = [&](float v0, float v1) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1)); };
   // input value k of tile t's row of this lane (k = 16 blk + 4 g + r): the encoder's LDS row, then the one-hot block from column 63 on
   auto x0_block = [&](int t, int blk, float scale, float(&v)[4]) {
-    const bool ok = rrow[t] < M;
     const float* frow = pe_scratch + (wave * T + t) * 1024 + (lane & 15) * 64;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -101,16 +100,18 @@ __global__ __launch_bounds__(256, 1) void k_cesr_f16(const float* __restrict__ X
         if (k == 63) e = 0.f;
         if (k >= 63 && k - 63 == label[t]) e = 1.f;
       }
-      v[r] = ok ? e * scale : 0.f;
+      v[r] = e * scale;
     }
   };
   auto load_layer0 = [&]() {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+      // rows beyond M compute on the LAST valid row's inputs (no select on the data path; only the store below is guarded)
+      const long rin = rrow[t] < M ? rrow[t] : M - 1;
       float enc[16];
-      load_features_pe10x(X, nullptr, rrow[t], M, lane, pe_scratch + (wave * T + t) * 1024, enc, ONEHOT ? (long)n_label : 1L);
+      load_features_pe10x(X, nullptr, rin, M, lane, pe_scratch + (wave * T + t) * 1024, enc, ONEHOT ? (long)n_label : 1L);
       (void)enc;
-      label[t] = (ONEHOT && rrow[t] < M) ? (int)(rrow[t] % n_label) : -1;
+      label[t] = ONEHOT ? (int)(rin % n_label) : -1;
 #pragma unroll
       for (int blk = 0; blk < K0P / 16; ++blk) {
         float v[4];
@@ -221,13 +222,15 @@ __global__ __launch_bounds__(256, 1) void k_cesr_f16(const float* __restrict__ X
         }
       }
     };
+    // outputs: lanes g == 0 hold neurons 0..3 of their row (rows beyond M computed on the last valid row's inputs: not stored)
     auto output_chunk = [&](const f4(&pa)[T]) {
 #pragma unroll
       for (int t = 0; t < T; ++t)
         if (g == 0 && rrow[t] < M) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < n_out) Y[rrow[t] * n_out + r] = pa[t][r];
+          float* yp = Y + rrow[t] * n_out;
+          yp[0] = pa[t][0];
+          yp[1] = pa[t][1];
+          if (n_out > 2) yp[2] = pa[t][2];
         }
     };
     f4 bias = bias_of(cb);

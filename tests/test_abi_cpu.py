@@ -21,8 +21,8 @@ def _exported(path):
 
 
 def test_library_exports_header_symbols():
-    """The default library exports exactly what include/robir_hip.h declares (ABI version 8: 88 entry points -- the retired kernel
-    generations left it in round 5, the seven helper kernels of csrc/surface.hip joined in round 6), the legacy library -- where it has
+    """The default library exports exactly what include/robir_hip.h declares (ABI version 8: 89 entry points -- the retired kernel
+    generations left it in round 5, the seven helper kernels of csrc/surface.hip and rb_cesr_net_f16_points joined in round 6), the legacy library -- where it has
     been built: ROBIR_BUILD_LEGACY=1, optional since round 6 -- exactly that plus include/robir_hip_legacy.h."""
     from robir_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
