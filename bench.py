@@ -539,7 +539,7 @@ def main():
         bytes_launch = 32.0 * fetches + pairs * (2 * 19.0 + 33.0)
         # Honest bound (VERDICT r5 task 7): the records are dependent 32-byte reads of a 29 MB table that sits in the L2 (4 MB per XCD) and
         # the 256 MB Infinity Cache, NOT in HBM -- so `achieved` / `peak` price the gathered bytes against the aggregate L2 bandwidth
-        # (MI355X_MICROARCH.md: 34.5 TB/s), and the kernel is really latency x occupancy bound: `dependent_read_ns` is what one
+        # (MI355X_MICROARCH.md: 34.5 TB/s), and the kernel is really latency x occupancy bound: `lockstep_iteration_ms` is what one
         # lock-step iteration costs per ray in flight.  The HBM reading of the same bytes is kept as a labelled side figure.
         gbs = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         octree_line = {"bound": "hbm", "bound_note": "nominally the metric's HBM roofline; the table is L2 / Infinity-Cache resident, so the figures below are "
@@ -552,9 +552,9 @@ def main():
                        "launches": k_n, "avg_launch_ms": k_ms, "pairs_per_launch": pairs,
                        "octree_records_read_per_ray": fetches / max(pairs, 1), "iterations_per_ray": ray_steps / max(pairs, 1),
                        "gathered_bytes_per_ray": 32.0 * fetches / max(pairs, 1),
-                       "dependent_read_ns": k_ms * 1e6 / max(ray_steps / max(pairs, 1), 1e-9) if k_ms > 0 else None,
-                       "dependent_read_note": "launch time / lock-step iterations per ray: the wall time of ONE dependent round of record reads for "
-                                              "all rays in flight (latency x occupancy is the real bound)"}
+                       "lockstep_iteration_ms": k_ms / max(ray_steps / max(pairs, 1), 1e-9) if k_ms > 0 else None,
+                       "lockstep_iteration_note": "launch time / lock-step iterations per ray: the wall time of ONE dependent round of record reads "
+                                                  "for all rays in flight (latency x occupancy is the real bound)"}
     line = None
     if rank == 0:
         roofline = vis_roofline(vis_mode, k_ms, k_n, evals)
