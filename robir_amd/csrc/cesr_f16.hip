@@ -18,6 +18,10 @@
 #include "x6t_engine.h"
 #include <type_traits>
 
+#ifndef FX_CG
+#define FX_CG 1             // MFMAs between two LDS-DMA copies of a wave within a chunk (4: measured no gain, 3.47 / 3.40 -> 3.59 / 3.42 ms: profiles/r06_dma_placement.md)
+#endif
+
 namespace rb {
 
 constexpr int FX_SLOT_B = 18 * 1024;      // K = 576: eighteen 1 KB fragments
@@ -280,12 +284,18 @@ __global__ __launch_bounds__(256, 1) void k_cesr_f16(const float* __restrict__ X
             if (j2 < NCH) win[(sl - 1) % D] = frag_of(ring_lane + slot_b[j2 & 3], k2);
           }
           if (s == NSLOT - T) nbias = bias_of(cb + jb + 1);
-          if (s < NC3) {
+          // copy i of this wave goes behind MFMA FX_CG i
+          // (a short chunk -- layer 0's K = 64 / 192 -- packs them closer: all of them must fit its NSLOT positions)
+          const int cg_fit = NC3 > 1 ? (NSLOT - 1) / (NC3 - 1) : 1;
+          const int cg = cg_fit < 1 ? 1 : (cg_fit < FX_CG ? cg_fit : FX_CG);
+          const bool copy_here = s % cg == 0 && s / cg < NC3;
+          const int copies_before = (s + cg - 1) / cg < NC3 ? (s + cg - 1) / cg : NC3;
+          if (copy_here) {
 #ifndef FX_ABL_NODMA                     // timing ablation (wrong results): no LDS-DMA copies after the prologue's
-            xt_copy_piece_seq(s, src3, dst3, lv);
+            xt_copy_piece_seq(s / cg, src3, dst3, lv);
 #endif
           } else if (nep > 0) {
-            const int m0 = PER * (s - NC3);
+            const int m0 = PER * (s - copies_before);
 #pragma unroll
             for (int i = 0; i < PER; ++i)
               if (m0 + i < nep) micro(m0 + i, jb - 1, accs[(jb - 1) & 1]);

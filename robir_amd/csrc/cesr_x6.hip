@@ -9,7 +9,12 @@
 #include "common.h"
 #include "mlp_engine.h"
 #include "x6_ring.h"
+#include "x6t_engine.h"
 #include <type_traits>
+
+#ifndef QX_SPREAD
+#define QX_SPREAD 1         // the LDS-DMA copies of a unit one at a time, three MFMAs apart (0: blocks of 1 / 4 / 2 instructions; profiles/r06_dma_placement.md: -2.4 %)
+#endif
 
 namespace rb {
 
@@ -234,6 +239,28 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       const f4* src3 = u + 3 < NU ? wl + in_layer : wnext[u + 3 - NU < 3 ? u + 3 - NU : 0];
       const int sl3 = (u + 3) & 3;
       const unsigned dst3 = ring_b + slot_b[sl3], bdst3 = bias_b + bslot_b[sl3];
+#if QX_SPREAD
+      // The copies of unit u+3 ONE AT A TIME behind every third MFMA of the unit's second half instead of blocks of 1 / 4 / 2
+      // (tools/ubench/dma_stagger.hip: back-to-back copies cost the issuing wave ~70 cycles each, copies four MFMAs apart ~26): copy 0 = the
+      // bias head, copy c = piece c - 1 of this wave's span (M0 carried from piece to piece as in x6t_engine.h: nothing else writes it).
+      const int ncp3 = sx_np(K3), ns3 = sx_ns(K3), nsw3 = sx_nsw(K3);
+      const int first3 = wave * nsw3 < ns3 - nsw3 ? wave * nsw3 : ns3 - nsw3;
+      const f4* span3 = src3 + 4 + first3 * 64;
+      const unsigned dspan3 = dst3 + (unsigned)first3 * 1024u;
+      unsigned lv3 = lane16;
+      auto spread_site = [&](int site) {
+        constexpr int NSITE = 2 * (KB - HB);
+#ifdef QX_ABL_NODMA
+        return;
+#endif
+#pragma unroll
+        for (int cidx = 0; cidx < 8; ++cidx)
+          if (cidx < ncp3 && (cidx * NSITE) / ncp3 == site) {
+            if (cidx == 0) sx_dma4(src3, lane4, bdst3);
+            else xt_copy_piece_seq(cidx - 1, span3, dspan3, lv3, true);
+          }
+      };
+#endif
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         const int st = u * KB + kb;
@@ -267,6 +294,12 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           QX_MFMA(acc.c2, wfl[st % NB], xh[xk]);
           QX_MFMA(acc.c2, wfm[st % NB], xm[xk]);
           QX_MFMA(acc.c2, wfh[st % NB], xl[xk]);
+#if QX_SPREAD
+          if (kb >= HB) {
+            spread_site(2 * (kb - HB));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
           QX_MFMA(acc.c1, wfm[st % NB], xh[xk]);
           QX_MFMA(acc.c1, wfh[st % NB], xm[xk]);
           QX_MFMA(acc.c0, wfh[st % NB], xh[xk]);
@@ -278,6 +311,9 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           if (kb == (KB >= 6 ? 3 : 1)) epilogue(accs[(c - 1) & 1], c - 1, 1);
         }
 #endif
+#if QX_SPREAD
+        if (kb >= HB) spread_site(2 * (kb - HB) + 1);
+#else
         if (kb >= HB) {
 #pragma unroll
           for (int un = 0; un < 3; ++un)
@@ -291,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
               else qx_copy<288>(un, src3, lane4, lane16, bdst3, dst3, wave);
             }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
