@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       const int L3 = u + 3 < NU ? LI : Net::layer_of(UB + u + 3);
       const int K3 = Net::kunit(L3);
       const int nu3 = sx_units(K3);
+      (void)nu3;
       const long in_layer = (long)((u + 3) / HV) * Net::chunk_f4s(LI) + (long)((u + 3) % HV) * (KU / 32) * 192;
       const f4* src3 = u + 3 < NU ? wl + in_layer : wnext[u + 3 - NU < 3 ? u + 3 - NU : 0];
       const int sl3 = (u + 3) & 3;
