@@ -378,16 +378,16 @@ extern "C" int rb_cesr_net_f16_points(const float* x, long M, int kind, int n_la
                                       rb_stream_t stream) {
   if (M <= 0) return 0;
   RB_REQUIRE(x && Wp && Y, "null pointer");
+#ifndef FX_TILES
+#define FX_TILES 3          // tiles per wave the library is built with (2 or 3: one instance per net keeps the build short)
+#endif
+  RB_REQUIRE(tiles == FX_TILES, "this build carries one tile count (FX_TILES)");
   const int pg = persistent_grid((M + 64 * tiles - 1) / (64 * tiles), n_workgroups);
   if (pg <= 0) return rb::fail(__func__, "device query failed");
   const unsigned grid = (unsigned)pg;
   unsigned* rw = range_flags() ? range_flags() + RB_RANGE_SOFTPLUS512 : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const f4* W = (const f4*)Wp;
-#ifndef FX_TILES
-#define FX_TILES 3          // tiles per wave the library is built with (2 or 3: one instance per net keeps the build short)
-#endif
-  RB_REQUIRE(tiles == FX_TILES, "this build carries one tile count (FX_TILES)");
   switch (kind) {
     case 0: hipLaunchKernelGGL((k_cesr_f16<64, 464, false, FX_TILES>), dim3(grid), dim3(256), 0, s, x, M, 1, W, 3, Y, rw); break;
     case 2:

@@ -374,3 +374,68 @@ def test_round4_entry_points_on_empty_tiny_and_ragged_inputs(dev, synth_weights)
         assert float((res["f16x1"][0] - res["fp32"][0]).abs().max()) <= 5e-3                         # the narrower mode: sane, not equal
     finally:
         sg_render.VIS_PRECISION, ops.DVIS_X6_FORM = old, old_form
+
+
+def test_round6_entry_points_on_empty_tiny_and_bad_inputs(dev):
+    """The entry points added in round 6 (csrc/surface.hip, csrc/cesr_f16.hip) through the C ABI at the edges: zero rows (status 0, no
+    launch, null pointers allowed), one row against the closed forms, bad arguments (an error code and a message, no launch)."""
+    import ctypes
+    import math
+    from robir_amd import _lib, ops, packing, synth
+    L = _lib.lib()
+    c_long, c_int, c_float, ptr, sp = ctypes.c_long, ctypes.c_int, ctypes.c_float, _lib.ptr, _lib.stream_ptr
+    z1 = torch.zeros(8, device=dev)
+    # zero rows: nothing to do, not an error -- whatever the pointers
+    assert L.rb_pe_encode(None, c_long(0), c_int(3), None, c_int(4), c_int(1), None, sp()) == 0
+    assert L.rb_expected_sin(None, None, c_long(0), None, None, sp()) == 0
+    assert L.rb_tonemap_curve(None, c_long(0), c_int(1), None, c_int(0), c_int(2), None, sp()) == 0
+    assert L.rb_sample_pdf(None, None, c_long(0), c_int(8), None, c_long(0), c_int(4), None, None, sp()) == 0
+    assert L.rb_neus_core_aux(None, c_long(1), None, None, c_long(0), c_int(8), c_float(1.0), c_float(1.0), c_float(0.1), None, None, None, sp()) == 0
+    assert L.rb_sample_dirs(None, None, None, c_long(0), None, sp()) == 0
+    assert L.rb_intersect_sphere(None, None, c_long(0), c_float(1.0), None, sp()) == 0
+    assert L.rb_cesr_net_f16_points(None, c_long(0), c_int(0), c_int(1), None, None, c_int(3), c_int(0), sp()) == 0
+    # ... and the wrappers return empty tensors of the right shape
+    e3 = torch.zeros(0, 3, device=dev)
+    fr = torch.tensor([1.0, 2.0, 4.0], device=dev)
+    assert ops.pe_encode(e3, fr).shape == (0, 21) and ops.pe_encode(e3, fr, include_input=False).shape == (0, 18)
+    assert ops.tonemap_curve(torch.zeros(0, 3, device=dev), torch.zeros(0, 1, device=dev), 2).shape == (0, 3)
+    assert ops.sample_dirs(e3, torch.zeros(0, device=dev), torch.zeros(0, device=dev)).shape == (0, 3)
+    assert ops.intersect_sphere(e3, e3, 1.0).shape == (0, 3)
+    # null pointers / bad arguments: refused with a message
+    assert L.rb_pe_encode(None, c_long(1), c_int(3), ptr(fr), c_int(3), c_int(1), ptr(z1), sp()) != 0 and b"null" in L.rb_last_error()
+    assert L.rb_pe_encode(ptr(z1), c_long(1), c_int(0), ptr(fr), c_int(3), c_int(1), ptr(z1), sp()) != 0 and b"d >= 1" in L.rb_last_error()
+    assert L.rb_tonemap_curve(ptr(z1), c_long(3), c_int(1), None, c_int(0), c_int(9), ptr(z1), sp()) != 0 and b"curve" in L.rb_last_error()
+    assert L.rb_tonemap_curve(ptr(z1), c_long(3), c_int(1), None, c_int(0), c_int(2), ptr(z1), sp()) != 0 and b"shift" in L.rb_last_error()
+    assert L.rb_sample_pdf(ptr(z1), ptr(z1), c_long(1), c_int(1), ptr(z1), c_long(0), c_int(4), ptr(z1), ptr(z1), sp()) != 0 and b"bins" in L.rb_last_error()
+    assert L.rb_sample_pdf(ptr(z1), ptr(z1), c_long(1), c_int(4), ptr(z1), c_long(3), c_int(4), ptr(z1), ptr(z1), sp()) != 0 and b"stride" in L.rb_last_error()
+    assert L.rb_sample_dirs(ptr(z1), None, ptr(z1), c_long(1), ptr(z1), sp()) != 0 and b"null" in L.rb_last_error()
+    assert L.rb_intersect_sphere(ptr(z1), ptr(z1), c_long(1), c_float(1.0), None, sp()) != 0 and b"null" in L.rb_last_error()
+    # one row against the closed forms
+    x = torch.tensor([[0.3, -0.2, 0.5]], device=dev)
+    pe = ops.pe_encode(x, fr).cpu()[0]
+    want = [0.3, -0.2, 0.5]
+    for f in (1.0, 2.0, 4.0):
+        want += [math.sin(f * v) for v in (0.3, -0.2, 0.5)] + [math.cos(f * v) for v in (0.3, -0.2, 0.5)]
+    assert float((pe - torch.tensor(want)).abs().max()) <= 1e-6
+    o, d = torch.tensor([[0.0, 0.0, 0.0]], device=dev), torch.tensor([[0.0, 0.6, 0.8]], device=dev)
+    assert float((ops.intersect_sphere(o, d, 2.0).cpu()[0] - torch.tensor([0.0, 1.2, 1.6])).abs().max()) <= 1e-6
+    bins = torch.tensor([[0.0, 1.0, 2.0, 3.0]], device=dev)
+    w = torch.tensor([[1.0, 0.0, 1.0]], device=dev)
+    s, cdf = ops.sample_pdf(bins, w, torch.tensor([0.25, 0.75], device=dev))
+    assert s.shape == (1, 2) and cdf.shape == (1, 4) and abs(float(cdf[0, -1]) - 1.0) <= 1e-6
+    assert 0.0 <= float(s[0, 0]) <= 1.0 and 2.0 <= float(s[0, 1]) <= 3.0            # the empty middle bin is never sampled
+    # the plain-f16 CESR kernel: a tile count the build does not carry, an unknown kind, too many labels -- refused; one row runs
+    cz = synth.synth_cesr_nets(0)
+    blob = packing.pack_softplus512_f16({"net." + k: v for k, v in cz["normal_net"].items()}, "net.", 63, dev)
+    y = torch.zeros(3, device=dev)
+    for tiles in (0, 1, 7):
+        assert L.rb_cesr_net_f16_points(ptr(x), c_long(1), c_int(0), c_int(1), ptr(blob), ptr(y), c_int(tiles), c_int(0), sp()) != 0
+        assert b"tile" in L.rb_last_error()
+    assert L.rb_cesr_net_f16_points(ptr(x), c_long(1), c_int(1), c_int(1), ptr(blob), ptr(y), c_int(ops.CESR_F16_TILES), c_int(0), sp()) != 0
+    assert b"kind" in L.rb_last_error()
+    assert L.rb_cesr_net_f16_points(ptr(x), c_long(1), c_int(2), c_int(129), ptr(blob), ptr(y), c_int(ops.CESR_F16_TILES), c_int(0), sp()) != 0
+    assert b"n_label" in L.rb_last_error()
+    assert L.rb_cesr_net_f16_points(None, c_long(1), c_int(0), c_int(1), ptr(blob), ptr(y), c_int(ops.CESR_F16_TILES), c_int(0), sp()) != 0
+    one = ops.cesr_net_f16_points(x, 1, 0, blob, 1)
+    torch.cuda.synchronize()
+    assert one.shape == (1, 3) and bool(torch.isfinite(one).all())
