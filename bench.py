@@ -43,7 +43,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f3
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA (not the 2:1-sparse marketing figure)
 # HBM bytes per (point, direction) pair: (2 x FETCH_SIZE + WRITE_SIZE) / pairs at 32 chunks per launch.  DERIVED, not a counter of the
 # timed run (PMC passes cannot run inside the timed region): f16x6 from the PMC passes of this round's kernel
-# (profiles/r05_dvis_x6t_pmc.md), the split-precision kernel from profiles/r03_pmc_summary.md
+# (profiles/r06_dvis_x6t_pmc.md: FETCH_SIZE / WRITE_SIZE equal r05's to 0.1 %), the split-precision kernel from profiles/r03_pmc_summary.md
 # f16 mode, point-block form (profiles/r05_dvis_f16p_pmc.md, 64 chunks per launch): its pair values go out as 16-lane rows and its rounds
 # fetch whole table rows (L2 / MALL hits mostly): more bytes per pair, still < 0.1 TB/s
 TRAFFIC_B_PER_PAIR = {"f16x6": 33.0, "f16x1": 68.4, "default": 22.1}
@@ -464,7 +464,7 @@ def main():
                 # 1 % of the HBM roofline -- the bound is the matrix pipe
                 "traffic": TRAFFIC_B_PER_PAIR.get(vis, TRAFFIC_B_PER_PAIR["default"]) * evals / max(k_n, 1),
                 "traffic_unit": "B/launch", "traffic_source": "derived",
-                "pmc_file": TRAFFIC_PROFILE.get(vis, "profiles/r05_dvis_x6t_pmc.md"),
+                "pmc_file": TRAFFIC_PROFILE.get(vis, "profiles/r06_dvis_x6t_pmc.md"),
                 "traffic_note": "bytes per pair of a separate PMC pass of the same kernel (2 x FETCH_SIZE + WRITE_SIZE) x this launch's pairs",
                 "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                 "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
