@@ -108,6 +108,24 @@ def test_mlp_precision_switch(monkeypatch):
     import pytest
     with pytest.raises(ValueError):
         nets.mlp_precision()
+    # the whole policy table (robir_amd/precision.py): light-visibility kernel, stand-alone MLPs, the two CESR nets
+    monkeypatch.delenv("ROBIR_MLP_PRECISION")
+    monkeypatch.delenv("ROBIR_CESR_PRECISION", raising=False)
+    want = {"exact": ("f16x6", "f16x6", "f16x6"), "split": ("f16x3-auto", "f16x3", "f16x3"),
+            "f16": ("f16x1", "f16x3", "f16x1"),            # the labelled throughput policy: plain f16 where a one-product kernel exists
+            "f16-vis": ("f16x1", "f16x6", "f16x6")}        # round 4's meaning of f16: the light-visibility MLP only
+    for pol, (vis, mlp, cesr) in want.items():
+        monkeypatch.setenv("ROBIR_PRECISION", pol)
+        assert (precision.vis_precision(), precision.mlp_precision(), precision.cesr_precision()) == (vis, mlp, cesr), pol
+    monkeypatch.setenv("ROBIR_PRECISION", "f16")
+    monkeypatch.setenv("ROBIR_CESR_PRECISION", "f16x6")     # the CESR nets alone back on exact operands
+    assert precision.cesr_precision() == "f16x6" and precision.vis_precision() == "f16x1"
+    monkeypatch.delenv("ROBIR_CESR_PRECISION")
+    monkeypatch.setenv("ROBIR_MLP_PRECISION", "f16x6")      # an explicit MLP override also covers the CESR nets
+    assert precision.cesr_precision() == "f16x6"
+    monkeypatch.setenv("ROBIR_PRECISION", "fp16")
+    with pytest.raises(ValueError):
+        precision.policy()
 
 
 def test_object_surface_of_the_reference_model():

@@ -73,3 +73,51 @@ def test_default_policy_never_touches_the_legacy_library(monkeypatch):
                                            out["normals"][hit][:64].contiguous())
     assert x.shape == (64, 3) and bool(torch.isfinite(ge))
     ops.range_check(sync=True)
+
+
+def test_f16_vis_policy_runs_on_the_default_library_alone(monkeypatch):
+    """ROBIR_PRECISION=f16-vis (round 4's meaning of `f16`, kept selectable: plain f16 in the light-visibility MLP, every other net on the
+    exact-operand kernels) needs no legacy library; with ROBIR_CESR_PRECISION=f16x1 on top the CESR hook runs its one-product kernel --
+    still on the default library.  A labelled NARROWER mode: only sanity bands here (the light visibility within 2e-2 of the exact render)."""
+    from robir_amd import _lib, nets, precision, renderer, sg_render, synth
+
+    def refuse():
+        raise AssertionError("the f16-vis policy asked for the legacy library")
+
+    monkeypatch.setattr(_lib, "legacy", refuse)
+    dev = torch.device("cuda:0")
+    m = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
+    m.deferred_chunks = 0
+    uv, pose, K = synth.synth_camera(64, 64)
+    inp = {"uv": torch.from_numpy(uv).to(dev)[None, 1024:2048], "pose": torch.from_numpy(pose).to(dev)[None],
+           "intrinsics": torch.from_numpy(K).to(dev)[None], "object_mask": torch.ones(1, 1024, dtype=torch.bool, device=dev),
+           "hdr_shift": torch.full((1024, 1), 0.5, device=dev)}
+    monkeypatch.delenv("ROBIR_MLP_PRECISION", raising=False)
+    monkeypatch.delenv("ROBIR_VIS_PRECISION", raising=False)
+    monkeypatch.delenv("ROBIR_CESR_PRECISION", raising=False)
+    monkeypatch.setenv("ROBIR_PRECISION", "exact")
+    monkeypatch.setattr(sg_render, "VIS_PRECISION", "f16x6")
+    hit = m(inp, trainstage="Material", train_spec=True)["network_object_mask"]          # sizes the recorded draws
+    draws = {k: torch.from_numpy(v).to(dev) for k, v in synth.pbr_draws(0, int(hit.sum()), chunk_id=1).items()}
+    ref = m(inp, trainstage="Material", train_spec=True, draws=draws)
+    monkeypatch.setenv("ROBIR_PRECISION", "f16-vis")
+    assert (precision.vis_precision(), precision.mlp_precision(), precision.cesr_precision()) == ("f16x1", "f16x6", "f16x6")
+    monkeypatch.setattr(sg_render, "VIS_PRECISION", precision.vis_precision())
+    out = m(inp, trainstage="Material", train_spec=True, draws=draws)
+    torch.cuda.synchronize()
+    assert bool((out["network_object_mask"] == hit).all())
+    assert torch.equal(out["normal_map"], ref["normal_map"]) and torch.equal(out["diffuse_albedo"], ref["diffuse_albedo"])      # the exact-operand nets ran
+    dv = (out["vis_shadow"][hit] - ref["vis_shadow"][hit]).abs()
+    assert 0.0 < float(dv.max()) <= 2e-2, float(dv.max())                                                             # the plain-f16 visibility kernel ran
+    # the CESR nets' one-product kernel under the same policy
+    monkeypatch.setenv("ROBIR_CESR_PRECISION", "f16x1")
+    c = synth.synth_cesr_nets(0)
+    shadow, normal = nets.SDFNetwork(63 + 128, 2, 512, 8, [4], 0), nets.SDFNetwork(63, 3, 512, 8, [4], 0)
+    shadow.load_state_dict({k: torch.from_numpy(v) for k, v in c["shadow_net"].items()})
+    normal.load_state_dict({k: torch.from_numpy(v) for k, v in c["normal_net"].items()})
+    m.get_sg_render = renderer.CESRHook(m, shadow.to(dev).eval(), normal.to(dev).eval(), is_training=False, cur_iter=100000, prefit="explore")
+    try:
+        oc = m(inp, trainstage="Material", lin_diff=True, train_spec=True)
+        assert bool(torch.isfinite(oc["sg_rgb"][oc["network_object_mask"]]).all().cpu())
+    finally:
+        m.__dict__.pop("get_sg_render", None)
