@@ -12,6 +12,9 @@
 #include "x6t_engine.h"
 #include <type_traits>
 
+#ifndef QX_FINE
+#define QX_FINE 1           // a filler slot behind EVERY MFMA, the previous chunk's softplus + split as single-instruction steps (0: two clusters per chunk; -1.3 % / -2 %, bit-identical: profiles/r06_dma_placement.md)
+#endif
 #ifndef QX_SPREAD
 #define QX_SPREAD 1         // the LDS-DMA copies of a unit one at a time, three MFMAs apart (0: blocks of 1 / 4 / 2 instructions; profiles/r06_dma_placement.md: -2.4 %)
 #endif
@@ -216,6 +219,52 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
         hidden_pair(a, pj, q);
       }
     };
+#if QX_FINE
+    // The epilogue of a hidden chunk (four values per lane) as single-instruction steps in a skewed order: step 4 t + r = stage t - r of
+    // value r (stages: two combines, -|z| k, exp2, 1 + e, log2, max, fma [, / sqrt 2]) -- consecutive steps belong to different values, a
+    // step's input is four steps old, at most every other step is a quarter-rate transcendental -- then the two pairs' exact three-way
+    // splits (sx_split_pair's instructions, the pairs alternating) and the sentinel.  The same operations in the same order per value as
+    // hidden_pair(): bit-identical results.
+    constexpr int FNS = SKIPOUT ? 9 : 8, FNA = 4 * (FNS + 3), FNP = 2 * 11, FNSTEP = FNA + FNP;
+    float f_t[4], f_z[4], f_e[4], f_u[4], f_v[4];
+    unsigned f_h[2], f_m[2], f_l[2];
+    float f_s[2][2], f_d[2][2];
+    auto fine_step = [&](int sidx, int pj, const SxAcc& a) {
+      if (sidx < FNA) {
+        const int tt = sidx >> 2, r = sidx & 3, st = tt - r;
+        if (st < 0 || st >= FNS) return;
+        if (st == 0) f_t[r] = __builtin_fmaf(a.c2[r], C11, a.c1[r]);
+        else if (st == 1) f_z[r] = __builtin_fmaf(f_t[r], C11, a.c0[r]);
+        else if (st == 2) f_e[r] = -__builtin_fabsf(f_z[r]) * SP_T_PER_Z;
+        else if (st == 3) f_e[r] = __builtin_amdgcn_exp2f(f_e[r]);
+        else if (st == 4) f_u[r] = 1.0f + f_e[r];
+        else if (st == 5) f_u[r] = __builtin_amdgcn_logf(f_u[r]);
+        else if (st == 6) f_t[r] = __builtin_fmaxf(f_z[r], 0.0f);
+        else if (st == 7) f_v[r] = __builtin_fmaf(f_u[r], SP_LN2_OVER_100, f_t[r]);
+        else f_v[r] = f_v[r] * inv_sqrt2;
+      } else {
+        const int w = sidx - FNA, q = w & 1, st = w >> 1;
+        const float v0 = f_v[2 * q], v1 = f_v[2 * q + 1];
+        if (st == 0) f_h[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+        else if (st == 1) f_s[q][0] = v0 * 2048.0f;
+        else if (st == 2) f_s[q][1] = v1 * 2048.0f;
+        else if (st == 3) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(f_d[q][0]) : "v"(f_h[q]), "s"(negk), "v"(f_s[q][0]));
+        else if (st == 4) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(f_d[q][1]) : "v"(f_h[q]), "s"(negk), "v"(f_s[q][1]));
+        else if (st == 5) f_m[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f_d[q][0], f_d[q][1]));
+        else if (st == 6) f_s[q][0] = f_d[q][0] * 2048.0f;
+        else if (st == 7) f_s[q][1] = f_d[q][1] * 2048.0f;
+        else if (st == 8) asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(f_l[q]) : "v"(f_m[q]), "s"(negk), "v"(f_s[q][0]));
+        else if (st == 9) asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f_l[q]) : "v"(f_m[q]), "s"(negk), "v"(f_s[q][1]));
+        else {
+          const int o = (pj & 1) * 2 + q;
+          yh[pj >> 1][o] = f_h[q];
+          ym[pj >> 1][o] = f_m[q];
+          yl[pj >> 1][o] = f_l[q];
+          sat = sat_acc_pos(sat, f_h[q]);
+        }
+      }
+    };
+#endif
     zero_acc(accs[0], bias_of(0));
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -292,6 +341,40 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
         {
           const int xk = hvi * KB + kb;
 #define QX_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, W), __builtin_bit_cast(h8, X), ACC, 0, 0, 0)
+#if QX_FINE
+          // a filler slot behind EVERY MFMA: the steps of chunk c-1's epilogue (hidden layers), the copies at their two sites per k-block
+          constexpr int NSC = HV * KB * 6;                                        // MFMAs (= slots) per chunk
+          constexpr int FPER_ = (FNSTEP + NSC - 1) / NSC, FPER = FPER_ > 4 ? 4 : FPER_;
+          const bool fine_here = !OUT && c > 0;
+#define QX_SLOT(J)                                                                                   \
+  {                                                                                                  \
+    if (fine_here) {                                                                                 \
+      const int sc_ = (hvi * KB + kb) * 6 + (J);                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < FPER; ++i_)                                            \
+        if (FPER * sc_ + i_ < FNSTEP) fine_step(FPER * sc_ + i_, c - 1, accs[(c - 1) & 1]);          \
+    }                                                                                                \
+    if (QX_SPREAD && kb >= HB && ((J) == 2 || (J) == 5)) spread_site(2 * (kb - HB) + ((J) == 5));   \
+    if ((J) < 5) __builtin_amdgcn_sched_barrier(0);                                                  \
+  }
+          QX_MFMA(acc.c2, wfl[st % NB], xh[xk]);
+          QX_SLOT(0)
+          QX_MFMA(acc.c2, wfm[st % NB], xm[xk]);
+          QX_SLOT(1)
+          QX_MFMA(acc.c2, wfh[st % NB], xl[xk]);
+          QX_SLOT(2)
+          QX_MFMA(acc.c1, wfm[st % NB], xh[xk]);
+          QX_SLOT(3)
+          QX_MFMA(acc.c1, wfh[st % NB], xm[xk]);
+          QX_SLOT(4)
+          QX_MFMA(acc.c0, wfh[st % NB], xh[xk]);
+          QX_SLOT(5)
+#undef QX_SLOT
+          if (fine_here && hvi == HV - 1 && kb == KB - 1) {      // what a short chunk (layer 0) cannot carry behind its MFMAs
+#pragma unroll
+            for (int m_ = 0; m_ < FNSTEP; ++m_)
+              if (m_ >= FPER * NSC) fine_step(m_, c - 1, accs[(c - 1) & 1]);
+          }
+#else
           QX_MFMA(acc.c2, wfl[st % NB], xh[xk]);
           QX_MFMA(acc.c2, wfm[st % NB], xm[xk]);
           QX_MFMA(acc.c2, wfh[st % NB], xl[xk]);
@@ -304,16 +387,17 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           QX_MFMA(acc.c1, wfm[st % NB], xh[xk]);
           QX_MFMA(acc.c1, wfh[st % NB], xm[xk]);
           QX_MFMA(acc.c0, wfh[st % NB], xh[xk]);
+#endif
 #undef QX_MFMA
         }
 #ifndef QX_ABL_NOEPI                     // timing ablation (wrong results): no softplus / split between the MFMAs
-        if (c > 0 && hvi == 0) {              // softplus + three-way split (or the store) of chunk c-1
+        if (c > 0 && hvi == 0 && (OUT || !QX_FINE)) {              // softplus + three-way split (or the store) of chunk c-1
           if (kb == 0) epilogue(accs[(c - 1) & 1], c - 1, 0);
           if (kb == (KB >= 6 ? 3 : 1)) epilogue(accs[(c - 1) & 1], c - 1, 1);
         }
 #endif
 #if QX_SPREAD
-        if (kb >= HB) spread_site(2 * (kb - HB) + 1);
+        if (kb >= HB && !QX_FINE) spread_site(2 * (kb - HB) + 1);
 #else
         if (kb >= HB) {
 #pragma unroll

@@ -19,6 +19,7 @@ def test_default_policy_never_touches_the_legacy_library(monkeypatch):
         raise AssertionError("the default policy asked for the legacy library")
 
     monkeypatch.setattr(_lib, "legacy", refuse)
+    monkeypatch.setattr(_lib, "legacy_loaded", lambda: False)      # (an earlier test of this process may have loaded it: range_check would then read its sentinels too)
     monkeypatch.setattr(sg_render, "VIS_PRECISION", "f16x6")
     dev = torch.device("cuda:0")
     m = renderer.build_synthetic_model(dev, seed=0, variance=0.3)            # octree build included
@@ -85,6 +86,7 @@ def test_f16_vis_policy_runs_on_the_default_library_alone(monkeypatch):
         raise AssertionError("the f16-vis policy asked for the legacy library")
 
     monkeypatch.setattr(_lib, "legacy", refuse)
+    monkeypatch.setattr(_lib, "legacy_loaded", lambda: False)      # (an earlier test of this process may have loaded it: range_check would then read its sentinels too)
     dev = torch.device("cuda:0")
     m = renderer.build_synthetic_model(dev, seed=0, variance=0.3)
     m.deferred_chunks = 0
