@@ -61,7 +61,8 @@ _LIVE = weakref.WeakSet()            # queues with recorded chunks that have not
 # function is wrapped to bump a counter; a pass remembers the count at its first chunk and a different count at the next forward() is
 # treated like a changed state (the pending chunks run from their own state, the new chunk runs at once: immediate-execution results).
 # Not visible from here: methods called on a Generator OBJECT (gen.manual_seed / gen.set_state on torch.cuda.default_generators[i] or
-# torch.default_generator with an unchanged resulting state) -- C methods of an extension type; such loops set deferred_chunks = 0.
+# torch.default_generator with an unchanged resulting state) -- C methods of an extension type -- and a seeding function a caller bound
+# by name (`from torch import manual_seed`) BEFORE this module was imported; such loops set deferred_chunks = 0.
 _SEED_EPOCH = [0]
 
 
