@@ -10,6 +10,10 @@
 #include "x6_ring.h"
 #include <type_traits>
 
+#ifndef VX_FP8
+#define VX_FP8 0            // 1: EXPERIMENT: h.xl and l.xh as bf8 products on v_mfma_f32_16x16x128_f8f6f4 (weights: packing.repack_vis_x6_fp8)
+#endif
+
 namespace rb {
 
 constexpr int VX_SLOT_B = 24 * 1024 + 512;
@@ -45,8 +49,31 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
   unsigned sat = 0u;
   u4 xh[8], xm[8], xl[8];              // operands of the current layer (K <= 256): three pieces, one tile
   u4 yh[8], ym[8], yl[8];              // ... of the next layer
+#if VX_FP8
+  typedef int vx_i8 __attribute__((ext_vector_type(8)));
+  vx_i8 xh8[2], xl8[2], yh8[2], yl8[2];      // bf8 (e5m2) copies of the h and l pieces, 32 K values per lane and group of 128 (xl / yl stay unused)
+  unsigned l_keep = 0u;
+#endif
   long rrow = 0;
 
+#if VX_FP8
+  // pair q (0..3) of k-block kb: the f16 h and m pieces as before; behind the second pair of a 16-value block (q odd) the top bytes of the
+  // block's four h and four l halves become dword 2 kb + q / 2 of the group's bf8 operands (truncation to e5m2: one v_perm_b32 each)
+  auto put_pair8 = [&](float v0, float v1, u4& dh, u4& dm, vx_i8 (&d8h)[2], vx_i8 (&d8l)[2], int kb, int q) {
+    unsigned h, m, l;
+    sx_split_pair(v0, v1, negk, h, m, l);
+    dh[q] = h;
+    dm[q] = m;
+    if (q & 1) {
+      const int j8 = 2 * kb + (q >> 1);
+      d8h[j8 >> 3][j8 & 7] = (int)__builtin_amdgcn_perm(h, dh[q - 1], 0x07050301u);
+      d8l[j8 >> 3][j8 & 7] = (int)__builtin_amdgcn_perm(l, l_keep, 0x07050301u);
+    } else {
+      l_keep = l;
+    }
+    sat = sat_acc(sat, h);
+  };
+#endif
   auto put_pair = [&](float v0, float v1, u4& dh, u4& dm, u4& dl, int q) {
     unsigned h, m, l;
     sx_split_pair(v0, v1, negk, h, m, l);
@@ -64,7 +91,11 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = (2 * kb + (q >> 1)) * 4 + (q & 1) * 2;
+#if VX_FP8
+        put_pair8(in0[i], in0[i + 1], xh[kb], xm[kb], xh8, xl8, kb, q);
+#else
         put_pair(in0[i], in0[i + 1], xh[kb], xm[kb], xl[kb], q);
+#endif
       }
   };
 
@@ -92,16 +123,32 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
     };
     auto combine = [&](const SxAcc& a, int r) { return __builtin_fmaf(__builtin_fmaf(a.c2[r], C11, a.c1[r]), C11, a.c0[r]); };
     auto hidden_pair = [&](const SxAcc& a, int pj, int q) {
+#if VX_FP8
+      put_pair8(fmaxf(combine(a, 2 * q), 0.f), fmaxf(combine(a, 2 * q + 1), 0.f), yh[pj >> 1], ym[pj >> 1], yh8, yl8, pj >> 1, (pj & 1) * 2 + q);
+#else
       put_pair(fmaxf(combine(a, 2 * q), 0.f), fmaxf(combine(a, 2 * q + 1), 0.f), yh[pj >> 1], ym[pj >> 1], yl[pj >> 1], (pj & 1) * 2 + q);
+#endif
     };
     zero_acc(accs[0], bias_of(0));
+#if VX_FP8
+    vx_i8 w8h, w8l;                    // the group's bf8 weight fragments (requested at its first k-block, used behind its last)
+    // k-block kb of a chunk: group kb / 4 (12 KB = 768 lane-strided u4), its h plane at 2 (kb % 4), m behind it; h8 / l8 at 512 / 640
+    auto frag16 = [&](int c, int kb) { return frag_of(c) + (kb >> 2) * 768 + (2 * (kb & 3)) * 64; };
+    auto frag8 = [&](int c, int grp) { return frag_of(c) + grp * 768 + 512; };
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i)
       if (i < NSTEP) {
+#if VX_FP8
+        const u4* f = frag16(i / KB, i % KB);
+        wfh[i % NB] = f[0];
+        wfm[i % NB] = f[64];
+#else
         const u4* f = frag_of(i / KB) + (3 * (i % KB)) * 64;
         wfh[i % NB] = f[0];
         wfm[i % NB] = f[64];
         wfl[i % NB] = f[128];
+#endif
       }
 #pragma unroll
     for (int jb = 0; jb < NCH; ++jb) {
@@ -130,22 +177,32 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
           for (int i = BS - 1; i >= 0; --i) {
             const int s2 = st + D + i;
             if (s2 < NSTEP) {
+#if VX_FP8
+              const u4* f = frag16(s2 / KB, s2 % KB);
+              wfm[s2 % NB] = f[64];
+              wfh[s2 % NB] = f[0];
+#else
               const u4* f = frag_of(s2 / KB) + (3 * (s2 % KB)) * 64;
               wfl[s2 % NB] = f[128];
               wfm[s2 % NB] = f[64];
               wfh[s2 % NB] = f[0];
+#endif
             }
           }
         }
         if (st % BS == BS - 1 || kb == KB - 1) {
           const int k0 = (st % BS == BS - 1) ? (kb - (BS - 1) > 0 ? kb - (BS - 1) : 0) : kb - (st % BS);
 #define VX_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, W), __builtin_bit_cast(h8, X), ACC, 0, 0, 0)
+#if !VX_FP8
 #pragma unroll
           for (int k = k0; k <= kb; ++k) VX_MFMA(acc.c2, wfl[(jb * KB + k) % NB], xh[k]);
+#endif
 #pragma unroll
           for (int k = k0; k <= kb; ++k) VX_MFMA(acc.c2, wfm[(jb * KB + k) % NB], xm[k]);
+#if !VX_FP8
 #pragma unroll
           for (int k = k0; k <= kb; ++k) VX_MFMA(acc.c2, wfh[(jb * KB + k) % NB], xl[k]);
+#endif
 #pragma unroll
           for (int k = k0; k <= kb; ++k) VX_MFMA(acc.c1, wfm[(jb * KB + k) % NB], xh[k]);
 #pragma unroll
@@ -154,6 +211,18 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
           for (int k = k0; k <= kb; ++k) VX_MFMA(acc.c0, wfh[(jb * KB + k) % NB], xh[k]);
 #undef VX_MFMA
         }
+#if VX_FP8
+        if ((kb & 3) == 0) {                   // the group's two bf8 fragments: four reads, used three k-blocks later
+          const u4* f8 = frag8(jb, kb >> 2);
+          const u4 a0 = f8[0], a1 = f8[64], b0 = f8[128], b1 = f8[192];
+          w8h = vx_i8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+          w8l = vx_i8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+        }
+        if ((kb & 3) == 3) {                   // c2 += l.xh + h.xl over the group's 128 K: two MFMAs at twice the f16 rate
+          acc.c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8l, xh8[kb >> 2], acc.c2, 1, 1, 0, 0, 0, 0);
+          acc.c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8h, xl8[kb >> 2], acc.c2, 1, 1, 0, 0, 0, 0);
+        }
+#endif
         if (jb > 0 && !OUT) {                  // relu + three-way split of chunk jb-1
           if (kb == 0) hidden_pair(accs[(jb - 1) & 1], jb - 1, 0);
           if (kb == 3) hidden_pair(accs[(jb - 1) & 1], jb - 1, 1);
@@ -196,8 +265,16 @@ __global__ __launch_bounds__(256, 1) void k_vis_x6(const float* __restrict__ P, 
       for (int kb = 0; kb < 8; ++kb) {
         xh[kb] = yh[kb];
         xm[kb] = ym[kb];
+#if !VX_FP8
         xl[kb] = yl[kb];
+#endif
       }
+#if VX_FP8
+      xh8[0] = yh8[0];
+      xh8[1] = yh8[1];
+      xl8[0] = yl8[0];
+      xl8[1] = yl8[1];
+#endif
     }
   };
 

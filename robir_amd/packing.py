@@ -476,3 +476,33 @@ def pack_softplus512_h3(sd, prefix, k_in, device):
                     + [-1] * 16)
         ls.append(dict(W=W, b=b, n_pad=n_pad, k_pad=k_pad, perm=perm))
     return pack_layers_h3(ls, device)
+
+
+def repack_vis_x6_fp8(blob, device):
+    """EXPERIMENT (csrc/vis_x6.hip built with -DVX_FP8=1; not a shipped path): the blob of pack_vis_x6 with the l pieces
+    of every weight replaced by bf8 (e5m2) copies of the h and l pieces in the K = 128 order of v_mfma_f32_16x16x128_f8f6f4.  Same size:
+    per chunk [16 bias floats] + per group of 128 K: [k-block 0..3][h | m][lane][8 halves] (8 KB), [h8][2 planes][lane][16 bytes] (2 KB),
+    [l8] (2 KB).  Byte 4 j + r of a lane's 32 is the K position of half 4 (j % 2) + r of k-block 4 G + j / 2 in the f16 planes: what
+    the kernel's v_perm_b32 of the activations' f16 pieces produces."""
+    import numpy as np
+    src = blob.detach().cpu().numpy().view(np.uint16).copy()
+    out = src.copy()
+    pos = 0
+    for (K, nch) in ((128, 16), (256, 16), (256, 16), (256, 16), (256, 1)):
+        cu16 = (16 + 24 * K) * 2                    # uint16 elements of a chunk: 16 bias floats + K/32 k-blocks x 3 planes x 64 lanes x 8 halves
+        for _ in range(nch):
+            body = src[pos + 32:pos + cu16].reshape(K // 32, 3, 64, 8)
+            dst = out[pos + 32:pos + cu16].reshape(K // 128, 6144)      # 12 KB per group
+            for G in range(K // 128):
+                f16part = body[4 * G:4 * G + 4, 0:2]                                      # [kk][h|m][lane][8]
+                dst[G, :4096] = f16part.reshape(-1)
+                for which, plane in ((0, 0), (2, 1)):                                     # h -> h8, l -> l8
+                    p = body[4 * G:4 * G + 4, which].astype(np.uint32)                    # [kk][lane][8] f16 patterns
+                    b8 = ((p + 0x7F + ((p >> 8) & 1)) >> 8).astype(np.uint8)              # e5m2, round to nearest even
+                    # byte (j8, r) of a lane <- k-block j8 // 2, half 4 (j8 % 2) + r
+                    lanes = b8.transpose(1, 0, 2).reshape(64, 4, 2, 4).reshape(64, 8, 4)  # [lane][j8 = 2 kk + half-block][r]
+                    planes = lanes.reshape(64, 2, 16).transpose(1, 0, 2)                  # [plane = j8 // 4][lane][16 bytes]
+                    dst[G, 4096 + plane * 1024:4096 + (plane + 1) * 1024] = np.ascontiguousarray(planes).reshape(-1).view(np.uint16)
+            pos += cu16
+    assert pos <= src.size
+    return torch.from_numpy(out.view(np.float32)).to(device)

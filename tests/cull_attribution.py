@@ -1,7 +1,7 @@
 """Diagnostic behind tests/test_renderer_gpu.py's cull attribution (VERDICT r5 task 4): one 1024-pixel chunk of the synthetic 64 x 64
 view, HIP forward vs the oracle on the same octree tables and draws; per output field the error of the points whose sampled light
 directions sit on the n.d > 1e-6 cull (conftest.cull_marked_points) and of all the other points.
-    python tools/cull_attribution.py [chunk]        (GPU box; ~1 minute incl. the oracle's octree build)"""
+    python tests/cull_attribution.py [chunk]        (GPU box; ~1 minute incl. the oracle's octree build)"""
 import os
 import sys
 

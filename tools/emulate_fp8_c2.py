@@ -10,6 +10,7 @@ logits from a float64 evaluation for
     x6       all six products exact, every class accumulated in fp32 (what the kernels do)
     x6-fp8   the same with h.xl and l.xh formed from bf8 operands (register- and stream-neutral: xl and the l weights are only ever used there,
              so their f16 copies go; bf8 copies of xh and of the h weights take their place -- 4 f16 + 2 fp8 MFMAs per k-block instead of 6 f16)
+    x6-fp8t  x6-fp8 with the ACTIVATIONS' bf8 copies taken by truncation (the top bytes of the f16 pieces: one v_perm_b32 per four values)
     x6-fp8c2 all three c2 products from bf8 operands
 python tools/emulate_fp8_c2.py"""
 import os
@@ -46,6 +47,12 @@ def bf8(v):
     return b.astype(np.uint16).view(np.float16).astype(np.float64)
 
 
+def bf8t(v):
+    """e5m2 by TRUNCATION: the top byte of the f16 pattern as it stands (what one v_perm_b32 per four values extracts)"""
+    b = v.astype(np.float16).view(np.uint16) & np.uint16(0xFF00)
+    return b.view(np.float16).astype(np.float64)
+
+
 def acc32(a, b):
     """sum_k a[r,k] b[n,k] accumulated in fp32 k-block (32) by k-block, products exact (as the MFMA forms them)"""
     out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
@@ -67,6 +74,8 @@ def layer(x, W, bias, mode):
         c2 = acc32(xl, wh).astype(np.float64) + acc32(xm, wm) + acc32(xh, wl)
     elif mode == "x6-fp8":
         c2 = acc32(bf8(xl), bf8(wh)).astype(np.float64) + acc32(xm, wm) + acc32(bf8(xh), bf8(wl))
+    elif mode == "x6-fp8t":      # activations truncated (v_perm_b32 of the f16 pieces), weights rounded (packed on the host)
+        c2 = acc32(bf8t(xl), bf8(wh)).astype(np.float64) + acc32(xm, wm) + acc32(bf8t(xh), bf8(wl))
     else:
         c2 = acc32(bf8(xl), bf8(wh)).astype(np.float64) + acc32(bf8(xm), bf8(wm)) + acc32(bf8(xh), bf8(wl))
     c2 = c2.astype(np.float32)
@@ -98,7 +107,7 @@ def main():
     ref = run(x, layers, "f64")
     scale = np.abs(ref) + np.abs(ref).mean()
     print("light-visibility MLP logits, %d rows: error against float64, |a - b| / (|b| + mean|b|): median / 99th percentile / maximum" % n)
-    for mode in ("fp32", "x6", "x6-fp8", "x6-fp8c2"):
+    for mode in ("fp32", "x6", "x6-fp8", "x6-fp8t", "x6-fp8c2"):
         e = (np.abs(run(x, layers, mode) - ref) / scale).ravel()
         print("  %-9s %.2e / %.2e / %.2e" % (mode, np.median(e), np.quantile(e, 0.99), e.max()))
 
