@@ -56,7 +56,8 @@ PRECISIONS = {
     # name: (light-visibility kernel, stand-alone MLP kernels, dtype string of the JSON line)
     "exact": ("f16x6", "f16x6",
               "f32 (every MLP -- light visibility, SDF values and reverse-mode gradient, colour, visibility, 512-wide and CESR nets: every "
-              "fp32 operand exact as three f16 pieces, six f16 MFMA products per multiply-add in three fp32 accumulators; the 32 -> 128 "
+              "fp32 operand exact as three f16 pieces, six MFMA products per multiply-add in three fp32 accumulators -- in the light-visibility "
+              "kernel the two outer products of the 2^-22 class from bf8 copies of their operands, error against float64 unchanged; the 32 -> 128 "
               "-> 16 auto-encoder decoders on the f32-input MFMA) -- not narrower than the reference's fp32"),
     "fp32-mfma": ("fp32", "fp32", "f32 (every MLP on v_mfma_f32_16x16x4_f32)"),
     "f16": ("f16x1", "f16x3", "f16 (light-visibility MLP and the two CESR nets: ONE f16 MFMA product per multiply-add, f16 weights and f16 activations, fp32 accumulate; "
@@ -280,6 +281,12 @@ def vis_peak(vis):
     if vis == "f16x1":
         return PEAK_F16_MFMA_TFLOPS, "dense f16 MFMA 2500 TFLOP/s, one product per multiply-add (plain f16 operands: NARROWER than fp32)"
     if vis == "f16x6":
+        from robir_amd import ops
+        if ops.DVIS_X6_FP8:
+            # k_dvis_x6t since round 6: four exact f16 products + the two outer products of the 2^-22 class as bf8 MFMAs at twice the f16 rate =
+            # five f16-equivalent products per multiply-add: the bound of what the kernel executes MOVED UP with it (2500 / 5, not 2500 / 6)
+            return PEAK_F16_MFMA_TFLOPS / 5.0, ("dense f16 MFMA 2500 TFLOP/s / 5 f16-equivalent products per multiply-add (three-piece operands: four exact f16 "
+                                                "products + two bf8 products of the 2^-22 class on v_mfma_f32_16x16x128_f8f6f4 at twice the f16 rate)")
         return PEAK_F16_MFMA_TFLOPS / 6.0, "dense f16 MFMA 2500 TFLOP/s / 6 products per multiply-add (exact three-piece operands)"
     return PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA 2500 TFLOP/s / 3 (hi*hi, hi*lo, lo*hi products per multiply-add)"
 
@@ -471,6 +478,7 @@ def main():
                 "pmc_file": TRAFFIC_PROFILE.get(vis, "profiles/r06_dvis_x6t_pmc.md"),
                 "traffic_note": "bytes per pair of a separate PMC pass of the same kernel (2 x FETCH_SIZE + WRITE_SIZE) x this launch's pairs",
                 "precision": vis, "peak_note": note, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "frac_of_six_f16_products_bound": achieved / (PEAK_F16_MFMA_TFLOPS / 6.0) if vis == "f16x6" else None,
                 "launches": k_n, "avg_launch_ms": k_ms, "evals_per_launch": evals / max(k_n, 1),
                 "flops_per_eval": 2 * VIS_MACS_PER_EVAL}
 
@@ -590,7 +598,7 @@ def main():
             # DESIGN.md section 7's prediction for this N from the single-GPU step of the same precision (exact: 1358 ms of light
             # visibility + 54 ms of everything else, both proportional to a rank's chunks, + ~2 ms of per-pass launches and host
             # syncs + the tile gather): what the first SCALE run is held against
-            base_ms = {"exact": 1412.0, "f16": 338.0, "split": 700.0, "fp32-mfma": 3650.0}.get(args.precision)
+            base_ms = {"exact": 1260.0, "f16": 338.0, "split": 700.0, "fp32-mfma": 3650.0}.get(args.precision)
             line["per_rank"] = per_rank
             line["allgather_ms"] = allgather_ms
             line["roofline"]["of_rank"] = max(per_rank, key=lambda r: r["dvis_kernel_ms_per_step"])["rank"]

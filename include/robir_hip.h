@@ -190,8 +190,14 @@ int rb_dvis_fused(const float* normals, const int* chunk_id, long n, const float
 /* The light-visibility stage with EXACT fp32 operands on the f16 matrix pipe ("f16x6", csrc/vis_diffuse_x6t.hip + x6t_engine.h; the
  * DEFAULT and bench.py's headline kernel): every operand as three halves (h + m 2^-11 + l 2^-22 = the fp32 value exactly), the six
  * partial products of weight >= 2^-22 in three fp32 accumulators by weight class -- not narrower than the reference's fp32
- * (VisNetwork, model/implicit_differentiable_renderer.py:241-258, evaluated by nn.Linear in fp32).  W49 = the three hidden layers and
- * the 256->2 output layer (rows padded to 16) packed by rb_pack_layer_x6 back to back = 49 chunks; scale_log2 = 0.  One workgroup of
+ * (VisNetwork, model/implicit_differentiable_renderer.py:241-258, evaluated by nn.Linear in fp32).  Since round 6 the two outer
+ * products of the 2^-22 class (h.xl, l.xh) are formed from bf8 copies of their operands on v_mfma_f32_16x16x128_f8f6f4 (twice the f16
+ * rate; the other four products stay exact; error against float64 unchanged: DESIGN.md section 6).  W49 = the three hidden layers and
+ * the 256->2 output layer (rows padded to 16) packed by rb_pack_layer_x6 back to back = 49 chunks, then re-arranged per half chunk
+ * of 128 K as [k-block 0..3][h | m][lane][8 halves] (8 KB), [h8: 2 planes][lane][16 bytes] (2 KB), [l8] (2 KB) with byte 4 j + r of
+ * a lane's 32 = the e5m2 rounding of half 4 (j % 2) + r of k-block 4 G + j / 2 (robir_amd/packing.py: repack_x6_chunks_fp8): the same
+ * size; scale_log2 = 8 NAMES this layout (a library built with -DXT_FP8=0 takes rb_pack_layer_x6's own layout and scale_log2 = 0; a
+ * mismatch is refused).  One workgroup of
  * four waves per point, TWO 16-sample tiles per wave (a weight fragment read from the LDS feeds both tiles, a pass of the weights
  * serves 128 samples), output layer on the matrix pipe.  Other arguments as rb_dvis_fused; vis_out agrees with its precision 0 to
  * fp32 summation order. */

@@ -26,6 +26,17 @@ constexpr int XT_WF4 = 1536;             // weight part of a packed chunk: [kb 8
 constexpr int XT_CF4 = 4 + XT_WF4;       // packed chunk in global memory: 16 bias floats + weights
 constexpr int XT_SLOTS = 4, XT_DIST = 3;
 constexpr int XT_PIECES = 6;             // 4 KB rows (1 KB per wave) of one chunk copy
+// Round 6 (XT_FP8, default on; DESIGN section 5.6 item 10, profiles/r06_fp8_c2.md): of the six products of a multiply-add the two outer ones of
+// the 2^-22 class -- h.xl and l.xh, each with an operand of at most three significant bits -- are formed from bf8 (e5m2) copies of their
+// operands on v_mfma_f32_16x16x128_f8f6f4, which does a half chunk's 128 K in one instruction at twice the f16 rate: four f16 + two bf8
+// products = five f16-equivalents instead of six.  The other four products (h.xh | h.xm, m.xh | m.xm) stay exact.  Error against a float64
+// evaluation: unchanged (the two terms enter at 2^-22 and are right to two or three bits: <= 2^-24 of a product, below what fp32's own
+// accumulation rounds away; tests/test_precision_gpu.py).  Register- and stream-neutral: the f16 l pieces of weights and activations are
+// used nowhere else and go; bf8 copies of the h and l pieces take their place (weights: packing.repack_x6_chunks_fp8, named by
+// scale_log2 = 8; activations: the top bytes of the f16 pieces, one v_perm_b32 per four values).  -DXT_FP8=0: six f16 products (rounds 4-5).
+#ifndef XT_FP8
+#define XT_FP8 1
+#endif
 #ifndef XT_PINGPONG
 #define XT_PINGPONG 0
 #endif
@@ -158,6 +169,17 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
   asm volatile("" : "+v"(ring_a0), "+v"(ring_a2));
   const lds_u4p ring_u = (lds_u4p)ring_a0, ring_u2 = (lds_u4p)ring_a2;
   u4 wh[4], wm[4], wl[4];              // rolling window: the fragments of four k-blocks (half a chunk)
+#if XT_FP8
+  typedef int xt_i8 __attribute__((ext_vector_type(8)));
+  xt_i8 w8h, w8l;                      // ... and the half's bf8 fragments of the h and l pieces (wl unused)
+  // a half chunk = 12 KB = 768 lane-strided u4: [k-block 0..3][h | m] (512), h8 (two planes: 128), l8 (128)
+#define XT_F16OFF(KB, PIECE) (((KB) >> 2) * 768 + (((KB) & 3) * 2 + (PIECE)) * 64)
+#define XT_LOAD8(DST, BASE, OFF)                                                                                             \
+  {                                                                                                                          \
+    const u4 a_ = (BASE)[(OFF)], b_ = (BASE)[(OFF) + 64];                                                                    \
+    DST = xt_i8{(int)a_[0], (int)a_[1], (int)a_[2], (int)a_[3], (int)b_[0], (int)b_[1], (int)b_[2], (int)b_[3]};             \
+  }
+#endif
   f4 bias;
   if (rounds > 0) {
 #pragma unroll
@@ -170,17 +192,34 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#if XT_FP8
+      wh[k] = ring_u[XT_F16OFF(k, 0)];
+      wm[k] = ring_u[XT_F16OFF(k, 1)];
+#else
       wh[k] = ring_u[(k * 3 + 0) * 64];
       wm[k] = ring_u[(k * 3 + 1) * 64];
       wl[k] = ring_u[(k * 3 + 2) * 64];
+#endif
     }
+#if XT_FP8
+    XT_LOAD8(w8h, ring_u, 512)
+    XT_LOAD8(w8l, ring_u, 640)
+#endif
     bias = bias_tab[g];
   }
 
   unsigned sat = 0u;                   // range sentinel: running max of the h pieces (all >= 0 here: ReLU outputs)
+#if XT_FP8
+  struct Ops {
+    u4 h[2][8], m[2][8];               // B operands of a layer, two tiles: the f16 h and m pieces (one 128-bit tuple per k-block)
+    xt_i8 h8[2][2], l8[2][2];          // ... and bf8 copies of the h and l pieces, 32 K values per lane and half (the top bytes of the f16 pieces)
+  };
+  unsigned el_keep[2] = {0u, 0u};
+#else
   struct Ops {
     u4 h[2][8], m[2][8], l[2][8];      // B operands of a layer, two tiles (one 128-bit tuple per k-block and piece)
   };
+#endif
   Ops P, Q;                            // current / next layer's operands, filled chunk by chunk; the layers alternate the roles
 
 #define XT_MFMA(ACC, WREG, XREG) \
@@ -214,7 +253,16 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(mu), "s"(negk), "v"(e1));
     Y.h[t][jb >> 1][(jb & 1) * 2 + q] = eh;
     Y.m[t][jb >> 1][(jb & 1) * 2 + q] = mu;
+#if XT_FP8
+    if (q == 0) {
+      el_keep[t] = lu;
+    } else {      // the block's four h and four l halves -> dword jb of the next layer's bf8 operands (their top bytes: e5m2 by truncation)
+      Y.h8[t][jb >> 3][jb & 7] = (int)__builtin_amdgcn_perm(eh, Y.h[t][jb >> 1][(jb & 1) * 2], 0x07050301u);
+      Y.l8[t][jb >> 3][jb & 7] = (int)__builtin_amdgcn_perm(lu, el_keep[t], 0x07050301u);
+    }
+#else
     Y.l[t][jb >> 1][(jb & 1) * 2 + q] = lu;
+#endif
   };
   // the twelve stage instances of a chunk's epilogue in issue order
   auto ep_slot = [&](Ops& Y, int s, int pj) {
@@ -325,7 +373,16 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           sx_split_pair(fmaxf(av[2 * q] + bv[2 * q], 0.f), fmaxf(av[2 * q + 1] + bv[2 * q + 1], 0.f), negk, h, m, l);
           P.h[t][kb / 2][(kb & 1) * 2 + q] = h;
           P.m[t][kb / 2][(kb & 1) * 2 + q] = m;
+#if XT_FP8
+          if (q == 0) {
+            el_keep[t] = l;
+          } else {
+            P.h8[t][kb >> 3][kb & 7] = (int)__builtin_amdgcn_perm(h, P.h[t][kb / 2][(kb & 1) * 2], 0x07050301u);
+            P.l8[t][kb >> 3][kb & 7] = (int)__builtin_amdgcn_perm(l, el_keep[t], 0x07050301u);
+          }
+#else
           P.l[t][kb / 2][(kb & 1) * 2 + q] = l;
+#endif
           sat = sat_acc_nonneg(sat, h);
         }
       }
@@ -374,8 +431,13 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
 #ifdef XT_ABL_NOLDS                   // timing ablation (wrong results): no fragment reads
 #define XT_FRAG(DST, KB, PIECE) asm volatile("" : "+v"(DST))
 #else
+#if XT_FP8
+#define XT_FRAG(DST, KB, PIECE) DST = nfrag[XT_F16OFF(KB, PIECE)]
+#else
 #define XT_FRAG(DST, KB, PIECE) DST = nfrag[((KB) * 3 + (PIECE)) * 64]
 #endif
+#endif
+#define XT_MFMA8(ACC, WREG, XREG) ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(WREG, XREG, ACC, 1, 1, 0, 0, 0, 0)
 #define XT_EP(S)                        \
   do {                                  \
     if (jb > 0) ep_slot(Y, (S), jb - 1); \
@@ -410,6 +472,22 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_RUN(acc[0].c1, wh, X.m[0]);                       // 2
           if (H == 0) XT_EP(1); else XT_EP(10);
           XT_FENCE;
+#if XT_FP8
+          XT_MFMA8(acc[0].c2, w8h, X.l8[0][H]);                // 3: h.xl of the half's 128 K as ONE bf8 MFMA
+          if (H == 0) XT_EP(2); else XT_EP(11);
+          XT_FENCE;
+          XT_RUN(acc[1].c0, wh, X.h[1]);                       // 4
+          if (H == 0) XT_EP(3); else XT_COPY(0);
+          XT_FENCE;
+          XT_RUN_REFILL(acc[1].c1, wh, X.m[1], 0);             // 5: the f16 h fragments' last use
+          if (H == 0) XT_EP(4); else XT_COPY(1);
+          XT_FENCE;
+          XT_MFMA8(acc[1].c2, w8h, X.l8[1][H]);                // 6: the bf8 h fragment's last use
+#ifndef XT_ABL_NOLDS
+          XT_LOAD8(w8h, nfrag, (1 - H) * 768 + 512)
+#endif
+          XT_FENCE;
+#else
           XT_RUN(acc[0].c2, wh, X.l[0]);                       // 3
           if (H == 0) XT_EP(2); else XT_EP(11);
           XT_FENCE;
@@ -421,6 +499,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_FENCE;
           XT_RUN_REFILL(acc[1].c2, wh, X.l[1], 0);             // 6: the h fragments' last use
           XT_FENCE;
+#endif
           XT_RUN(acc[0].c1, wm, X.h[0]);                       // 7
           if (H == 0) XT_EP(5); else XT_COPY(2);
           XT_FENCE;
@@ -432,17 +511,29 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_FENCE;
           XT_RUN_REFILL(acc[1].c2, wm, X.m[1], 1);             // 10: the m fragments' last use
           XT_FENCE;
+#if XT_FP8
+          XT_MFMA8(acc[0].c2, w8l, X.h8[0][H]);                // 11: l.xh as one bf8 MFMA
+          if (H == 0) XT_EP(8); else XT_COPY(5);
+          XT_FENCE;
+          XT_MFMA8(acc[1].c2, w8l, X.h8[1][H]);                // 12: the bf8 l fragment's last use
+#ifndef XT_ABL_NOLDS
+          XT_LOAD8(w8l, nfrag, (1 - H) * 768 + 640)
+#endif
+          XT_FENCE;
+#else
           XT_RUN(acc[0].c2, wl, X.h[0]);                       // 11
           if (H == 0) XT_EP(8); else XT_COPY(5);
           XT_FENCE;
           XT_RUN_REFILL(acc[1].c2, wl, X.h[1], 2);             // 12: the l fragments' last use
           XT_FENCE;
+#endif
         }
 #undef XT_RUN
 #undef XT_RUN_REFILL
 #undef XT_COPY
 #undef XT_FENCE
 #undef XT_FRAG
+#undef XT_MFMA8
 #undef XT_EP
         prev[0] = acc[0];
         prev[1] = acc[1];
@@ -466,8 +557,19 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
         for (int kb = 0; kb < 8; ++kb) {
           P.h[t][kb] = Q.h[t][kb];
           P.m[t][kb] = Q.m[t][kb];
+#if !XT_FP8
           P.l[t][kb] = Q.l[t][kb];
+#endif
         }
+#if XT_FP8
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          P.h8[t][hf] = Q.h8[t][hf];
+          P.l8[t][hf] = Q.l8[t][hf];
+        }
+#endif
     }
     Ops& HX = P;
 #endif
@@ -487,6 +589,29 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
         acc[t].c2 = f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
+#if XT_FP8
+      for (int kb = 0; kb < 8; ++kb) {
+        const u4 fh = hw[XT_F16OFF(kb, 0)], fm = hw[XT_F16OFF(kb, 1)];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          XT_MFMA(acc[t].c0, fh, HX.h[t][kb]);
+          XT_MFMA(acc[t].c1, fh, HX.m[t][kb]);
+          XT_MFMA(acc[t].c1, fm, HX.h[t][kb]);
+          XT_MFMA(acc[t].c2, fm, HX.m[t][kb]);
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        xt_i8 f8h, f8l;
+        XT_LOAD8(f8h, hw, hf * 768 + 512)
+        XT_LOAD8(f8l, hw, hf * 768 + 640)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t].c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f8h, HX.l8[t][hf], acc[t].c2, 1, 1, 0, 0, 0, 0);
+          acc[t].c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f8l, HX.h8[t][hf], acc[t].c2, 1, 1, 0, 0, 0, 0);
+        }
+      }
+#else
       for (int kb = 0; kb < 8; ++kb) {
         const u4 fh = hw[(kb * 3 + 0) * 64], fm = hw[(kb * 3 + 1) * 64], fl = hw[(kb * 3 + 2) * 64];
 #pragma unroll
@@ -499,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_MFMA(acc[t].c2, fl, HX.h[t][kb]);
         }
       }
+#endif
       bias = bias_tab[g];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -562,7 +688,11 @@ extern "C" int rb_dvis_fused_x6t(const float* normals, const int* chunk_id, long
   RB_REQUIRE(normals && A && Bd && dirs && wdir && wsum && W49 && vis_out, "null pointer");
   RB_REQUIRE(n <= RB_MAX_BLOCKS, "too many points for one launch (one workgroup each)");
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= XT_MAX_DIRS, "need L <= 256 and L*nsamp <= 4096");
+#if XT_FP8
+  RB_REQUIRE(scale_log2 == 8, "this build of k_dvis_x6t takes the bf8 weight layout (packing.repack_x6_chunks_fp8; scale_log2 = 8 names it)");
+#else
   RB_REQUIRE(scale_log2 == 0, "k_dvis_x6t takes weights packed with scale_log2 = 0");
+#endif
   XtArgs a{};
   a.A = A, a.Bd = Bd, a.W49 = (const f4*)W49, a.argmax_vis = argmax_vis;
   a.range_word = range_flags() ? range_flags() + RB_RANGE_DVIS : nullptr;
@@ -584,7 +714,11 @@ extern "C" int rb_dvis_stream_x6(const float* normals, const int* chunk_id, long
   RB_REQUIRE(L > 0 && L <= 256 && nsamp > 0 && (long)L * nsamp <= XT_MAX_DIRS && (L * nsamp) % 16 == 0,
              "need L <= 256, L*nsamp <= 4096 and a multiple of 16");
   RB_REQUIRE((long)n * (L * nsamp / 16) < (1L << 31), "tile index would overflow 31 bits");
+#if XT_FP8
+  RB_REQUIRE(scale_log2 == 8, "this build of k_dvis_x6t takes the bf8 weight layout (packing.repack_x6_chunks_fp8; scale_log2 = 8 names it)");
+#else
   RB_REQUIRE(scale_log2 == 0, "k_dvis_x6t takes weights packed with scale_log2 = 0");
+#endif
   hipStream_t s = (hipStream_t)stream;
   if (n_workgroups <= 0) n_workgroups = device_cus();
   RB_REQUIRE(n_workgroups > 0, "device query failed");

@@ -544,6 +544,7 @@ def chunk_ids_ascending(chunk_id):
         known = bool((chunk_id[1:] >= chunk_id[:-1]).all())
         chunk_id._robir_ascending = known
     return known
+DVIS_X6_FP8 = os.environ.get("ROBIR_DVIS_X6_FP8", "1") == "1"      # the two-tile light-visibility kernel as built (csrc/vis_diffuse_x6t.hip XT_FP8 = 1: two of its six products on the bf8 MFMA) takes the weight layout of packing.repack_x6_chunks_fp8; 0 for a library built with -DXT_FP8=0 (a mismatch is refused by the entry point)
 DVIS_X6_FORM = os.environ.get("ROBIR_DVIS_X6_FORM", "auto")          # what "f16x6" runs: auto | f16x6-pt | f16x6-stream | f16x6-1t
 
 
@@ -613,6 +614,8 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
         counters = torch.empty(2, dtype=torch.int64, device=dev)
         x6 = precision in ("f16x6-stream", "f16x1")      # "f16x1": plain f16, one product (csrc/vis_diffuse_f16t.hip): NARROWER than fp32
         blob, fmt = split["hidden_x6_head" if x6 else "hidden_h3_head"], split["x6_head_scale_log2" if x6 else "h3_head_scale_log2"]
+        if precision == "f16x6-stream" and DVIS_X6_FP8:
+            blob, fmt = split["hidden_x6_head_fp8"], 8
         if precision == "f16x1" and DVIS_F16_GEN >= 2:
             blob, fmt = split["hidden_f16_head"], 1       # rb_dvis_stream_f16: format 1 = the h-only blob -> second-generation kernel
         call("rb_dvis_stream_f16" if precision == "f16x1" else ("rb_dvis_stream_x6" if x6 else "rb_dvis_stream"), ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
@@ -621,9 +624,10 @@ def dvis_fused(normals, chunk_id, A, Bd, dirs, wdir, wsum, split, L, nsamp, argm
              c_int(DVIS_STREAM_WORKGROUPS), ptr(out), ptr(eval_count), stream_ptr())
         return out
     if precision in X6:
+        fp8 = DVIS_X6_FP8 and precision != "f16x6-1t"
         call("rb_dvis_fused_x6" if precision == "f16x6-1t" else "rb_dvis_fused_x6t", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),
-             ptr(split["hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
-             c_int(split["x6_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
+             ptr(split["hidden_x6_head_fp8" if fp8 else "hidden_x6_head"]), c_int(L), c_int(nsamp), c_int(1 if argmax_vis else 0),
+             c_int(8 if fp8 else split["x6_head_scale_log2"]), ptr(out), ptr(eval_count), stream_ptr())
         return out
     if precision == "f16x3-v2":
         call("rb_dvis_fused_v2", ptr(normals), ptr(chunk_id), c_long(n), ptr(A), ptr(Bd), ptr(dirs), ptr(wdir), ptr(wsum),

@@ -186,6 +186,8 @@ class _VisSplit(dict):
             v = pack_layers_h3(self._hl + [dict(W=self["w_last"], b=self["b_last"], n_pad=16, k_pad=256)], self._device)
         elif k == "hidden_f16_head":
             v = pack_vis_f16_head(self["hidden_x6_head"])
+        elif k == "hidden_x6_head_fp8":      # the 49 chunks in the bf8 layout (k_dvis_x6t built with -DXT_FP8=1; format 8)
+            v = repack_x6_chunks_fp8(self["hidden_x6_head"], self._device, ((256, 49),))
         else:
             raise KeyError(k)
         self[k] = v
@@ -479,16 +481,22 @@ def pack_softplus512_h3(sd, prefix, k_in, device):
 
 
 def repack_vis_x6_fp8(blob, device):
-    """EXPERIMENT (csrc/vis_x6.hip built with -DVX_FP8=1; not a shipped path): the blob of pack_vis_x6 with the l pieces
-    of every weight replaced by bf8 (e5m2) copies of the h and l pieces in the K = 128 order of v_mfma_f32_16x16x128_f8f6f4.  Same size:
+    """EXPERIMENT (csrc/vis_x6.hip built with -DVX_FP8=1): the blob of pack_vis_x6 in the bf8 layout of repack_x6_chunks_fp8."""
+    return repack_x6_chunks_fp8(blob, device, ((128, 16), (256, 16), (256, 16), (256, 16), (256, 1)))
+
+
+def repack_x6_chunks_fp8(blob, device, layout):
+    """A blob of exact-operand chunks (rb_pack_layer_x6: per chunk [16 bias floats][k-block][h | m | l][lane][8 halves]; `layout` = its (K,
+    number of chunks) runs) with the l pieces of every weight replaced by bf8 (e5m2) copies of the h and l pieces in the K = 128 order of
+    v_mfma_f32_16x16x128_f8f6f4 (the products h.xl and l.xh of the 2^-22 class at twice the f16 rate).  Same size:
     per chunk [16 bias floats] + per group of 128 K: [k-block 0..3][h | m][lane][8 halves] (8 KB), [h8][2 planes][lane][16 bytes] (2 KB),
     [l8] (2 KB).  Byte 4 j + r of a lane's 32 is the K position of half 4 (j % 2) + r of k-block 4 G + j / 2 in the f16 planes: what
-    the kernel's v_perm_b32 of the activations' f16 pieces produces."""
+    the kernels' v_perm_b32 of the activations' f16 pieces produces.  Anything behind the chunks (padding) is kept."""
     import numpy as np
     src = blob.detach().cpu().numpy().view(np.uint16).copy()
     out = src.copy()
     pos = 0
-    for (K, nch) in ((128, 16), (256, 16), (256, 16), (256, 16), (256, 1)):
+    for (K, nch) in layout:
         cu16 = (16 + 24 * K) * 2                    # uint16 elements of a chunk: 16 bias floats + K/32 k-blocks x 3 planes x 64 lanes x 8 halves
         for _ in range(nch):
             body = src[pos + 32:pos + cu16].reshape(K // 32, 3, 64, 8)
