@@ -579,3 +579,44 @@ def test_streaming_kernel_equals_one_point_per_workgroup_kernel(dev, vis_net):
             assert e == evals, (n, k)
             assert torch.equal(v, ref), (n, k, float((v - ref).abs().max()))
         ops.range_check(sync=True)
+
+
+def test_light_visibility_arithmetic_vs_float64(dev, vis_net, oracle_sd, monkeypatch):
+    """The default light-visibility kernel since round 6 forms the two outer products of the 2^-22 class (h.xl, l.xh) from bf8 copies of their
+    operands (csrc/vis_diffuse_x6t.hip, XT_FP8).  Anchored on a FLOAT64 evaluation of the reference's formulas (oracle, same points,
+    directions and draws): the per-lobe visibilities of the default kernel must be no farther from it than those of the f32-input-MFMA
+    kernel (factor 1.0 + 2^-23, median and 99th percentile -- the bar tests/test_precision_gpu.py sets for every net), and no farther than
+    1.1 x those of round 3's six-exact-products kernel (k_dvis_x6, legacy library; that leg is skipped without it)."""
+    from robir_amd import _lib, sg_render, synth
+    from robir_oracle import nets as on, sg as osg
+    g = np.random.Generator(np.random.PCG64(61))
+    n, L, nsamp = 96, 128, 32
+    pts = torch.from_numpy((g.standard_normal((n, 3)) * 0.25).astype(np.float32))
+    nrm = torch.nn.functional.normalize(torch.from_numpy(g.standard_normal((n, 3)).astype(np.float32)), dim=-1)
+    lgt = torch.from_numpy(synth.synth_light_sgs(3, L))
+    lobe, lam = lgt[:, :3], lgt[:, 3:4].abs()
+    u = torch.from_numpy(g.random((2, L, nsamp), dtype=np.float32))
+    draws = {"dvis_theta": u[0][None].to(dev), "dvis_phi": u[1][None].to(dev)}
+    sd64 = {k: v.double() for k, v in oracle_sd.items() if k.startswith("visibility_network.")}
+    # the sampled directions and the cull in fp32 like every kernel's (shared geometry), the MLP and everything behind it in float64
+    r64 = osg.diffuse_visibility(pts, nrm, lambda p, d: on.vis_logits(sd64, p.double(), d.double()),
+                                 torch.nn.functional.normalize(lobe, dim=-1), lam, u[0], u[1]).double()
+    modes = ["f16x6", "fp32"]
+    try:
+        _lib.legacy()
+        modes.append("f16x6-1t")
+    except Exception:
+        pass
+    err = {}
+    for mode in modes:
+        monkeypatch.setattr(sg_render, "VIS_PRECISION", mode)
+        out = sg_render.get_diffuse_visibility(pts.to(dev), nrm.to(dev), vis_net, lobe.to(dev), lam.to(dev), nsamp=nsamp, draws=draws).cpu().double()
+        e = ((out - r64).abs() / (r64.abs() + r64.abs().mean())).flatten()
+        err[mode] = (float(e.median()), float(e.kthvalue(int(0.99 * e.numel())).values), float(e.max()))
+        record_metric("light_visibility_vs_float64/" + mode, median=err[mode][0], p99=err[mode][1], max=err[mode][2])
+        print(f"light visibility vs float64, {mode}: median {err[mode][0]:.2e} p99 {err[mode][1]:.2e} max {err[mode][2]:.2e}")
+    eps = 2.0 ** -23
+    for i in (0, 1):
+        assert err["f16x6"][i] <= 1.0 * err["fp32"][i] + eps, (i, err)
+        if "f16x6-1t" in err:
+            assert err["f16x6"][i] <= 1.1 * err["f16x6-1t"][i] + 1e-8, (i, err)
