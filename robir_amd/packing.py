@@ -507,6 +507,8 @@ def repack_x6_chunks_fp8(blob, device, layout):
                 for which, plane in ((0, 0), (2, 1)):                                     # h -> h8, l -> l8
                     p = body[4 * G:4 * G + 4, which].astype(np.uint32)                    # [kk][lane][8] f16 patterns
                     b8 = ((p + 0x7F + ((p >> 8) & 1)) >> 8).astype(np.uint8)              # e5m2, round to nearest even
+                    finite = (p & 0x7C00) != 0x7C00                                        # ... a finite half never rounds up to infinity: saturate
+                    b8 = np.where(finite & ((b8 & 0x7F) >= 0x7C), (b8 & 0x80) | 0x7B, b8).astype(np.uint8)
                     # byte (j8, r) of a lane <- k-block j8 // 2, half 4 (j8 % 2) + r
                     lanes = b8.transpose(1, 0, 2).reshape(64, 4, 2, 4).reshape(64, 8, 4)  # [lane][j8 = 2 kk + half-block][r]
                     planes = lanes.reshape(64, 2, 16).transpose(1, 0, 2)                  # [plane = j8 // 4][lane][16 bytes]
