@@ -12,12 +12,17 @@
 #include "x6t_engine.h"
 #include <type_traits>
 
+#ifndef QX_FP8
+#define QX_FP8 0            // 1 (needs QX_FINE): EXPERIMENT -- in the layers whose units are K = 256 the products h.xl and l.xh as bf8 MFMAs (vis_diffuse_x6t.hip XT_FP8)
+#endif
 #ifndef QX_FINE
 #define QX_FINE 1           // a filler slot behind EVERY MFMA, the previous chunk's softplus + split as single-instruction steps (0: two clusters per chunk; -1.3 % / -2 %, bit-identical: profiles/r06_dma_placement.md)
 #endif
 #ifndef QX_SPREAD
 #define QX_SPREAD 1         // the LDS-DMA copies of a unit one at a time, three MFMAs apart (0: blocks of 1 / 4 / 2 instructions; profiles/r06_dma_placement.md: -2.4 %)
 #endif
+
+static_assert(!QX_FP8 || QX_FINE, "QX_FP8 is written into the QX_FINE form of the k-block");
 
 namespace rb {
 
@@ -86,6 +91,10 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
   unsigned sat = 0u;
   u4 xh[18], xm[18], xl[18];           // operands of the current layer (K <= 576): three pieces, one tile
   u4 yh[16], ym[16], yl[16];           // ... of the next layer
+#if QX_FP8
+  typedef int qx_i8 __attribute__((ext_vector_type(8)));
+  qx_i8 xh8[4], xl8[4], yh8[4], yl8[4];      // bf8 copies of the h and l pieces for the layers that run two products on the bf8 MFMA (K = 512: four groups of 128)
+#endif
   long rrow = 0;
   int label = -1;
 
@@ -178,6 +187,8 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     constexpr int LI = decltype(LI_tag)::value;
     constexpr int KU = Net::kunit(LI), KB = KU / 32, HV = Net::hv(LI), NU = Net::nunits(LI), UB = Net::ubase(LI);
     constexpr bool OUT = LI == 8, SKIPOUT = LI == 3;
+    constexpr bool FP8 = QX_FP8 && KU == 256;                       // this layer's weights are in the bf8 layout (packing.repack_x6_chunks_fp8)
+    constexpr bool NEXT_FP8 = QX_FP8 && LI != 3 && LI != 8;         // ... and so are the next layer's: its operands get bf8 copies instead of f16 l pieces
 #ifndef QX_DB
 #define QX_DB 1              // fragment sets read ahead per k-block: 2 measured 1 % slower (and 66 instead of 42 spilled registers in the shadow_net instance)
 #endif
@@ -259,6 +270,14 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
           const int o = (pj & 1) * 2 + q;
           yh[pj >> 1][o] = f_h[q];
           ym[pj >> 1][o] = f_m[q];
+#if QX_FP8
+          if constexpr (NEXT_FP8) {
+            if (q == 1) {      // the top bytes of the block's four h / l halves: dword pj of the next layer's bf8 operands
+              yh8[pj >> 3][pj & 7] = (int)__builtin_amdgcn_perm(f_h[1], f_h[0], 0x07050301u);
+              yl8[pj >> 3][pj & 7] = (int)__builtin_amdgcn_perm(f_l[1], f_l[0], 0x07050301u);
+            }
+          } else
+#endif
           yl[pj >> 1][o] = f_l[q];
           sat = sat_acc_pos(sat, f_h[q]);
         }
@@ -269,11 +288,23 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
 #pragma unroll
     for (int i = 0; i < D; ++i)
       if (i < NSTEP) {
-        const u4* f = frag_of(i / KB) + (3 * (i % KB)) * 64;
-        wfh[i % NB] = f[0];
-        wfm[i % NB] = f[64];
-        wfl[i % NB] = f[128];
+#if QX_FP8
+        if constexpr (FP8) {      // a group of 128 K = 768 lane-strided u4: [k-block 0..3][h | m] (512), h8 (128), l8 (128)
+          const u4* f = frag_of(i / KB) + ((i % KB) >> 2) * 768 + (2 * ((i % KB) & 3)) * 64;
+          wfh[i % NB] = f[0];
+          wfm[i % NB] = f[64];
+        } else
+#endif
+        {
+          const u4* f = frag_of(i / KB) + (3 * (i % KB)) * 64;
+          wfh[i % NB] = f[0];
+          wfm[i % NB] = f[64];
+          wfl[i % NB] = f[128];
+        }
       }
+#if QX_FP8
+    qx_i8 w8h, w8l;
+#endif
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int c = u / HV, hvi = u % HV;
@@ -332,16 +363,75 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
 #else
           if (s2 < NSTEP) {
 #endif
-            const u4* f = frag_of(s2 / KB) + (3 * (s2 % KB)) * 64;
-            wfl[s2 % NB] = f[128];
-            wfm[s2 % NB] = f[64];
-            wfh[s2 % NB] = f[0];
+#if QX_FP8
+            if constexpr (FP8) {
+              const u4* f = frag_of(s2 / KB) + ((s2 % KB) >> 2) * 768 + (2 * ((s2 % KB) & 3)) * 64;
+              wfm[s2 % NB] = f[64];
+              wfh[s2 % NB] = f[0];
+            } else
+#endif
+            {
+              const u4* f = frag_of(s2 / KB) + (3 * (s2 % KB)) * 64;
+              wfl[s2 % NB] = f[128];
+              wfm[s2 % NB] = f[64];
+              wfh[s2 % NB] = f[0];
+            }
           }
         }
+#if QX_FP8
+        if constexpr (FP8) {
+          if ((kb & 3) == 0) {      // the group's two bf8 fragments: four reads, used behind the group's last k-block
+            const u4* f8 = frag_of(u) + (kb >> 2) * 768 + 512;
+            const u4 a0 = f8[0], a1 = f8[64], b0 = f8[128], b1 = f8[192];
+            w8h = qx_i8{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+            w8l = qx_i8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+          }
+        }
+#endif
         {
           const int xk = hvi * KB + kb;
 #define QX_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, W), __builtin_bit_cast(h8, X), ACC, 0, 0, 0)
+#if QX_FINE && QX_FP8
+          if constexpr (FP8) {
+            // four f16 products per k-block + two bf8 MFMAs per group of four: 4 KB + 2 (KB / 4) slots per unit
+            constexpr int NSC8 = HV * (KB * 4 + (KB / 4) * 2);
+            constexpr int FPER8_ = (FNSTEP + NSC8 - 1) / NSC8, FPER8 = FPER8_ > 4 ? 4 : FPER8_;
+            const bool fine_here8 = !OUT && c > 0;
+            const int sbase8 = hvi * (KB * 4 + (KB / 4) * 2) + kb * 4 + (kb >> 2) * 2;
+#define QX_SLOT8(J)                                                                                    \
+  {                                                                                                    \
+    if (fine_here8) {                                                                                  \
+      const int sc_ = sbase8 + (J);                                                                    \
+      _Pragma("unroll") for (int i_ = 0; i_ < FPER8; ++i_)                                             \
+        if (FPER8 * sc_ + i_ < FNSTEP) fine_step(FPER8 * sc_ + i_, c - 1, accs[(c - 1) & 1]);          \
+    }                                                                                                  \
+    if (QX_SPREAD && kb >= HB && ((J) == 1 || (J) == 3)) spread_site(2 * (kb - HB) + ((J) == 3));      \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  }
+            QX_MFMA(acc.c2, wfm[st % NB], xm[xk]);
+            QX_SLOT8(0)
+            QX_MFMA(acc.c1, wfm[st % NB], xh[xk]);
+            QX_SLOT8(1)
+            QX_MFMA(acc.c1, wfh[st % NB], xm[xk]);
+            QX_SLOT8(2)
+            QX_MFMA(acc.c0, wfh[st % NB], xh[xk]);
+            QX_SLOT8(3)
+            if ((kb & 3) == 3) {
+              acc.c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8l, xh8[xk >> 2], acc.c2, 1, 1, 0, 0, 0, 0);
+              QX_SLOT8(4)
+              acc.c2 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8h, xl8[xk >> 2], acc.c2, 1, 1, 0, 0, 0, 0);
+              QX_SLOT8(5)
+            }
+#undef QX_SLOT8
+            if (fine_here8 && hvi == HV - 1 && kb == KB - 1) {
+#pragma unroll
+              for (int m_ = 0; m_ < FNSTEP; ++m_)
+                if (m_ >= FPER8 * NSC8) fine_step(m_, c - 1, accs[(c - 1) & 1]);
+            }
+          } else
+#endif
 #if QX_FINE
+          {
           // a filler slot behind EVERY MFMA: the steps of chunk c-1's epilogue (hidden layers), the copies at their two sites per k-block
           constexpr int NSC = HV * KB * 6;                                        // MFMAs (= slots) per chunk
           constexpr int FPER_ = (FNSTEP + NSC - 1) / NSC, FPER = FPER_ > 4 ? 4 : FPER_;
@@ -373,6 +463,7 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
 #pragma unroll
             for (int m_ = 0; m_ < FNSTEP; ++m_)
               if (m_ >= FPER * NSC) fine_step(m_, c - 1, accs[(c - 1) & 1]);
+          }
           }
 #else
           QX_MFMA(acc.c2, wfl[st % NB], xh[xk]);
@@ -432,8 +523,16 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
     }
     constexpr int NCH = NU / HV;
     const SxAcc& last = accs[(NCH - 1) & 1];
-    epilogue(last, NCH - 1, 0);
-    epilogue(last, NCH - 1, 1);
+#if QX_FINE && QX_FP8
+    if constexpr (!OUT) {      // the last chunk through the same steps (they also fill the bf8 operands)
+#pragma unroll
+      for (int m_ = 0; m_ < FNSTEP; ++m_) fine_step(m_, NCH - 1, last);
+    } else
+#endif
+    {
+      epilogue(last, NCH - 1, 0);
+      epilogue(last, NCH - 1, 1);
+    }
     if constexpr (SKIPOUT) {
       build_skip_operands();
       fold_sat_in();
@@ -442,8 +541,17 @@ __global__ __launch_bounds__(256, 1) void k_cesr_x6(const float* __restrict__ X,
       for (int kb = 0; kb < 16; ++kb) {
         xh[kb] = yh[kb];
         xm[kb] = ym[kb];
-        xl[kb] = yl[kb];
+        if constexpr (!NEXT_FP8) xl[kb] = yl[kb];
       }
+#if QX_FP8
+      if constexpr (NEXT_FP8) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          xh8[gq] = yh8[gq];
+          xl8[gq] = yl8[gq];
+        }
+      }
+#endif
     }
   };
 

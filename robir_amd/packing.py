@@ -485,9 +485,17 @@ def repack_vis_x6_fp8(blob, device):
     return repack_x6_chunks_fp8(blob, device, ((128, 16), (256, 16), (256, 16), (256, 16), (256, 1)))
 
 
+def repack_softplus512_x6_fp8(blob, device, k_in):
+    """EXPERIMENT (csrc/cesr_x6.hip built with -DQX_FP8=1): the blob of pack_softplus512_x6 with the layers of K = 512 in the bf8 layout of
+    repack_x6_chunks_fp8; layer 0 (K = 64 / 192) and the skip layer (K = 576) keep rb_pack_layer_x6's layout."""
+    k0p, n3p = _pad16(k_in), _pad16(512 - k_in)
+    return repack_x6_chunks_fp8(blob, device, ((k0p, 32, False), (512, 32, True), (512, 32, True), (512, n3p // 16, True), (576, 32, False),
+                                               (512, 32, True), (512, 32, True), (512, 32, True), (512, 1, True)))
+
+
 def repack_x6_chunks_fp8(blob, device, layout):
     """A blob of exact-operand chunks (rb_pack_layer_x6: per chunk [16 bias floats][k-block][h | m | l][lane][8 halves]; `layout` = its (K,
-    number of chunks) runs) with the l pieces of every weight replaced by bf8 (e5m2) copies of the h and l pieces in the K = 128 order of
+    number of chunks[, convert]) runs) with the l pieces of every weight replaced by bf8 (e5m2) copies of the h and l pieces in the K = 128 order of
     v_mfma_f32_16x16x128_f8f6f4 (the products h.xl and l.xh of the 2^-22 class at twice the f16 rate).  Same size:
     per chunk [16 bias floats] + per group of 128 K: [k-block 0..3][h | m][lane][8 halves] (8 KB), [h8][2 planes][lane][16 bytes] (2 KB),
     [l8] (2 KB).  Byte 4 j + r of a lane's 32 is the K position of half 4 (j % 2) + r of k-block 4 G + j / 2 in the f16 planes: what
@@ -496,8 +504,12 @@ def repack_x6_chunks_fp8(blob, device, layout):
     src = blob.detach().cpu().numpy().view(np.uint16).copy()
     out = src.copy()
     pos = 0
-    for (K, nch) in layout:
+    for run in layout:
+        K, nch = run[0], run[1]
         cu16 = (16 + 24 * K) * 2                    # uint16 elements of a chunk: 16 bias floats + K/32 k-blocks x 3 planes x 64 lanes x 8 halves
+        if len(run) > 2 and not run[2]:             # a run that keeps rb_pack_layer_x6's own layout (layers whose K is not a multiple of 128)
+            pos += nch * cu16
+            continue
         for _ in range(nch):
             body = src[pos + 32:pos + cu16].reshape(K // 32, 3, 64, 8)
             dst = out[pos + 32:pos + cu16].reshape(K // 128, 6144)      # 12 KB per group

@@ -37,6 +37,8 @@ n = npts * nl
 p = ((torch.rand(npts, 3, generator=g) - 0.5) * 0.6).to(dev)
 sh = packing.pack_softplus512_x6({"net." + k: v for k, v in c["shadow_net"].items()}, "net.", 191, dev)
 no = packing.pack_softplus512_x6({"net." + k: v for k, v in c["normal_net"].items()}, "net.", 63, dev)
+if "fp8" in sys.argv[3:]:      # a library built with -DQX_FP8=1 (experiment): the K = 512 layers in the bf8 layout
+    sh, no = packing.repack_softplus512_x6_fp8(sh, dev, 191), packing.repack_softplus512_x6_fp8(no, dev, 63)
 mac_sh, mac_no = 1836032, 1836544
 t = timed(lambda: ops.cesr_net_x6_points(p, n, 2, sh, nl))
 out = [f"shadow {t:.3f} ms ({2 * mac_sh * n / t / 1e9 / 416.7:.3f})"]
