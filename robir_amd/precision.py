@@ -1,8 +1,9 @@
 """One switch for the arithmetic of every MLP kernel.
 
   ROBIR_PRECISION=exact  (default)  not narrower than the reference's fp32: the fused light-visibility kernel carries every
-                                    fp32 operand exactly as three f16 pieces (six f16 MFMA products per multiply-add, three fp32
-                                    accumulators: csrc/vis_diffuse_x6.hip), and so do the SDF network (values and reverse-mode
+                                    fp32 operand exactly as three f16 pieces (six MFMA products per multiply-add, three fp32
+                                    accumulators: csrc/vis_diffuse_x6.hip; since round 6 the two outer products of the 2^-22 class from bf8
+                                    copies of their operands, error against float64 unchanged: csrc/vis_diffuse_x6t.hip XT_FP8), and so do the SDF network (values and reverse-mode
                                     gradient), the colour network, the stand-alone visibility MLP, the 512-wide nets and the CESR
                                     nets (MLP mode "f16x6": csrc/sdf_x6.hip, sdf_back_x6.hip, color_x6.hip, vis_x6.hip, wide_x6.hip,
                                     cesr_x6.hip); the small auto-encoder decoders run on the f32-input MFMA.  ROBIR_MLP_PRECISION=fp32 puts every stand-alone MLP on the f32-input MFMA;
