@@ -479,13 +479,17 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_RUN(acc[1].c0, wh, X.h[1]);                       // 4
           if (H == 0) XT_EP(3); else XT_COPY(0);
           XT_FENCE;
+#ifndef XT_FP8_EP_AT6
+#define XT_FP8_EP_AT6 1     // the filler of position 5 (which also carries the four h refills) behind the bf8 MFMA of position 6: a single 32-cycle MFMA shadows its fillers better than the last of a run of four (-0.8 %, bit-identical); 0: at position 5
+#endif
           XT_RUN_REFILL(acc[1].c1, wh, X.m[1], 0);             // 5: the f16 h fragments' last use
-          if (H == 0) XT_EP(4); else XT_COPY(1);
+          if (!XT_FP8_EP_AT6) { if (H == 0) XT_EP(4); else XT_COPY(1); }
           XT_FENCE;
           XT_MFMA8(acc[1].c2, w8h, X.l8[1][H]);                // 6: the bf8 h fragment's last use
 #ifndef XT_ABL_NOLDS
           XT_LOAD8(w8h, nfrag, (1 - H) * 768 + 512)
 #endif
+          if (XT_FP8_EP_AT6) { if (H == 0) XT_EP(4); else XT_COPY(1); }
           XT_FENCE;
 #else
           XT_RUN(acc[0].c2, wh, X.l[0]);                       // 3
@@ -506,19 +510,23 @@ __global__ __launch_bounds__(256, 1) void k_dvis_x6t(const XtArgs a) {
           XT_RUN(acc[0].c2, wm, X.m[0]);                       // 8
           if (H == 0) XT_EP(6); else XT_COPY(3);
           XT_FENCE;
+#ifndef XT_FP8_EP_AT12
+#define XT_FP8_EP_AT12 0    // 1: the fillers of positions 9 / 11 behind the bf8 MFMAs of positions 11 / 12 (XT_FP8 only)
+#endif
           XT_RUN(acc[1].c1, wm, X.h[1]);                       // 9
-          if (H == 0) XT_EP(7); else XT_COPY(4);
+          if (!(XT_FP8 && XT_FP8_EP_AT12)) { if (H == 0) XT_EP(7); else XT_COPY(4); }
           XT_FENCE;
           XT_RUN_REFILL(acc[1].c2, wm, X.m[1], 1);             // 10: the m fragments' last use
           XT_FENCE;
 #if XT_FP8
           XT_MFMA8(acc[0].c2, w8l, X.h8[0][H]);                // 11: l.xh as one bf8 MFMA
-          if (H == 0) XT_EP(8); else XT_COPY(5);
+          if (XT_FP8_EP_AT12) { if (H == 0) XT_EP(7); else XT_COPY(4); } else { if (H == 0) XT_EP(8); else XT_COPY(5); }
           XT_FENCE;
           XT_MFMA8(acc[1].c2, w8l, X.h8[1][H]);                // 12: the bf8 l fragment's last use
 #ifndef XT_ABL_NOLDS
           XT_LOAD8(w8l, nfrag, (1 - H) * 768 + 640)
 #endif
+          if (XT_FP8_EP_AT12) { if (H == 0) XT_EP(8); else XT_COPY(5); }
           XT_FENCE;
 #else
           XT_RUN(acc[0].c2, wl, X.h[0]);                       // 11
