@@ -439,3 +439,10 @@ def test_round6_entry_points_on_empty_tiny_and_bad_inputs(dev):
     one = ops.cesr_net_f16_points(x, 1, 0, blob, 1)
     torch.cuda.synchronize()
     assert one.shape == (1, 3) and bool(torch.isfinite(one).all())
+    # the two-tile light-visibility kernel names its weight layout through scale_log2 (8 = the bf8 layout of packing.repack_x6_chunks_fp8 since
+    # round 6, 0 = rb_pack_layer_x6's own for a library built with -DXT_FP8=0): the other name is refused before any launch
+    if ops.DVIS_X6_FP8:
+        z = torch.zeros(4096, device=dev)
+        rc = L.rb_dvis_fused_x6t(ptr(z), None, c_long(1), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), c_int(8), c_int(4), c_int(0), c_int(0),
+                                 ptr(z), None, sp())
+        assert rc != 0 and b"bf8 weight layout" in L.rb_last_error()
